@@ -1,0 +1,92 @@
+"""Seeded input recipes shared by make_golden.py (runs beside the reference, in
+the build container) and by the parity tests (run anywhere).  Pure numpy; the
+expected outputs live in the committed ``*.npz`` files next to this module."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def msda_inputs(seed, batch, shapes, heads, head_dim, num_query, points, lo=-0.25, hi=1.25):
+    """Random operands of the core op (a6).
+
+    value f32[B, sum(h*w), heads, head_dim]; loc f32[B,Nq,heads,L,P,2] uniform in
+    [lo,hi] (so a good share of the corners fall outside the map); attention
+    weights = softmax over L*P of N(0,1); grad_out N(0,1).
+    """
+    rng = np.random.default_rng(seed)
+    shapes = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
+    nlev = shapes.shape[0]
+    nkeys = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = rng.standard_normal((batch, nkeys, heads, head_dim)).astype(np.float32)
+    loc = rng.uniform(lo, hi, (batch, num_query, heads, nlev, points, 2)).astype(np.float32)
+    logits = rng.standard_normal((batch, num_query, heads, nlev * points))
+    logits -= logits.max(-1, keepdims=True)
+    w = np.exp(logits)
+    w /= w.sum(-1, keepdims=True)
+    w = w.reshape(batch, num_query, heads, nlev, points).astype(np.float32)
+    grad_out = rng.standard_normal((batch, num_query, heads * head_dim)).astype(np.float32)
+    lsi = np.concatenate([[0], np.cumsum(shapes[:, 0] * shapes[:, 1])[:-1]]).astype(np.int64)
+    return dict(value=value, shapes=shapes, level_start=lsi, loc=loc, w=w, grad_out=grad_out)
+
+
+MSDA_CASES = {
+    # name: kwargs of msda_inputs
+    'small_2lvl': dict(seed=11, batch=2, shapes=[[7, 7], [5, 4]], heads=4, head_dim=8,
+                       num_query=37, points=4),
+    'odd_dim': dict(seed=12, batch=1, shapes=[[3, 9]], heads=2, head_dim=5, num_query=19, points=3),
+    'vocc': dict(seed=13, batch=6, shapes=[[14, 14]], heads=8, head_dim=96, num_query=155,
+                 points=8),
+}
+
+# grids whose projection / visibility is pinned: (bev_z, bev_h, bev_w)
+GRIDS = {'vocc': (4, 15, 15), 'c1': (4, 16, 16), 'c2': (16, 50, 50)}
+
+
+def small_layer_cfg(dims=32, heads=4, points=8, ffn=64):
+    """Encoder-layer config at reduced width (the reference classes accept it)."""
+    return dict(
+        type='VoxelFormerLayer',
+        attn_cfgs=[dict(type='SpatialCrossAttention', pc_range=list(PC_RANGE), embed_dims=dims,
+                        deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=dims,
+                                                  num_heads=heads, num_points=points,
+                                                  num_levels=1))],
+        feedforward_channels=ffn, ffn_dropout=0.1,
+        ffn_cfgs=dict(type='FFN', embed_dims=dims, feedforward_channels=ffn, num_fcs=2,
+                      ffn_drop=0.1, act_cfg=dict(type='ReLU', inplace=True)),
+        operation_order=('cross_attn', 'norm', 'ffn', 'norm'))
+
+
+PC_RANGE = (-6.0, -6.0, -1.5, 6.0, 6.0, 2.0)
+
+
+def small_encoder_cfg(dims=32, heads=4, points=8, ffn=64, layers=2):
+    return dict(type='VoxelFormerEncoder', num_layers=layers, pc_range=list(PC_RANGE),
+                num_points_in_voxel=4, return_intermediate=False,
+                transformerlayers=small_layer_cfg(dims, heads, points, ffn))
+
+
+def vocc_encoder_cfg(dims=768):
+    """The encoder dict of projects/configs/verformer/vocc.py:110-137, restated."""
+    return dict(
+        type='VoxelFormerEncoder', num_layers=3, pc_range=list(PC_RANGE), num_points_in_voxel=4,
+        return_intermediate=False,
+        transformerlayers=dict(
+            type='VoxelFormerLayer',
+            attn_cfgs=[dict(type='SpatialCrossAttention', pc_range=list(PC_RANGE),
+                            deformable_attention=dict(type='MSDeformableAttention3D',
+                                                      embed_dims=dims, num_points=8, num_levels=1),
+                            embed_dims=dims)],
+            feedforward_channels=dims * 2, ffn_dropout=0.1,
+            operation_order=('cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def vocc_transformer_cfg(dims=768, decoder=None):
+    return dict(type='VoxelPerceptionTransformer', rotate_prev_bev=True, use_shift=True,
+                use_can_bus=True, embed_dims=dims, decoder_on_bev=False,
+                encoder=vocc_encoder_cfg(dims), decoder=decoder)

@@ -1,0 +1,151 @@
+/*
+ * ver_ops.h -- C ABI of the MI355X (gfx950) kernels for VER's 2D->3D lifting path.
+ *
+ * Drop-in boundary.  The reference (DefaultRui/VLN-VER) is pure Python; the only native
+ * entry points on its hot path are two symbols of the third-party mmcv-full 1.4.0 `_ext`
+ * library, loaded at
+ *   projects/mmdet3d_plugin/bevformer/modules/multi_scale_deformable_attn_function.py:11-12
+ * and called at :118-124 (forward) and :150-160 (backward).  `ver_msda_forward` /
+ * `ver_msda_backward` below are exactly those two calls with torch tensors replaced by raw
+ * device pointers + sizes.  The remaining entry points replace Python/torch code of the
+ * reference that sits on the same path (file:line cited per function) with fused kernels.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - buffers are dense, row-major, in the index order written in the comment;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it
+ *     (no allocation, no synchronisation, no global state besides the last-error string);
+ *   - return value: 0 on success, negative VER_E* on failure; `ver_last_error()` returns a
+ *     thread-local description of the last failure;
+ *   - dtype: fp32 everywhere (the reference forces fp32 on this op:
+ *     multi_scale_deformable_attn_function.py:93 `custom_fwd(cast_inputs=torch.float32)`),
+ *     except `value_dtype` where noted (VER_F32 = 0, VER_BF16 = 1: value stored as bf16,
+ *     arithmetic still fp32).
+ */
+#ifndef VER_OPS_H
+#define VER_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VER_ABI_VERSION 1
+
+#define VER_OK            0
+#define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
+#define VER_EUNSUPPORTED -2   /* shape outside what the fused kernels are built for   */
+#define VER_ELAUNCH      -3   /* HIP reported an error at launch                      */
+
+#define VER_F32  0
+#define VER_BF16 1
+
+int         ver_abi_version(void);
+const char* ver_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * mmcv op boundary: ext_module.ms_deform_attn_forward(value, value_spatial_shapes,
+ *   value_level_start_index, sampling_locations, attention_weights, im2col_step)
+ *   (multi_scale_deformable_attn_function.py:118-124).
+ *
+ *   value       f32 [B, num_keys, heads, head_dim]
+ *   shapes_hw   i64 [levels, 2]   (h, w) per level            (device, like the reference)
+ *   level_start i64 [levels]
+ *   loc         f32 [B, Nq, heads, levels, points, 2]   (x, y) normalised to [0,1]
+ *   attn_w      f32 [B, Nq, heads, levels, points]
+ *   out         f32 [B, Nq, heads*head_dim]              (written, need not be zeroed)
+ * out[b,q,h,:] = sum_{l,p} attn_w * bilinear(value_l[b,:,h,:], x = loc_x*W-0.5, y = loc_y*H-0.5),
+ * zero outside the map.  `im2col_step` of the reference only batches launches and has no
+ * numerical effect; it is accepted and ignored.
+ */
+int ver_msda_forward(const float* value, const int64_t* shapes_hw, const int64_t* level_start,
+                     const float* loc, const float* attn_w, float* out,
+                     int B, int num_keys, int heads, int head_dim, int levels, int points,
+                     int Nq, int im2col_step, void* stream);
+
+/* ext_module.ms_deform_attn_backward(value, shapes, level_start, loc, attn_w, grad_output,
+ *   grad_value, grad_sampling_loc, grad_attn_weight, im2col_step)
+ *   (multi_scale_deformable_attn_function.py:150-160).  As in the reference the three
+ *   gradient buffers are caller-allocated and ZERO-INITIALISED by the caller (:146-148);
+ *   grad_value is accumulated with atomics, grad_loc / grad_attn_w are written.
+ */
+int ver_msda_backward(const float* value, const int64_t* shapes_hw, const int64_t* level_start,
+                      const float* loc, const float* attn_w, const float* grad_out,
+                      float* grad_value, float* grad_loc, float* grad_attn_w,
+                      int B, int num_keys, int heads, int head_dim, int levels, int points,
+                      int Nq, int im2col_step, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Hit table: the per-viewpoint visibility structure shared by the three encoder layers.
+ *   uv        f32 [B, Ncam, Nq, D, 2]  projected, normalised pixel coords (NOT clamped)
+ *   vis       u8  [B, Nq]              bit c set <=> camera c sees voxel n (any anchor)
+ *   vis_list  i32 [B, Ncam, Nq]        ascending voxel ids seen by camera c  (= the reference's
+ *                                      `indexes[c]`, spatial_cross_attention.py:139-141)
+ *   vis_cnt   i32 [B, Ncam]
+ *   own_list  i32 [B, Ncam, Nq]        voxels whose output row the (b,c) workgroups write:
+ *                                      lowest camera that sees it, or n % Ncam if none does
+ *   own_cnt   i32 [B, Ncam]
+ */
+
+/* VoxelFormerEncoder.get_reference_points('3d') + point_sampling
+ *   (bevformer/modules/voxel_encoder.py:54-83, 119-195) for B viewpoints at once, followed
+ *   by the list construction above (replaces the per-camera nonzero() host syncs of
+ *   spatial_cross_attention.py:139-142).  D = 1 (the reference never produces more anchors).
+ *   world2pixel f32 [B, Ncam, 4, 4] row-major; origin f32 [B, 3];
+ *   pc_range: HOST pointer to 6 floats (xmin,ymin,zmin,xmax,ymax,zmax);
+ *   flat voxel index n = k*H*W + j*W + i.
+ */
+int ver_project_points(const float* world2pixel, const float* origin, const float* pc_range,
+                       int B, int Ncam, int bev_z, int bev_h, int bev_w,
+                       float img_w, float img_h,
+                       float* uv, uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
+                       int32_t* own_list, int32_t* own_cnt, void* stream);
+
+/* Same lists from a caller-supplied mask in the reference's layout
+ *   bev_mask u8/bool [Ncam, B, Nq, D]  (spatial_cross_attention.py:87,139-141,170).
+ */
+int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
+                       uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
+                       int32_t* own_list, int32_t* own_cnt, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused multi-view gather = the body of SpatialCrossAttention.forward between the three
+ * input projections and output_proj (spatial_cross_attention.py:139-173 together with
+ * MSDeformableAttention3D.forward :345-398): per-camera re-batching, softmax over the
+ * points, location arithmetic, bilinear sampling, scatter-add over cameras and division by
+ * the camera count -- without padded rows, atomics or host syncs.
+ *
+ *   value   f32|bf16 [B, Ncam, map_h*map_w, heads, head_dim]   value_proj output
+ *   offsets f32 [B, Nq, heads, points, 2]     sampling_offsets output, in pixels (one level)
+ *   logits  f32 [B, Nq, heads, points]        attention_weights output, PRE-softmax
+ *   slots   f32 [B, Nq, heads*head_dim]       (written; every row, unseen voxels get zeros)
+ * slots[b,n] = (1/max(1,#cams seeing n)) * sum_{c sees n} sum_p softmax(logits)[p] *
+ *              bilinear(value[b,c], uv[b,c,n,p%D] + offsets[n,p]/(map_w,map_h))
+ * Supported: one feature level; head_dim in {8,16,32,64,96,128}; points in {4,8}; D | points;
+ *   map_h*map_w*head_dim*4 <= 75 KiB (one (camera, head) tile in LDS).
+ */
+int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
+                    const float* uv, const uint8_t* vis, const int32_t* own_list,
+                    const int32_t* own_cnt, float* slots,
+                    int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
+                    int map_h, int map_w, void* stream);
+
+/* Gradient of ver_sca_forward.
+ *   grad_slots   f32 [B, Nq, heads*head_dim]
+ *   grad_value   f32 [B, Ncam, map_h*map_w, heads, head_dim]  (written in full)
+ *   grad_offsets f32 [B, Nq, heads, points, 2]                (written in full)
+ *   grad_logits  f32 [B, Nq, heads, points]                   (written in full; softmax bwd fused)
+ * None of the outputs needs to be zeroed by the caller.
+ */
+int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
+                     const float* uv, const uint8_t* vis, const int32_t* vis_list,
+                     const int32_t* vis_cnt, const float* grad_slots,
+                     float* grad_value, float* grad_offsets, float* grad_logits,
+                     int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
+                     int map_h, int map_w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VER_OPS_H */

@@ -1,0 +1,67 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/ver_ops.h declares; the Python side fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from util import ROOT, pkg
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'ver_ops.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ver_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for need in ('ver_msda_forward', 'ver_msda_backward', 'ver_project_points',
+                 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward', 'ver_last_error',
+                 'ver_abi_version'):
+        assert need in names
+
+
+def test_library_exports_every_declared_symbol():
+    hip = pkg('hipops')
+    build = pkg('csrc.build')
+    build.build_hip(verbose=False)          # hipcc cross-compiles gfx950 without a GPU
+    assert os.path.exists(hip.LIB_PATH)
+    handle = ctypes.CDLL(hip.LIB_PATH)
+    for name in _declared():
+        assert hasattr(handle, name), name
+    assert sorted(hip.SYMBOLS) == _declared()
+    assert handle.ver_abi_version() == hip.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    """Null pointers / bad sizes are rejected before anything touches the device."""
+    hip = pkg('hipops')
+    lib = hip.lib()
+    rc = lib.ver_msda_forward(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 64, None)
+    assert rc == -1 and b'null' in lib.ver_last_error()
+    rc = lib.ver_sca_forward(None, 0, None, None, None, None, None, None, None, 1, 6, 1, 1, 8, 96,
+                             8, 14, 14, None)
+    assert rc == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_ops_refuse_cpu_tensors():
+    hip = pkg('hipops')
+    v = torch.zeros(1, 4, 1, 8)
+    with pytest.raises(RuntimeError, match='GPU'):
+        hip.MultiScaleDeformableAttnFunction_fp32.apply(
+            v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2),
+            torch.zeros(1, 1, 1, 1, 1), 64)
+    with pytest.raises(RuntimeError, match='GPU'):
+        hip.project_points(torch.zeros(1, 6, 4, 4), torch.zeros(1, 3), [-1, -1, -1, 1, 1, 1], 2, 2, 2)
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    hip = pkg('hipops')
+    monkeypatch.setattr(hip, '_lib', None)
+    monkeypatch.setattr(hip, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(hip.HipLibraryError, match='no CPU/PyTorch fallback'):
+        hip.lib()

@@ -1,0 +1,166 @@
+"""Module-level parity on the GPU: SpatialCrossAttention, MSDeformableAttention3D,
+VoxelFormerEncoder and VoxelPerceptionTransformer.get_voxel_features against the golden
+vectors generated from the reference and against the CPU oracle.  ``-m gpu``."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from util import close, golden, maxdiff, oracle, pkg, state_from
+
+warnings.filterwarnings('ignore')
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda'
+TOL = 1e-4
+
+
+def _noTF32():
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+
+
+def test_msda3d_module_matches_reference():
+    _noTF32()
+    r = pkg('registry')
+    pkg()
+    g = golden('msda3d_small')
+    att = r.build_attention(dict(type='MSDeformableAttention3D', embed_dims=32, num_heads=4,
+                                 num_levels=1, num_points=8)).eval()
+    att.load_state_dict(state_from(g), strict=True)
+    att.to(DEV)
+    out = att(T(g['query']).to(DEV), key=T(g['value']).to(DEV), value=T(g['value']).to(DEV),
+              reference_points=T(g['ref']).to(DEV), spatial_shapes=torch.tensor([[7, 7]], device=DEV),
+              level_start_index=torch.tensor([0], device=DEV))
+    assert maxdiff(out.cpu(), g['out']) < 2e-5
+
+
+def test_sca_module_matches_reference():
+    _noTF32()
+    r = pkg('registry')
+    pkg()
+    g = golden('sca_small')
+    sca = r.build_attention(dict(
+        type='SpatialCrossAttention', embed_dims=32, pc_range=list(cases.PC_RANGE),
+        deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=32, num_heads=4,
+                                  num_levels=1, num_points=8))).eval()
+    sca.load_state_dict(state_from(g), strict=True)
+    sca.to(DEV)
+    feat = T(g['feat']).to(DEV)
+    out = sca(T(g['query']).to(DEV), feat, feat, reference_points_cam=T(g['uv']).to(DEV),
+              bev_mask=T(g['mask']).to(DEV), spatial_shapes=torch.tensor([[7, 7]], device=DEV),
+              level_start_index=torch.tensor([0], device=DEV))
+    assert maxdiff(out.cpu(), g['out']) < 2e-5
+
+
+def _metas(w2p, org, idx):
+    return [{'sample_idx': 'scanA_vp%d' % b, 'world2pixel': w2p[b], 'origin': org[b]} for b in idx]
+
+
+def test_encoder_small_forward_backward_matches_reference():
+    _noTF32()
+    r = pkg('registry')
+    syn = pkg('synthetic')
+    pkg()
+    g = golden('encoder_small')
+    enc = r.build_transformer_layer_sequence(cases.small_encoder_cfg()).eval()
+    enc.load_state_dict(state_from(g), strict=True)
+    enc.to(DEV)
+    z, h, w = (int(v) for v in g['grid'])
+    nq = z * h * w
+    w2p, org = syn.camera_batch(2, seed=1)
+    shapes = torch.tensor([[14, 14]], device=DEV)
+    for b in range(2):
+        enc.zero_grad()
+        q = T(g['bev_query']).to(DEV).requires_grad_(True)                 # [Nq,1,C]
+        feat = T(g['feats'][b]).to(DEV).unsqueeze(2).requires_grad_(True)  # [6,196,1,C]
+        out = enc(q, feat, feat, bev_z=z, bev_h=h, bev_w=w, bev_pos=torch.zeros(nq, 1, 32, device=DEV),
+                  spatial_shapes=shapes, level_start_index=torch.tensor([0], device=DEV),
+                  prev_bev=None, shift=torch.zeros(1, 3, device=DEV), img_metas=_metas(w2p, org, [b]))
+        assert maxdiff(out.detach().cpu(), g['out'][b]) < 2e-5
+        gout = T(np.random.default_rng(40 + b).standard_normal(out.shape).astype(np.float32))
+        out.backward(gout.to(DEV))
+        assert close(q.grad.cpu(), g['grad_query'][b])
+        assert close(feat.grad.cpu(), g['grad_feats'][b])
+        for k, p in enc.named_parameters():
+            assert close(p.grad.cpu(), g['gp%d.%s' % (b, k)], atol=2e-4, rtol=1e-4), k
+    # both viewpoints in ONE batched call == the two bs=1 reference runs
+    q2 = T(g['bev_query']).to(DEV).repeat(1, 2, 1)
+    feat2 = T(g['feats']).to(DEV).permute(1, 2, 0, 3).contiguous()        # [6,196,2,C]
+    out2 = enc(q2, feat2, feat2, bev_z=z, bev_h=h, bev_w=w, bev_pos=None, spatial_shapes=shapes,
+               level_start_index=torch.tensor([0], device=DEV), prev_bev=None,
+               img_metas=_metas(w2p, org, [0, 1]))
+    assert maxdiff(out2.detach().cpu(), g['out'][:, 0]) < 2e-5
+
+
+def _vocc_transformer():
+    r = pkg('registry')
+    syn = pkg('synthetic')
+    pkg()
+    tr = r.build_transformer(cases.vocc_transformer_cfg()).eval()
+    syn.load_seeded(tr, 2)
+    return tr.to(DEV)
+
+
+@pytest.mark.parametrize('gname', ['vocc', 'c1', 'c2'])
+def test_get_voxel_features_matches_reference(gname):
+    """a1+a8 at full width (C=768), the three BASELINE.json grids; fp32, tolerance 1e-4."""
+    _noTF32()
+    syn = pkg('synthetic')
+    g = golden('encoder_vocc')
+    tr = _vocc_transformer()
+    z, h, w = cases.GRIDS[gname]
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    bq = T(np.random.default_rng(5).standard_normal((z * h * w, 768)).astype(np.float32)).to(DEV)
+    idx = [0] if gname == 'c2' else [0, 1]
+    step = 97 if gname == 'c2' else 7
+    with torch.no_grad():
+        for b in idx:
+            out = tr.get_voxel_features(T(feats[b]).to(DEV).unsqueeze(1), bq, z, h, w, bev_pos=None,
+                                        img_metas=_metas(w2p, org, [b]))
+            key = '%s_b%d_' % (gname, b)
+            assert out.shape == (1, z * h * w, 768)
+            assert maxdiff(out[0, ::step].cpu(), g[key + 'out']) < TOL
+            assert abs(float(out.norm()) - float(g[key + 'norm'])) < 2e-2
+        if gname != 'c2':     # batched call, device-resident camera tensors (the bench path)
+            mlvl = T(feats).to(DEV).permute(1, 0, 2, 3).contiguous()
+            out = tr.get_voxel_features(mlvl, bq, z, h, w, bev_pos=None,
+                                        world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+            for b in idx:
+                assert maxdiff(out[b, ::step].cpu(), g['%s_b%d_out' % (gname, b)]) < TOL
+
+
+def test_get_voxel_features_backward_matches_reference():
+    _noTF32()
+    syn = pkg('synthetic')
+    g = golden('encoder_vocc')
+    tr = _vocc_transformer()
+    z, h, w = cases.GRIDS['vocc']
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    for b in range(2):
+        tr.zero_grad()
+        bq = T(np.random.default_rng(5).standard_normal((z * h * w, 768)).astype(np.float32)).to(DEV)
+        bq.requires_grad_(True)
+        mlvl = T(feats[b]).to(DEV).unsqueeze(1).requires_grad_(True)
+        out = tr.get_voxel_features(mlvl, bq, z, h, w, bev_pos=None, img_metas=_metas(w2p, org, [b]))
+        gout = T(np.random.default_rng(50 + b).standard_normal(out.shape).astype(np.float32)).to(DEV)
+        out.backward(gout)
+        key = 'vocc_b%d_' % b
+        assert close(bq.grad[::9].cpu(), g[key + 'grad_query'], atol=2e-4, rtol=1e-4)
+        assert close(mlvl.grad[:, 0, ::7].cpu(), g[key + 'grad_feats'], atol=2e-4, rtol=1e-4)
+        names = [str(s) for s in g[key + 'grad_names']]
+        norms = g[key + 'grad_norms']
+        ours = dict(query=float(bq.grad.norm()), feats=float(mlvl.grad.norm()))
+        ours.update({k: float(p.grad.norm()) for k, p in tr.named_parameters() if p.grad is not None})
+        for name, want in zip(names, norms):
+            assert abs(ours[name] - want) <= 1e-3 * max(1.0, abs(want)), name
+
+
+def test_oracle_agrees_on_gpu_host():
+    """The CPU oracle gives the golden answer on this host too (its BLAS may differ)."""
+    from test_oracle_golden import test_get_voxel_features_full_width
+    test_get_voxel_features_full_width('vocc')

@@ -1,0 +1,297 @@
+"""Parity of the HIP kernels (through the C ABI, via ctypes) against the CPU oracle and the
+golden vectors.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances: forward 1e-4 absolute (north_star, fp32); gradients |a-b| <= 1e-4 + 1e-5*|b|
+(values reach O(100)); visibility masks / index lists bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from util import close, golden, maxdiff, oracle, oracle_slots, pkg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda'
+
+
+def _fn():
+    return pkg('hipops').MultiScaleDeformableAttnFunction_fp32
+
+
+# ------------------------------------------------------------------------------- a6: mmcv boundary
+@pytest.mark.parametrize('name', list(cases.MSDA_CASES))
+def test_msda_forward_backward_vs_golden_and_oracle(name):
+    o = oracle()
+    g = golden('msda_core_' + name)
+    c = cases.msda_inputs(**cases.MSDA_CASES[name])
+    value = T(c['value']).to(DEV).requires_grad_(True)
+    loc = T(c['loc']).to(DEV).requires_grad_(True)
+    w = T(c['w']).to(DEV).requires_grad_(True)
+    out = _fn().apply(value, T(c['shapes']).to(DEV), T(c['level_start']).to(DEV), loc, w, 64)
+    out.backward(T(c['grad_out']).to(DEV))
+    vc = T(c['value']).requires_grad_(True)
+    lc = T(c['loc']).requires_grad_(True)
+    wc = T(c['w']).requires_grad_(True)
+    ref = o.msda_core(vc, c['shapes'].tolist(), lc, wc)
+    ref.backward(T(c['grad_out']))
+    assert maxdiff(out.detach().cpu(), ref.detach()) < 2e-5
+    assert close(value.grad.cpu(), vc.grad)
+    assert close(loc.grad.cpu(), lc.grad)
+    assert close(w.grad.cpu(), wc.grad)
+    so, sv, sl = (5, 3, 5) if name == 'vocc' else (1, 1, 1)
+    assert maxdiff(out.detach().cpu()[:, ::so], g['out']) < 2e-5
+    assert close(value.grad.cpu()[:, ::sv], g['grad_value'])
+    assert close(loc.grad.cpu()[:, ::sl], g['grad_loc'])
+    assert close(w.grad.cpu()[:, ::sl], g['grad_w'])
+
+
+def test_msda_edge_cases():
+    """empty query set; every sample outside the map; NaN locations; one-pixel map."""
+    fn = _fn()
+    shapes = torch.tensor([[3, 4]], device=DEV)
+    lsi = torch.tensor([0], device=DEV)
+    value = torch.randn(2, 12, 2, 16, device=DEV)
+    out = fn.apply(value, shapes, lsi, torch.zeros(2, 0, 2, 1, 4, 2, device=DEV),
+                   torch.zeros(2, 0, 2, 1, 4, device=DEV), 64)
+    assert out.shape == (2, 0, 32)
+    w = torch.full((2, 5, 2, 1, 4), 0.25, device=DEV)
+    far = torch.full((2, 5, 2, 1, 4, 2), 7.5, device=DEV)
+    assert float(fn.apply(value, shapes, lsi, far, w, 64).abs().max()) == 0.0
+    assert float(fn.apply(value, shapes, lsi, -far, w, 64).abs().max()) == 0.0
+    nan = torch.full((2, 5, 2, 1, 4, 2), float('nan'), device=DEV)
+    assert float(fn.apply(value, shapes, lsi, nan, w, 64).abs().max()) == 0.0
+    # constant map: inside the map the bilinear weights sum to 1 -> output = const * sum(w)
+    const = torch.full((1, 12, 2, 16), 3.0, device=DEV)
+    mid = torch.rand(1, 7, 2, 1, 4, 2, device=DEV) * 0.5 + 0.25
+    w1 = torch.rand(1, 7, 2, 1, 4, device=DEV)
+    got = fn.apply(const, shapes, lsi, mid, w1, 64).view(1, 7, 2, 16)
+    want = 3.0 * w1.sum(-1).sum(-1)
+    assert maxdiff(got.cpu(), want[..., None].expand(-1, -1, -1, 16).cpu()) < 1e-5
+    one = torch.tensor([[1, 1]], device=DEV)
+    v1 = torch.randn(1, 1, 1, 8, device=DEV)
+    centre = torch.full((1, 1, 1, 1, 4, 2), 0.5, device=DEV)
+    got = fn.apply(v1, one, lsi, centre, torch.full((1, 1, 1, 1, 4), 0.25, device=DEV), 64)
+    assert maxdiff(got.cpu().view(-1), v1.cpu().view(-1)) < 1e-6
+
+
+def test_msda_linearity_at_full_size():
+    """Size-independent property on the vocc 50x50x16 shape (L = 6423 rows / camera):
+    the op is linear in value and in the attention weights."""
+    fn = _fn()
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    B, Nq = 6, 6423
+    shapes = torch.tensor([[14, 14]], device=DEV)
+    lsi = torch.tensor([0], device=DEV)
+    v1 = torch.randn(B, 196, 8, 96, generator=gen).to(DEV)
+    v2 = torch.randn(B, 196, 8, 96, generator=gen).to(DEV)
+    loc = (torch.rand(B, Nq, 8, 1, 8, 2, generator=gen) * 1.4 - 0.2).to(DEV)
+    w = torch.rand(B, Nq, 8, 1, 8, generator=gen).to(DEV)
+    a = fn.apply(v1, shapes, lsi, loc, w, 64)
+    b = fn.apply(v2, shapes, lsi, loc, w, 64)
+    ab = fn.apply(v1 * 2.0 + v2, shapes, lsi, loc, w, 64)
+    assert float((ab - (2.0 * a + b)).abs().max()) < 1e-4
+    half = fn.apply(v1, shapes, lsi, loc, w * 0.5, 64)
+    assert float((half - 0.5 * a).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------------------- a2 + a3: projection
+@pytest.mark.parametrize('gname', list(cases.GRIDS))
+def test_projection_visibility_and_lists(gname):
+    hip = pkg('hipops')
+    syn = pkg('synthetic')
+    o = oracle()
+    g = golden('point_sampling')
+    z, h, w = cases.GRIDS[gname]
+    nq = z * h * w
+    w2p, org = syn.camera_batch(2, seed=1)
+    hit = hip.project_points(T(w2p).to(DEV), T(org).to(DEV), cases.PC_RANGE, z, h, w)
+    torch.cuda.synchronize()
+    vis = hit.vis.cpu().numpy()
+    ref3d = o.reference_points_3d(z, h, w)
+    for b in range(2):
+        key = '%s_b%d_' % (gname, b)
+        want = np.unpackbits(g[key + 'mask'], axis=1)[:, :nq].astype(bool)        # reference's mask
+        got = ((vis[b][None, :] >> np.arange(6)[:, None]) & 1).astype(bool)
+        assert np.array_equal(got, want), 'visibility differs from the reference in %d voxels' % (
+            (got != want).sum())
+        uv_o, mask_o = o.point_sampling(ref3d, T(w2p[b]), T(org[b]), cases.PC_RANGE)
+        assert np.array_equal(got, mask_o.numpy())
+        assert maxdiff(hit.uv[b, :, :, 0].cpu(), uv_o) < 1e-5
+        step = 16 if gname == 'c2' else 1
+        assert maxdiff(hit.uv[b, :, ::step, 0].cpu(), g[key + 'uv']) < 1e-5
+        cnt = hit.vis_cnt[b].cpu().tolist()
+        assert cnt == g[key + 'hits'].tolist()
+        owned = []
+        for c in range(6):
+            lst = hit.vis_list[b, c, :cnt[c]].cpu().numpy()
+            assert np.array_equal(lst, np.nonzero(want[c])[0])          # = reference's indexes[c]
+            oc = int(hit.own_cnt[b, c])
+            owned.append(hit.own_list[b, c, :oc].cpu().numpy())
+            assert np.all(np.diff(owned[-1]) > 0)
+        allv = np.sort(np.concatenate(owned))
+        assert np.array_equal(allv, np.arange(nq))                      # every voxel owned once
+        lowest = np.where(want.any(0), want.argmax(0), np.arange(nq) % 6)
+        for c in range(6):
+            assert np.array_equal(owned[c], np.nonzero(lowest == c)[0])
+    assert hit.mask().shape == (6, 2, nq, 1)
+
+
+def test_projection_analytic_identity_camera():
+    """Known answer: world2pixel = K with no rotation: p=(x,y,z) -> u = (fx*x/z + cx)/1280."""
+    hip = pkg('hipops')
+    k = np.eye(4, dtype=np.float32)
+    k[0, 0] = k[1, 1] = 100.0
+    k[0, 2], k[1, 2] = 640.0, 512.0
+    w2p = np.tile(k, (1, 6, 1, 1))
+    org = np.zeros((1, 3), dtype=np.float32)
+    rng = (-1.0, -1.0, 0.0, 1.0, 1.0, 2.0)
+    hit = hip.project_points(T(w2p).to(DEV), T(org).to(DEV), rng, 2, 2, 2)
+    uv = hit.uv[0, 0, :, 0].cpu().numpy()
+    n = 0
+    for kz in range(2):
+        for j in range(2):
+            for i in range(2):
+                x, y, zz = -0.5 + i, -0.5 + j, 0.5 + kz
+                assert abs(uv[n, 0] - (100 * x / zz + 640) / 1280) < 1e-6
+                assert abs(uv[n, 1] - (100 * y / zz + 512) / 1024) < 1e-6
+                n += 1
+    assert hit.vis.cpu().tolist() == [[63] * 8]
+
+
+def test_hits_from_reference_layout_mask():
+    hip = pkg('hipops')
+    g = golden('sca_small')
+    mask = T(g['mask'])                    # [6,1,64,1]
+    hit = hip.hits_from_mask(T(g['uv']).to(DEV), mask.to(DEV))
+    m = mask[:, 0, :, 0].numpy()
+    cnt = hit.vis_cnt[0].cpu().tolist()
+    assert cnt == m.sum(1).tolist() and cnt[3] == 0
+    for c in range(6):
+        assert np.array_equal(hit.vis_list[0, c, :cnt[c]].cpu().numpy(), np.nonzero(m[c])[0])
+    assert maxdiff(hit.uv[0].cpu(), T(g['uv'])[:, 0]) == 0.0
+    # D = 2 anchors: a voxel is visible if any anchor is
+    mask2 = torch.zeros(6, 1, 10, 2, dtype=torch.bool)
+    mask2[1, 0, 3, 1] = True
+    mask2[4, 0, 3, 0] = True
+    hit2 = hip.hits_from_mask(torch.zeros(6, 1, 10, 2, 2, device=DEV), mask2.to(DEV))
+    assert int(hit2.vis[0, 3]) == (1 << 1) | (1 << 4) and int(hit2.vis[0].sum()) == 18
+
+
+# ------------------------------------------------------------------------------- a4 + a5 + a6: fused gather
+def _random_sca_case(seed, B, grid, heads, hd, P, map_hw=(14, 14), D=1):
+    syn = pkg('synthetic')
+    hip = pkg('hipops')
+    rng = np.random.default_rng(seed)
+    z, h, w = grid
+    nq = z * h * w
+    nk = map_hw[0] * map_hw[1]
+    w2p, org = syn.camera_batch(B, seed=1)
+    hit = hip.project_points(T(w2p).to(DEV), T(org).to(DEV), cases.PC_RANGE, z, h, w)
+    value = rng.standard_normal((B, 6, nk, heads, hd)).astype(np.float32)
+    offsets = (rng.standard_normal((B, nq, heads, P, 2)) * 3.0).astype(np.float32)
+    logits = rng.standard_normal((B, nq, heads, P)).astype(np.float32)
+    gslots = rng.standard_normal((B, nq, heads * hd)).astype(np.float32)
+    return hit, value, offsets, logits, gslots
+
+
+@pytest.mark.parametrize('heads,hd,P,grid', [(8, 96, 8, (4, 15, 15)), (4, 8, 8, (2, 6, 5)),
+                                             (2, 16, 4, (2, 6, 5)), (2, 32, 8, (3, 7, 7)),
+                                             (2, 64, 4, (2, 9, 8)), (1, 128, 8, (2, 6, 5))])
+def test_sca_gather_forward_backward_vs_oracle(heads, hd, P, grid):
+    hip = pkg('hipops')
+    o = oracle()
+    B = 3
+    hit, value, offsets, logits, gslots = _random_sca_case(7, B, grid, heads, hd, P)
+    v = T(value).to(DEV).requires_grad_(True)
+    of = T(offsets).to(DEV).requires_grad_(True)
+    lg = T(logits).to(DEV).requires_grad_(True)
+    slots = hip.sca_gather(v, of, lg, hit, 14, 14)
+    slots.backward(T(gslots).to(DEV))
+    mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()
+    vc, oc, lc = (T(value).requires_grad_(True), T(offsets).requires_grad_(True),
+                  T(logits).requires_grad_(True))
+    ref = oracle_slots(o, vc, oc, lc, hit.uv.cpu(), mask, (14, 14))
+    ref.backward(T(gslots))
+    assert maxdiff(slots.detach().cpu(), ref.detach()) < 2e-5
+    assert close(v.grad.cpu(), vc.grad)
+    assert close(of.grad.cpu(), oc.grad)
+    assert close(lg.grad.cpu(), lc.grad)
+    # unseen voxels produce exact zeros, forward is run-to-run deterministic
+    unseen = ~mask.any(1)
+    assert float(slots.detach().cpu()[unseen].abs().max()) == 0.0 if unseen.any() else True
+    again = hip.sca_gather(v.detach(), of.detach(), lg.detach(), hit, 14, 14)
+    assert torch.equal(again, slots.detach())
+
+
+def test_sca_gather_multi_camera_and_anchors():
+    """Hand-made masks: voxels seen by all 6 cameras, by none, a camera that sees nothing, and
+    D=2 Z-anchors (which the reference's MSDA3D supports although vocc produces D=1)."""
+    hip = pkg('hipops')
+    o = oracle()
+    rng = np.random.default_rng(9)
+    B, nq, heads, hd, P, D = 2, 50, 4, 8, 8, 2
+    mask = rng.uniform(size=(6, B, nq, D)) < 0.25
+    mask[:, :, :4] = False
+    mask[:, :, 4:8] = True
+    mask[2] = False
+    uv = rng.uniform(-0.1, 1.1, (6, B, nq, D, 2)).astype(np.float32)
+    hit = hip.hits_from_mask(T(uv).to(DEV), T(mask).to(DEV))
+    value = rng.standard_normal((B, 6, 49, heads, hd)).astype(np.float32)
+    offsets = (rng.standard_normal((B, nq, heads, P, 2)) * 2.0).astype(np.float32)
+    logits = rng.standard_normal((B, nq, heads, P)).astype(np.float32)
+    gs = rng.standard_normal((B, nq, heads * hd)).astype(np.float32)
+    v = T(value).to(DEV).requires_grad_(True)
+    of = T(offsets).to(DEV).requires_grad_(True)
+    lg = T(logits).to(DEV).requires_grad_(True)
+    slots = hip.sca_gather(v, of, lg, hit, 7, 7)
+    slots.backward(T(gs).to(DEV))
+    vc, oc, lc = (T(value).requires_grad_(True), T(offsets).requires_grad_(True),
+                  T(logits).requires_grad_(True))
+    m = T(mask).any(-1).permute(1, 0, 2)
+    ref = oracle_slots(o, vc, oc, lc, T(uv).permute(1, 0, 2, 3, 4), m, (7, 7))
+    ref.backward(T(gs))
+    assert maxdiff(slots.detach().cpu(), ref.detach()) < 2e-5
+    assert close(v.grad.cpu(), vc.grad)
+    assert close(of.grad.cpu(), oc.grad)
+    assert close(lg.grad.cpu(), lc.grad)
+    assert float(v.grad[:, 2].abs().max()) == 0.0          # blind camera gets a zero gradient tile
+
+
+def test_sca_gather_full_size_properties():
+    """50x50x16 grid (Nq = 40 000, chunked lists, atomic tile flush in backward):
+    linearity in value, and slots of a constant map = constant * (in-map weight mass)."""
+    hip = pkg('hipops')
+    hit, value, offsets, logits, gslots = _random_sca_case(11, 1, (16, 50, 50), 8, 96, 8)
+    v = T(value).to(DEV)
+    of = T(offsets).to(DEV)
+    lg = T(logits).to(DEV)
+    a = hip.sca_gather(v, of, lg, hit, 14, 14)
+    b = hip.sca_gather(v * -0.5, of, lg, hit, 14, 14)
+    assert float((b + 0.5 * a).abs().max()) < 1e-5
+    ones = hip.sca_gather(torch.ones_like(v), of, lg, hit, 14, 14)
+    assert float(ones.max()) <= 1.0 + 1e-5 and float(ones.min()) >= -1e-6
+    seen = (hit.vis[0] != 0)
+    assert int(seen.sum()) == 40000 - int((hit.vis[0] == 0).sum())
+    assert float(a[0][~seen].abs().max()) == 0.0
+    # backward at this size: d(sum slots * g)/d value is linear in g; compare two g's
+    vg = v.clone().requires_grad_(True)
+    g1 = T(gslots).to(DEV)
+    s = hip.sca_gather(vg, of, lg, hit, 14, 14)
+    (gv1,) = torch.autograd.grad(s, vg, g1, retain_graph=True)
+    (gv2,) = torch.autograd.grad(s, vg, 2.0 * g1)
+    assert close(gv2.cpu(), 2.0 * gv1.cpu(), atol=2e-4, rtol=1e-4)
+    # <g, J v> == <J^T g, v>  (adjoint identity, checks backward against forward at full size)
+    lhs = float((s.detach().double() * g1.double()).sum())
+    rhs = float((gv1.double() * v.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_errors_are_loud():
+    hip = pkg('hipops')
+    hit, value, offsets, logits, _ = _random_sca_case(1, 1, (2, 6, 5), 2, 8, 8)
+    bad = torch.zeros(1, 6, 196, 2, 24, device=DEV)          # head_dim 24 is not built
+    with pytest.raises(RuntimeError, match='head_dim 24'):
+        hip.sca_gather(bad, T(offsets).to(DEV), T(logits).to(DEV), hit, 14, 14)
+    with pytest.raises(RuntimeError, match='GPU'):
+        hip.sca_gather(T(value), T(offsets), T(logits), hit, 14, 14)

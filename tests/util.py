@@ -45,3 +45,30 @@ def close(a, b, atol=1e-4, rtol=1e-5):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return bool(((a - b).abs() <= atol + rtol * b.abs()).all())
+
+
+def oracle_slots(o, value, offsets, logits, uv, mask, map_hw):
+    """Camera-averaged gather ``slots`` [B,Nq,C] composed from the oracle's core op exactly as
+    the reference composes it (re-batch visible voxels per camera -> MSDA -> scatter-add ->
+    divide by the camera count; spatial_cross_attention.py:139-173,345-398).
+    value [B,Ncam,Nk,heads,hd]; offsets [B,Nq,heads,P,2] (pixels); logits [B,Nq,heads,P];
+    uv [B,Ncam,Nq,D,2]; mask bool [B,Ncam,Nq]."""
+    B, ncam, nk, heads, hd = value.shape
+    nq, P, D = offsets.shape[1], offsets.shape[3], uv.shape[3]
+    mh, mw = map_hw
+    norm = torch.tensor([float(mw), float(mh)], dtype=value.dtype)
+    out = []
+    for b in range(B):
+        aw = logits[b].softmax(-1)
+        off = (offsets[b] / norm).view(nq, heads, P // D, D, 2)
+        slots = value.new_zeros(nq, heads * hd)
+        for c in range(ncam):
+            idx = mask[b, c].nonzero().squeeze(-1)
+            if idx.numel() == 0:
+                continue
+            loc = (uv[b, c, idx][:, None, None, :, :] + off[idx]).reshape(len(idx), heads, 1, P, 2)
+            got = o.msda_core(value[b, c][None], [(mh, mw)], loc[None], aw[idx][None, :, :, None, :])
+            slots = slots.index_add(0, idx, got[0])
+        count = mask[b].sum(0).clamp(min=1).to(value.dtype)
+        out.append(slots / count[:, None])
+    return torch.stack(out)

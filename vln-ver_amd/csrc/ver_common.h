@@ -1,0 +1,83 @@
+// Shared device helpers for the gfx950 kernels of the VER lifting path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ver_ops.h"
+
+#define VER_WAVE 64
+
+int ver_fail(int code, const char* fmt, ...);           // ver_abi.hip
+int ver_check_launch(const char* what);                 // ver_abi.hip
+
+#define VER_REQUIRE(cond, code, ...)                     \
+    do {                                                 \
+        if (!(cond)) return ver_fail(code, __VA_ARGS__); \
+    } while (0)
+
+// Bilinear footprint of one sample on an H x W map, mmcv / Deformable-DETR convention
+// (SURVEY.md A.3): pixel coords x = loc_x*W - 0.5, y = loc_y*H - 0.5; the sample contributes
+// only if -1 < x < W and -1 < y < H; corners outside [0,W-1]x[0,H-1] contribute zero.
+struct Bilinear {
+    float w[4];   // weights of (y0,x0) (y0,x1) (y1,x0) (y1,x1); 0 for corners outside the map
+    int key[4];   // y*W + x of each corner, clamped into the map (safe to load from)
+    float gx[4];  // d w[k] / d x   (0 for invalid corners)
+    float gy[4];  // d w[k] / d y
+    bool any;
+};
+
+template <bool GRAD>
+__device__ __forceinline__ void bilinear_setup(float loc_x, float loc_y, int H, int W, Bilinear& s) {
+    const float x = loc_x * (float)W - 0.5f;
+    const float y = loc_y * (float)H - 0.5f;
+    s.any = (y > -1.0f) && (x > -1.0f) && (y < (float)H) && (x < (float)W);
+    if (!s.any) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s.w[k] = 0.0f;
+            s.key[k] = 0;
+            if (GRAD) {
+                s.gx[k] = 0.0f;
+                s.gy[k] = 0.0f;
+            }
+        }
+        return;
+    }
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float lx = x - xf, ly = y - yf;
+    const float hx = 1.0f - lx, hy = 1.0f - ly;
+    const bool vx0 = x0 >= 0, vx1 = x1 <= W - 1, vy0 = y0 >= 0, vy1 = y1 <= H - 1;
+    const int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : W - 1;
+    const int cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : H - 1;
+    const bool v00 = vy0 && vx0, v01 = vy0 && vx1, v10 = vy1 && vx0, v11 = vy1 && vx1;
+    s.w[0] = v00 ? hy * hx : 0.0f;
+    s.w[1] = v01 ? hy * lx : 0.0f;
+    s.w[2] = v10 ? ly * hx : 0.0f;
+    s.w[3] = v11 ? ly * lx : 0.0f;
+    s.key[0] = cy0 * W + cx0;
+    s.key[1] = cy0 * W + cx1;
+    s.key[2] = cy1 * W + cx0;
+    s.key[3] = cy1 * W + cx1;
+    if (GRAD) {
+        s.gx[0] = v00 ? -hy : 0.0f;
+        s.gx[1] = v01 ? hy : 0.0f;
+        s.gx[2] = v10 ? -ly : 0.0f;
+        s.gx[3] = v11 ? ly : 0.0f;
+        s.gy[0] = v00 ? -hx : 0.0f;
+        s.gy[1] = v01 ? -lx : 0.0f;
+        s.gy[2] = v10 ? hx : 0.0f;
+        s.gy[3] = v11 ? lx : 0.0f;
+    }
+}
+
+// Sum over the lanes of an aligned group of G lanes (G a power of two <= 64); every lane
+// of the group ends up with the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, VER_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -1,0 +1,209 @@
+"""ctypes binding of libver_hip.so (C ABI: include/ver_ops.h) + the autograd wrappers.
+
+There is NO fallback: if the library is missing or a tensor is not on the GPU these
+functions raise.  PyTorch is used only for device memory, the current HIP stream and
+autograd bookkeeping.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
+ABI_VERSION = 1
+SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
+           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward')
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libver_hip.so once; raise loudly when it is absent or stale."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                '%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name in SYMBOLS:
+            if not hasattr(handle, name):
+                raise HipLibraryError('%s does not export %s' % (LIB_PATH, name))
+        handle.ver_last_error.restype = ctypes.c_char_p
+        if handle.ver_abi_version() != ABI_VERSION:
+            raise HipLibraryError('libver_hip.so ABI %d != expected %d: rebuild'
+                                  % (handle.ver_abi_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().ver_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _gpu(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError('%s must be a GPU tensor: the VER ops only exist as HIP kernels' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+class MultiScaleDeformableAttnFunction_fp32(Function):
+    """Same call signature and gradient contract as the reference's wrapper of the mmcv op
+    (bevformer/modules/multi_scale_deformable_attn_function.py:90-163)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        value = _gpu(value, 'value', torch.float32)
+        loc = _gpu(sampling_locations, 'sampling_locations', torch.float32)
+        aw = _gpu(attention_weights, 'attention_weights', torch.float32)
+        shapes = _gpu(value_spatial_shapes, 'value_spatial_shapes').to(torch.int64)
+        lsi = _gpu(value_level_start_index, 'value_level_start_index').to(torch.int64)
+        bs, nk, heads, hd = value.shape
+        _, nq, _, nl, npt, _ = loc.shape
+        ctx.im2col_step = im2col_step
+        out = value.new_empty(bs, nq, heads * hd)
+        _check(lib().ver_msda_forward(_p(value), _p(shapes), _p(lsi), _p(loc), _p(aw), _p(out),
+                                      bs, nk, heads, hd, nl, npt, nq, int(im2col_step), _stream()),
+               'ver_msda_forward')
+        ctx.save_for_backward(value, shapes, lsi, loc, aw)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        bs, nk, heads, hd = value.shape
+        _, nq, _, nl, npt, _ = loc.shape
+        grad_value = torch.zeros_like(value)
+        grad_loc = torch.zeros_like(loc)
+        grad_aw = torch.zeros_like(aw)
+        go = _gpu(grad_output, 'grad_output').float().contiguous()
+        _check(lib().ver_msda_backward(_p(value), _p(shapes), _p(lsi), _p(loc), _p(aw), _p(go),
+                                       _p(grad_value), _p(grad_loc), _p(grad_aw), bs, nk, heads, hd,
+                                       nl, npt, nq, int(ctx.im2col_step), _stream()),
+               'ver_msda_backward')
+        return grad_value, None, None, grad_loc, grad_aw, None
+
+
+# the reference selects the fp32 variant for every dtype (spatial_cross_attention.py:388-391)
+MultiScaleDeformableAttnFunction_fp16 = MultiScaleDeformableAttnFunction_fp32
+
+
+# ------------------------------------------------------------------------------------------
+class HitTable:
+    """Per-batch visibility structure (layout: include/ver_ops.h, "Hit table")."""
+
+    __slots__ = ('uv', 'vis', 'vis_list', 'vis_cnt', 'own_list', 'own_cnt', 'B', 'Ncam', 'Nq', 'D')
+
+    def __init__(self, B, Ncam, Nq, D, device):
+        self.B, self.Ncam, self.Nq, self.D = B, Ncam, Nq, D
+        self.uv = torch.empty(B, Ncam, Nq, D, 2, dtype=torch.float32, device=device)
+        self.vis = torch.empty(B, Nq, dtype=torch.uint8, device=device)
+        self.vis_list = torch.empty(B, Ncam, Nq, dtype=torch.int32, device=device)
+        self.vis_cnt = torch.empty(B, Ncam, dtype=torch.int32, device=device)
+        self.own_list = torch.empty(B, Ncam, Nq, dtype=torch.int32, device=device)
+        self.own_cnt = torch.empty(B, Ncam, dtype=torch.int32, device=device)
+
+    def mask(self):
+        """bool [Ncam, B, Nq, 1] in the reference's bev_mask layout (for inspection/tests)."""
+        bits = torch.arange(self.Ncam, device=self.vis.device, dtype=torch.uint8)
+        m = (self.vis[None] >> bits[:, None, None]) & 1
+        return m.bool().unsqueeze(-1)
+
+
+def project_points(world2pixel, origin, pc_range, bev_z, bev_h, bev_w, img_w=1280.0, img_h=1024.0):
+    """get_reference_points('3d') + point_sampling + list building for B viewpoints
+    (voxel_encoder.py:54-83,119-195).  world2pixel f32[B,Ncam,4,4], origin f32[B,3]."""
+    w2p = _gpu(world2pixel, 'world2pixel', torch.float32)
+    org = _gpu(origin, 'origin', torch.float32)
+    B, ncam = w2p.shape[0], w2p.shape[1]
+    nq = bev_z * bev_h * bev_w
+    hit = HitTable(B, ncam, nq, 1, w2p.device)
+    rng = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
+    _check(lib().ver_project_points(_p(w2p), _p(org), rng, B, ncam, bev_z, bev_h, bev_w,
+                                    ctypes.c_float(img_w), ctypes.c_float(img_h), _p(hit.uv),
+                                    _p(hit.vis), _p(hit.vis_list), _p(hit.vis_cnt), _p(hit.own_list),
+                                    _p(hit.own_cnt), _stream()), 'ver_project_points')
+    return hit
+
+
+def hits_from_mask(reference_points_cam, bev_mask):
+    """Hit table from tensors in the reference's layout: reference_points_cam
+    [Ncam,B,Nq,D,2], bev_mask [Ncam,B,Nq,D] (spatial_cross_attention.py:86-87)."""
+    ncam, B, nq, D = bev_mask.shape
+    mask = _gpu(bev_mask, 'bev_mask').to(torch.uint8).contiguous()
+    hit = HitTable(B, ncam, nq, D, mask.device)
+    hit.uv.copy_(reference_points_cam.to(torch.float32).permute(1, 0, 2, 3, 4))
+    _check(lib().ver_hits_from_mask(_p(mask), B, ncam, nq, D, _p(hit.vis), _p(hit.vis_list),
+                                    _p(hit.vis_cnt), _p(hit.own_list), _p(hit.own_cnt), _stream()),
+           'ver_hits_from_mask')
+    return hit
+
+
+class SCAGatherFunction(Function):
+    """slots = fused multi-view gather (ver_sca_forward / ver_sca_backward)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, value, offsets, logits, hit, map_h, map_w):
+        value = _gpu(value, 'value', torch.float32)
+        offsets = _gpu(offsets, 'offsets', torch.float32)
+        logits = _gpu(logits, 'logits', torch.float32)
+        B, ncam, nk, heads, hd = value.shape
+        points = logits.shape[-1]
+        nq = hit.Nq
+        assert nk == map_h * map_w and B == hit.B and ncam == hit.Ncam
+        assert offsets.shape == (B, nq, heads, points, 2) and logits.shape == (B, nq, heads, points)
+        slots = value.new_empty(B, nq, heads * hd)
+        _check(lib().ver_sca_forward(_p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis),
+                                     _p(hit.own_list), _p(hit.own_cnt), _p(slots), B, ncam, nq, hit.D,
+                                     heads, hd, points, map_h, map_w, _stream()), 'ver_sca_forward')
+        ctx.save_for_backward(value, offsets, logits)
+        ctx.hit, ctx.map_hw = hit, (map_h, map_w)
+        return slots
+
+    @staticmethod
+    @once_differentiable
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_slots):
+        value, offsets, logits = ctx.saved_tensors
+        hit = ctx.hit
+        map_h, map_w = ctx.map_hw
+        B, ncam, nk, heads, hd = value.shape
+        points = logits.shape[-1]
+        gs = _gpu(grad_slots, 'grad_slots').float().contiguous()
+        g_value = torch.empty_like(value)
+        g_off = torch.empty_like(offsets)
+        g_log = torch.empty_like(logits)
+        _check(lib().ver_sca_backward(_p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis),
+                                      _p(hit.vis_list), _p(hit.vis_cnt), _p(gs), _p(g_value),
+                                      _p(g_off), _p(g_log), B, ncam, hit.Nq, hit.D, heads, hd, points,
+                                      map_h, map_w, _stream()), 'ver_sca_backward')
+        return g_value, g_off, g_log, None, None, None
+
+
+def sca_gather(value, offsets, logits, hit, map_h, map_w):
+    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w)

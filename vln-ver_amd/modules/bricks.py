@@ -1,0 +1,126 @@
+"""The few mmcv building blocks the lifting path constructs (restated from the published
+behaviour of mmcv-full 1.4.0; mmcv is not vendored by the
+reference).  Parameter names are the compatibility surface: ``layers.0.0.*``, ``layers.1.*``."""
+import copy
+
+import torch.nn as nn
+
+from ..registry import FEEDFORWARD_NETWORK, USING_MMCV, build_transformer_layer
+
+
+class BaseModule(nn.Module):
+    """nn.Module carrying ``init_cfg`` (mmcv.runner.BaseModule)."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self._is_init = False
+        self.init_cfg = copy.deepcopy(init_cfg)
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+        self._is_init = True
+
+
+class ModuleList(BaseModule, nn.ModuleList):
+    def __init__(self, modules=None, init_cfg=None):
+        BaseModule.__init__(self, init_cfg)
+        nn.ModuleList.__init__(self, modules)
+
+
+class Sequential(BaseModule, nn.Sequential):
+    def __init__(self, *args, init_cfg=None):
+        BaseModule.__init__(self, init_cfg)
+        nn.Sequential.__init__(self, *args)
+
+
+def build_norm_layer(cfg, num_features):
+    """-> (name, layer); only LayerNorm is used on this path
+    (custom_base_transformer_layer.py:163 with norm_cfg=dict(type='LN'))."""
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    if typ != 'LN':
+        raise KeyError('norm layer %s not available on the lifting path' % typ)
+    cfg.pop('requires_grad', None)
+    return 'ln', nn.LayerNorm(num_features, **cfg)
+
+
+def build_activation_layer(cfg):
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    table = {'ReLU': nn.ReLU, 'GELU': nn.GELU, 'LeakyReLU': nn.LeakyReLU}
+    if typ not in table:
+        raise KeyError('activation %s not available' % typ)
+    return table[typ](**cfg)
+
+
+class FFN(BaseModule):
+    """Linear -> act -> drop (x num_fcs-1) -> Linear -> drop, plus identity."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert num_fcs >= 2, 'num_fcs should be no less than 2. got %s.' % num_fcs
+        self.embed_dims = embed_dims
+        self.feedforward_channels = feedforward_channels
+        self.num_fcs = num_fcs
+        layers = []
+        in_channels = embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(Sequential(nn.Linear(in_channels, feedforward_channels),
+                                     build_activation_layer(act_cfg), nn.Dropout(ffn_drop)))
+            in_channels = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = Sequential(*layers)
+        drop = (dropout_layer or {}).get('drop_prob', 0.) if dropout_layer else 0.
+        self.dropout_layer = nn.Dropout(drop) if drop else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+if not USING_MMCV:
+    FEEDFORWARD_NETWORK.register_module(module=FFN)
+
+
+class TransformerLayerSequence(BaseModule):
+    """``num_layers`` deep copies of one layer config (mmcv TransformerLayerSequence)."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, list) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = ModuleList()
+        for i in range(num_layers):
+            self.layers.append(build_transformer_layer(transformerlayers[i]))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    if module is None:
+        return
+    if getattr(module, 'weight', None) is not None:
+        (nn.init.xavier_uniform_ if distribution == 'uniform' else nn.init.xavier_normal_)(
+            module.weight, gain=gain)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)

@@ -1,0 +1,160 @@
+"""VERFormer encoder on the MI355X kernels.
+
+Registry names, constructor kwargs, forward signatures and state-dict keys follow the
+reference's bevformer/modules/voxel_encoder.py:30-464.  Differences in *how*:
+
+* voxel centres, camera projection, visibility and the per-camera index lists are produced by
+  one device-side call (``ver_project_points``) for the whole batch, once per forward and
+  shared by the layers -- the reference re-reads JSON + pickle from disk every forward
+  (:121-135) and later syncs six ``nonzero()`` calls per layer;
+* camera matrices come from ``img_metas`` through a caching :class:`CameraStore`, or directly
+  as ``world2pixel`` / ``origin`` tensors in ``**kwargs`` (the bench path: no host work);
+* any batch size (the reference is bs=1 only).
+"""
+import torch
+
+from .. import hipops
+from ..camera_store import CameraStore
+from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
+from .bricks import TransformerLayerSequence
+from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
+
+IMG_W = 1280.0   # hard-coded in the reference, voxel_encoder.py:179
+IMG_H = 1024.0   # voxel_encoder.py:180
+
+
+@TRANSFORMER_LAYER_SEQUENCE.register_module(force=True)
+class VoxelFormerEncoder(TransformerLayerSequence):
+
+    def __init__(self, *args, pc_range=None, num_points_in_pillar=None, num_points_in_voxel=1,
+                 return_intermediate=False, dataset_type='nuscenes', camera_root=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.return_intermediate = return_intermediate
+        self.num_points_in_voxel = num_points_in_voxel    # accepted, never used (as upstream)
+        self.pc_range = pc_range
+        self.fp16_enabled = False
+        self.camera_store = CameraStore(camera_root)
+
+    @staticmethod
+    def get_reference_points(bev_z, bev_h, bev_w, num_points_in_voxel=1, dim='3d', bs=1,
+                             device='cuda', dtype=torch.float):
+        """Normalised voxel centres, z-major flattening (reference :54-115).  The forward path
+        does not call this (the projection kernel generates the centres itself); kept as API."""
+        zs = torch.linspace(0.5, bev_z - 0.5, bev_z, dtype=dtype, device=device) / bev_z
+        ys = torch.linspace(0.5, bev_h - 0.5, bev_h, dtype=dtype, device=device) / bev_h
+        xs = torch.linspace(0.5, bev_w - 0.5, bev_w, dtype=dtype, device=device) / bev_w
+        full = (bev_z, bev_h, bev_w)
+        pts = torch.stack([xs.view(1, 1, -1).expand(full), ys.view(1, -1, 1).expand(full),
+                           zs.view(-1, 1, 1).expand(full)], -1).reshape(-1, 3)
+        if dim == '3d':
+            return pts[None, None].repeat(bs, 1, 1, 1)          # [bs, D=1, Nq, 3]
+        if dim == '2d':
+            return pts[None, :, None].repeat(bs, 1, 1, 1)       # [bs, Nq, 1, 3]
+        raise ValueError('dim must be "3d" or "2d"')
+
+    def _cameras(self, bs, device, kwargs):
+        w2p, org = kwargs.get('world2pixel'), kwargs.get('origin')
+        if w2p is None or org is None:
+            metas = kwargs['img_metas']
+            if len(metas) != bs:
+                raise ValueError('img_metas has %d entries for batch size %d' % (len(metas), bs))
+            w_np, o_np = self.camera_store.batch(metas)
+            w2p = torch.from_numpy(w_np).to(device, non_blocking=True)
+            org = torch.from_numpy(o_np).to(device, non_blocking=True)
+        return w2p.to(torch.float32), org.to(torch.float32)
+
+    def hit_table(self, bev_z, bev_h, bev_w, bs, device, **kwargs):
+        w2p, org = self._cameras(bs, device, kwargs)
+        return hipops.project_points(w2p, org, self.pc_range, bev_z, bev_h, bev_w, IMG_W, IMG_H)
+
+    def point_sampling(self, reference_points, pc_range, img_metas, bev_zhw=None):
+        """API twin of the reference method (:119-195): -> (reference_points_cam
+        [Ncam,bs,Nq,1,2], bev_mask [Ncam,bs,Nq,1]).  ``reference_points`` only supplies
+        device/batch; the kernel regenerates the centres from the grid shape."""
+        bs, _, nq, _ = reference_points.shape
+        if bev_zhw is None:
+            raise ValueError('bev_zhw=(Z,H,W) is required: centres are generated on the device')
+        z, h, w = bev_zhw
+        assert z * h * w == nq
+        w2p, org = self._cameras(bs, reference_points.device, dict(img_metas=img_metas))
+        hit = hipops.project_points(w2p, org, pc_range, z, h, w, IMG_W, IMG_H)
+        return hit.uv.permute(1, 0, 2, 3, 4), hit.mask()
+
+    def forward(self, bev_query, key, value, *args, bev_z=None, bev_h=None, bev_w=None,
+                bev_pos=None, spatial_shapes=None, level_start_index=None, valid_ratios=None,
+                prev_bev=None, shift=0., **kwargs):
+        """bev_query [Nq,bs,C]; key/value [Ncam,Nk,bs,C] -> [bs,Nq,C] (reference :197-296)."""
+        if prev_bev is not None:
+            raise NotImplementedError('prev_bev is always None on the VER path (voxelformer.py:294)')
+        bs = bev_query.size(1)
+        hit = kwargs.pop('hit_table', None)
+        if hit is None:
+            hit = self.hit_table(bev_z, bev_h, bev_w, bs, bev_query.device, **kwargs)
+        map_hw = kwargs.pop('map_hw', None)
+        if map_hw is None:
+            hw = spatial_shapes.reshape(-1, 2)[0].tolist()
+            map_hw = (int(hw[0]), int(hw[1]))
+        kwargs.pop('world2pixel', None)
+        kwargs.pop('origin', None)
+        output = bev_query.permute(1, 0, 2)
+        bev_pos = bev_pos.permute(1, 0, 2) if bev_pos is not None else None
+        intermediate = []
+        for layer in self.layers:
+            output = layer(output, key, value, *args, bev_pos=bev_pos, bev_z=bev_z, bev_h=bev_h,
+                           bev_w=bev_w, spatial_shapes=spatial_shapes,
+                           level_start_index=level_start_index,
+                           reference_points_cam=hit.uv.permute(1, 0, 2, 3, 4), hit_table=hit,
+                           map_hw=map_hw, prev_bev=None, **kwargs)
+            if self.return_intermediate:
+                intermediate.append(output)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output
+
+
+@TRANSFORMER_LAYER.register_module(force=True)
+class VoxelFormerLayer(MyCustomBaseTransformerLayer):
+    """cross_attn -> norm -> ffn -> norm (vocc.py:136-137); reference :300-464."""
+
+    def __init__(self, attn_cfgs, feedforward_channels, ffn_dropout=0.0, operation_order=None,
+                 act_cfg=dict(type='ReLU', inplace=True), norm_cfg=dict(type='LN'), ffn_num_fcs=2,
+                 **kwargs):
+        super().__init__(attn_cfgs=attn_cfgs, feedforward_channels=feedforward_channels,
+                         ffn_dropout=ffn_dropout, operation_order=operation_order, act_cfg=act_cfg,
+                         norm_cfg=norm_cfg, ffn_num_fcs=ffn_num_fcs, **kwargs)
+        self.fp16_enabled = False
+
+    def forward(self, query, key=None, value=None, bev_pos=None, query_pos=None, key_pos=None,
+                attn_masks=None, query_key_padding_mask=None, key_padding_mask=None, ref_2d=None,
+                ref_3d=None, bev_z=None, bev_h=None, bev_w=None, reference_points_cam=None,
+                mask=None, spatial_shapes=None, level_start_index=None, prev_bev=None, **kwargs):
+        norm_index = attn_index = ffn_index = 0
+        identity = query
+        if attn_masks is None:
+            attn_masks = [None for _ in range(self.num_attn)]
+        for layer in self.operation_order:
+            if layer == 'self_attn':
+                query = self.attentions[attn_index](
+                    query, prev_bev, prev_bev, identity if self.pre_norm else None,
+                    query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
+                    key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
+                    spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
+                    level_start_index=torch.tensor([0], device=query.device), **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'norm':
+                query = self.norms[norm_index](query)
+                norm_index += 1
+            elif layer == 'cross_attn':
+                query = self.attentions[attn_index](
+                    query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
+                    key_pos=key_pos, reference_points=ref_3d,
+                    reference_points_cam=reference_points_cam, mask=mask,
+                    attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                attn_index += 1
+                identity = query
+            elif layer == 'ffn':
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn_index += 1
+        return query

@@ -1,0 +1,127 @@
+"""VoxelPerceptionTransformer: entry of the lifting path (``get_voxel_features``) and, when a
+decoder is configured, the detection half of ``forward``.
+
+Reference: bevformer/modules/voxel_transformer.py:24-301 (same registry name, kwargs,
+parameter names ``level_embeds`` [4,C] / ``cams_embeds`` [6,C] / ``reference_points``).
+The reference hard-wires ``reshape(6, 1, 14, 14, 768)`` (:146); here camera count, batch, map
+size and width come from the tensor, and the features are laid out ``[bs, Ncam, Nk, C]``
+contiguous so the value projection and the gather kernel read them without a transpose."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..registry import TRANSFORMER, build_transformer_layer_sequence
+from .bricks import BaseModule, xavier_init
+from .spatial_cross_attention import MSDeformableAttention3D
+
+
+@TRANSFORMER.register_module(force=True)
+class VoxelPerceptionTransformer(BaseModule):
+
+    def __init__(self, num_feature_levels=4, num_cams=6, two_stage_num_proposals=300, encoder=None,
+                 decoder=None, embed_dims=256, rotate_prev_bev=True, use_shift=True,
+                 use_can_bus=True, can_bus_norm=True, use_cams_embeds=True,
+                 rotate_center=[100, 100], decoder_on_bev=False, voxel_2_bev_type='mlp', bev_z=1,
+                 **kwargs):
+        super().__init__(**kwargs)
+        self.encoder = build_transformer_layer_sequence(encoder)
+        self.decoder = build_transformer_layer_sequence(decoder) if decoder is not None else None
+        self.embed_dims = embed_dims
+        self.num_feature_levels = num_feature_levels
+        self.num_cams = num_cams
+        self.fp16_enabled = False
+        self.rotate_prev_bev = rotate_prev_bev
+        self.use_shift = use_shift
+        self.use_can_bus = use_can_bus
+        self.can_bus_norm = can_bus_norm
+        self.use_cams_embeds = use_cams_embeds
+        self.decoder_on_bev = decoder_on_bev
+        self.voxel_2_bev_type = voxel_2_bev_type
+        self.bev_z = bev_z
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.rotate_center = rotate_center
+        self.init_layers()
+
+    def init_layers(self):
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dims))
+        self.cams_embeds = nn.Parameter(torch.Tensor(self.num_cams, self.embed_dims))
+        if self.decoder is not None:
+            self.reference_points = nn.Linear(self.embed_dims, 3)
+        if self.decoder is not None and self.decoder_on_bev and self.voxel_2_bev_type == 'mlp':
+            mid = self.embed_dims * self.bev_z
+            self.voxel2bev = nn.Sequential(
+                nn.Linear(mid, mid), nn.LayerNorm(mid), nn.ReLU(inplace=True),
+                nn.Linear(mid, self.embed_dims), nn.LayerNorm(self.embed_dims), nn.ReLU(inplace=True))
+
+    def init_weights(self):
+        """xavier-uniform on every >1-D parameter, then the deformable-attention re-inits and
+        N(0,1) embeddings (reference :99-116)."""
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformableAttention3D) or hasattr(m, '_ver_deformable_init'):
+                m.init_weights()
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.cams_embeds)
+        if self.decoder is not None:
+            xavier_init(self.reference_points, distribution='uniform', bias=0.)
+
+    def get_voxel_features(self, mlvl_feats, bev_queries, bev_z, bev_h, bev_w,
+                           grid_length=[0.512, 0.512], bev_pos=None, prev_bev=None, **kwargs):
+        """mlvl_feats [Ncam, bs, Nk, C] (the detector's (6,1,196,768)); bev_queries [Nq, C]
+        -> bev_embed [bs, Nq, C]   (reference :119-185)."""
+        num_cam, bs, nk, c = mlvl_feats.shape
+        map_h = int(math.isqrt(nk))
+        if map_h * map_h != nk:
+            raise ValueError('feature maps must be square token grids, got %d tokens' % nk)
+        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        if bev_pos is not None:
+            bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
+        shift = bev_queries.new_zeros(1, 3)
+        feat = mlvl_feats.permute(1, 0, 2, 3)                          # [bs,Ncam,Nk,C]
+        embed = self.level_embeds[0].to(feat.dtype)
+        if self.use_cams_embeds:
+            embed = embed[None, :] + self.cams_embeds.to(feat.dtype)   # [Ncam,C]
+            feat = feat + embed[None, :, None, :]
+        else:
+            feat = feat + embed[None, None, None, :]
+        feat = feat.contiguous()
+        spatial_shapes = torch.as_tensor([[map_h, map_h]], dtype=torch.long, device=feat.device)
+        level_start_index = spatial_shapes.new_zeros((1,))
+        feat_flatten = feat.permute(1, 2, 0, 3)                        # view: [Ncam,Nk,bs,C]
+        return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_z=bev_z, bev_h=bev_h,
+                            bev_w=bev_w, bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                            level_start_index=level_start_index, prev_bev=prev_bev, shift=shift,
+                            map_hw=(map_h, map_h), **kwargs)
+
+    def forward(self, mlvl_feats, bev_queries, object_query_embed, bev_z, bev_h, bev_w,
+                grid_length=[0.512, 0.512], bev_pos=None, reg_branches=None, cls_branches=None,
+                prev_bev=None, **kwargs):
+        """Encoder + detection decoder (reference :188-301) ->
+        (voxel_embed [Nq,bs,C], inter_states, init_reference_out, inter_references_out)."""
+        if self.decoder is None:
+            raise RuntimeError('forward() needs a decoder; use get_voxel_features() for lifting only')
+        voxel_embed = self.get_voxel_features(mlvl_feats, bev_queries, bev_z, bev_h, bev_w,
+                                              grid_length=grid_length, bev_pos=bev_pos,
+                                              prev_bev=prev_bev, **kwargs)
+        bs = mlvl_feats.shape[1]
+        query_pos, query = torch.split(object_query_embed, self.embed_dims, dim=1)
+        query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
+        query = query.unsqueeze(0).expand(bs, -1, -1)
+        reference_points = self.reference_points(query_pos).sigmoid()
+        init_reference_out = reference_points
+        query = query.permute(1, 0, 2)
+        query_pos = query_pos.permute(1, 0, 2)
+        voxel_embed = voxel_embed.permute(1, 0, 2)
+        if self.decoder_on_bev:
+            raise NotImplementedError('decoder_on_bev=True is not used by vocc.py (:109)')
+        for k in ('world2pixel', 'origin', 'hit_table', 'map_hw'):
+            kwargs.pop(k, None)
+        inter_states, inter_references = self.decoder(
+            query=query, key=None, value=voxel_embed, query_pos=query_pos,
+            reference_points=reference_points, reg_branches=reg_branches, cls_branches=cls_branches,
+            spatial_shapes=torch.tensor([[bev_z, bev_h, bev_w]], device=query.device),
+            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+        return voxel_embed, inter_states, init_reference_out, inter_references

@@ -123,7 +123,8 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  * slots[b,n] = (1/max(1,#cams seeing n)) * sum_{c sees n} sum_p softmax(logits)[p] *
  *              bilinear(value[b,c], uv[b,c,n,p%D] + offsets[n,p]/(map_w,map_h))
  * Supported: one feature level; head_dim in {8,16,32,64,96,128}; points in {4,8}; D | points;
- *   map_h*map_w*head_dim*4 <= 75 KiB (one (camera, head) tile in LDS).
+ *   one (camera, head) value tile must fit the 160 KiB LDS: map_h*map_w*head_dim*4 <= 160 KiB
+ *   in forward (<= 80 KiB keeps two workgroups per CU), twice that tile in backward.
  */
 int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
                     const float* uv, const uint8_t* vis, const int32_t* own_list,

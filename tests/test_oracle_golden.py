@@ -28,8 +28,7 @@ def test_msda_core_forward_backward(name):
         assert close(value.grad[:, ::3], g['grad_value'])
         assert close(loc.grad[:, ::5], g['grad_loc'])
         assert close(w.grad[:, ::5], g['grad_w'])
-        norms = [float(out.detach().norm()), float(value.grad.norm()), float(loc.grad.norm()),
-                 float(w.grad.norm())]
+        norms = [float(t.double().norm()) for t in (out.detach(), value.grad, loc.grad, w.grad)]
         np.testing.assert_allclose(norms, g['norms'], rtol=1e-5)
     else:
         assert maxdiff(out.detach(), g['out']) < 2e-5
@@ -120,7 +119,7 @@ def test_get_voxel_features_full_width(gname):
                                    T(org[b]), cases.PC_RANGE)
         key = '%s_b%d_' % (gname, b)
         assert maxdiff(out[0, ::7], g[key + 'out']) < TOL
-        assert abs(float(out.norm()) - float(g[key + 'norm'])) < 1e-2
+        assert abs(float(out.double().norm()) - float(g[key + 'norm'])) < 1e-2
     del shapes
 
 

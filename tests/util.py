@@ -44,7 +44,15 @@ def close(a, b, atol=1e-4, rtol=1e-5):
     fp32 summation-order noise alone is ~1e-5 relative)."""
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
-    return bool(((a - b).abs() <= atol + rtol * b.abs()).all())
+    bad = (a - b).abs() > atol + rtol * b.abs()
+    if bool(bad.any()):
+        d = (a - b).abs()
+        i = int(d.flatten().argmax())
+        print('close(): %d of %d outside atol=%g rtol=%g; worst |a-b|=%.3e at flat %d (a=%.6e b=%.6e)'
+              % (int(bad.sum()), bad.numel(), atol, rtol, float(d.flatten()[i]), i,
+                 float(a.flatten()[i]), float(b.flatten()[i])))
+        return False
+    return True
 
 
 def oracle_slots(o, value, offsets, logits, uv, mask, map_hw):
@@ -72,3 +80,24 @@ def oracle_slots(o, value, offsets, logits, uv, mask, map_hw):
         count = mask[b].sum(0).clamp(min=1).to(value.dtype)
         out.append(slots / count[:, None])
     return torch.stack(out)
+
+
+def close_mostly(a, b, atol=2e-4, rtol=1e-4, max_bad_frac=0.05, max_rel_l2=2e-2, max_median=2e-5):
+    """Gradient check for whole-network backward passes.
+
+    The network has kinks (ReLU pre-activations within ~1e-6 of zero, bilinear cell edges): with
+    ~4e6 hidden activations a few of them flip between ANY two fp32 implementations (the CPU
+    oracle on two different hosts differs from itself by 1.5e-3 in d(feats)), and one flipped
+    unit changes one voxel's gradient by O(0.1), which then spreads over a camera's value tile.
+    So: median error tiny, few elements outside the element-wise tolerance, small relative L2.
+    Kernel arithmetic itself is checked element-wise in test_hip_ops_gpu.py (no kinks there)."""
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    d = (a - b).abs()
+    bad = float((d > atol + rtol * b.abs()).double().mean())
+    rel = float(d.norm() / b.norm().clamp(min=1e-30))
+    med = float(d.median())
+    ok = bad <= max_bad_frac and rel <= max_rel_l2 and med <= max_median
+    if not ok:
+        print('close_mostly(): bad fraction %.4f, rel L2 %.3e, median %.3e' % (bad, rel, med))
+    return ok

@@ -138,10 +138,11 @@ int dispatch_group(int hd, F&& f) {
 
 int check_common(const void* value, const void* shapes, const void* lstart, const void* loc,
                  const void* aw, int B, int Nk, int heads, int hd, int L, int P, int Nq) {
-    VER_REQUIRE(value && shapes && lstart && loc && aw, VER_EINVAL, "ver_msda: null pointer argument");
     VER_REQUIRE(B >= 0 && Nq >= 0, VER_EINVAL, "ver_msda: negative batch/query count");
     VER_REQUIRE(Nk > 0 && heads > 0 && hd > 0 && L > 0 && P > 0, VER_EINVAL,
                 "ver_msda: num_keys/heads/head_dim/levels/points must be positive");
+    if (B == 0 || Nq == 0) return VER_OK;   // empty query set: buffers may legitimately be null
+    VER_REQUIRE(value && shapes && lstart && loc && aw, VER_EINVAL, "ver_msda: null pointer argument");
     VER_REQUIRE(hd <= 256, VER_EUNSUPPORTED, "ver_msda: head_dim %d > 256", hd);
     return VER_OK;
 }
@@ -156,9 +157,9 @@ extern "C" int ver_msda_forward(const float* value, const int64_t* shapes_hw, co
     int rc = check_common(value, shapes_hw, level_start, loc, attn_w, B, num_keys, heads, head_dim, levels,
                           points, Nq);
     if (rc) return rc;
-    VER_REQUIRE(out, VER_EINVAL, "ver_msda_forward: out is null");
     const long total = (long)B * Nq * heads;
     if (total == 0) return VER_OK;   // empty input: nothing to write (reference returns an empty tensor)
+    VER_REQUIRE(out, VER_EINVAL, "ver_msda_forward: out is null");
     hipStream_t st = (hipStream_t)stream;
     return dispatch_group(head_dim, [&](auto g, auto nc) {
         constexpr int G = decltype(g)::value, NC = decltype(nc)::value;
@@ -179,10 +180,10 @@ extern "C" int ver_msda_backward(const float* value, const int64_t* shapes_hw, c
     int rc = check_common(value, shapes_hw, level_start, loc, attn_w, B, num_keys, heads, head_dim, levels,
                           points, Nq);
     if (rc) return rc;
-    VER_REQUIRE(grad_out && grad_value && grad_loc && grad_attn_w, VER_EINVAL,
-                "ver_msda_backward: null gradient pointer");
     const long total = (long)B * Nq * heads;
     if (total == 0) return VER_OK;
+    VER_REQUIRE(grad_out && grad_value && grad_loc && grad_attn_w, VER_EINVAL,
+                "ver_msda_backward: null gradient pointer");
     hipStream_t st = (hipStream_t)stream;
     return dispatch_group(head_dim, [&](auto g, auto nc) {
         constexpr int G = decltype(g)::value, NC = decltype(nc)::value;

@@ -547,8 +547,9 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     VER_REQUIRE(slots, VER_EINVAL, "ver_sca_forward: slots is null");
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t lds = (size_t)map_h * map_w * head_dim * sizeof(float);
-    VER_REQUIRE(lds <= kMaxLds / 2, VER_EUNSUPPORTED,
-                "ver_sca_forward: %dx%dx%d value tile (%zu B) exceeds half of LDS", map_h, map_w, head_dim, lds);
+    VER_REQUIRE(lds <= kMaxLds, VER_EUNSUPPORTED,
+                "ver_sca_forward: %dx%dx%d value tile (%zu B) exceeds the 160 KiB LDS", map_h, map_w, head_dim,
+                lds);
     const int nchunks = (Nq + kFwdChunk - 1) / kFwdChunk;
     hipStream_t st = (hipStream_t)stream;
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {

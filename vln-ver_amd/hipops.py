@@ -51,7 +51,7 @@ def _check(rc, what):
 
 
 def _p(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.data_ptr())       # NULL for empty tensors; the C side returns early
 
 
 def _stream():

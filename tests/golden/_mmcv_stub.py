@@ -403,8 +403,15 @@ class _ExtStub:
         return missing
 
 
+_INSTALLED = False
+
+
 def install():
-    """Insert the fake modules and path-only ``projects`` packages."""
+    """Insert the fake modules and path-only ``projects`` packages (idempotent)."""
+    global _INSTALLED
+    if _INSTALLED:
+        return sys.modules['projects.mmdet3d_plugin.bevformer.modules']
+    _INSTALLED = True
     sys.dont_write_bytecode = True
     ext_loader = types.SimpleNamespace(load_ext=lambda name, funcs: _ExtStub())
 

@@ -90,3 +90,44 @@ def vocc_transformer_cfg(dims=768, decoder=None):
     return dict(type='VoxelPerceptionTransformer', rotate_prev_bev=True, use_shift=True,
                 use_can_bus=True, embed_dims=dims, decoder_on_bev=False,
                 encoder=vocc_encoder_cfg(dims), decoder=decoder)
+
+
+CLASS_NUM = 17
+QUERY_NUM = 100
+
+
+def vocc_decoder_cfg(dims=768):
+    """Decoder dict of projects/configs/verformer/vocc.py:138-166, restated."""
+    return dict(
+        type='VoxelDetectionTransformerDecoder', num_layers=6, return_intermediate=True,
+        transformerlayers=dict(
+            type='DetrTransformerDecoderLayer',
+            attn_cfgs=[dict(type='MultiheadAttention', embed_dims=dims, num_heads=8, dropout=0.1),
+                       dict(type='VoxelCustomMSDeformableAttention', embed_dims=dims, num_levels=1)],
+            ffn_cfgs=dict(type='FFN', embed_dims=768, feedforward_channels=1024, num_fcs=2,
+                          ffn_drop=0., act_cfg=dict(type='ReLU', inplace=True)),
+            feedforward_channels=dims * 2, ffn_dropout=0.1,
+            operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm')))
+
+
+def vocc_head_cfg(bev=(4, 15, 15), refine_occ=True, only_occ=False):
+    """``model['pts_bbox_head']`` of projects/configs/verformer/vocc.py:87-195, restated as data
+    (make_golden_head.py asserts equality with the file itself for the default arguments)."""
+    z, h, w = bev
+    tr = vocc_transformer_cfg(768, decoder=vocc_decoder_cfg(768))
+    return dict(
+        type='VoxelFormerOccupancyHead', bev_h=h, bev_w=w, bev_z=z, getbev=None,
+        num_query=QUERY_NUM, num_classes=CLASS_NUM, in_channels=768, sync_cls_avg_factor=True,
+        with_box_refine=True, as_two_stage=False, point_cloud_range=list(PC_RANGE),
+        occupancy_size=[0.1, 0.1, 0.1], occ_dims=128, occupancy_classes=16, only_occ=only_occ,
+        only_det=False, refine_occ=refine_occ, transformer=tr,
+        bbox_coder=dict(type='NMSFreeCoder', post_center_range=[-10, -10, -5.0, 10, 10, 5.0],
+                        pc_range=list(PC_RANGE), max_num=50, voxel_size=[0.2, 0.2, 8],
+                        num_classes=CLASS_NUM),
+        positional_encoding=dict(type='VoxelLearnedPositionalEncoding', num_feats=384,
+                                 row_num_embed=h, col_num_embed=w, z_num_embed=z),
+        loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=2.0),
+        loss_bbox=dict(type='L1Loss', loss_weight=0.25),
+        loss_iou=dict(type='GIoULoss', loss_weight=0.0),
+        loss_occupancy=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
+                            loss_weight=1.0))

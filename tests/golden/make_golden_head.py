@@ -1,0 +1,181 @@
+"""Golden vectors for the head-level path (a10 + "next" rows): builds the REFERENCE's
+``VoxelFormerOccupancyHead`` verbatim from the ``model['pts_bbox_head']`` dict of
+projects/configs/verformer/vocc.py and runs its forward (and an occupancy-loss backward).
+
+Adds to ``_mmcv_stub`` the mmdet / mmdet3d symbols the head file imports (restated from the
+published behaviour of mmdet 2.14.0; not vendored by the reference).
+Build-container only; loaded by make_golden.py."""
+import copy
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+import _mmcv_stub as stub
+import cases
+
+syn = importlib.import_module('vln-ver_amd.synthetic')
+T = torch.from_numpy
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_CFG = stub.REFERENCE_ROOT + '/projects/configs/verformer/vocc.py'
+
+
+class _Loss(nn.Module):
+    def __init__(self, use_sigmoid=False, gamma=2.0, alpha=0.25, loss_weight=1.0, **kw):
+        super().__init__()
+        self.use_sigmoid, self.gamma, self.alpha, self.loss_weight = use_sigmoid, gamma, alpha, loss_weight
+
+
+for _n in ('FocalLoss', 'L1Loss', 'GIoULoss'):
+    stub.LOSSES.register_module(name=_n)(type(_n, (_Loss,), {}))
+
+
+class BaseBBoxCoder:
+    def __init__(self, **kwargs):
+        pass
+
+
+class DETRHead(stub.BaseModule):
+    """Attribute contract of mmdet 2.14.0 DETRHead.__init__."""
+
+    def __init__(self, num_classes, in_channels, num_query=100, num_reg_fcs=2, transformer=None,
+                 sync_cls_avg_factor=False, positional_encoding=None, loss_cls=None, loss_bbox=None,
+                 loss_iou=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        self.bg_cls_weight = 0
+        self.sync_cls_avg_factor = sync_cls_avg_factor
+        self.num_query = num_query
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.num_reg_fcs = num_reg_fcs
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.fp16_enabled = False
+        self.loss_cls = stub.build_from_cfg(loss_cls, stub.LOSSES)
+        self.loss_bbox = stub.build_from_cfg(loss_bbox, stub.LOSSES)
+        self.loss_iou = stub.build_from_cfg(loss_iou, stub.LOSSES)
+        self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid else num_classes + 1
+        self.positional_encoding = stub.build_positional_encoding(positional_encoding)
+        self.transformer = stub.build_transformer(transformer)
+        self.embed_dims = self.transformer.embed_dims
+        assert positional_encoding['num_feats'] * 2 == self.embed_dims
+        self._init_layers()
+
+
+def _inverse_sigmoid(x, eps=1e-5):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def install_head_stubs():
+    stub.install()
+    m = stub._mod
+    m('mmdet.core', multi_apply=lambda f, *a, **k: tuple(map(list, zip(*map(f, *a)))),
+      reduce_mean=lambda t: t).__path__ = []
+    m('mmdet.core.bbox', BaseBBoxCoder=BaseBBoxCoder).__path__ = []
+    m('mmdet.core.bbox.builder', BBOX_CODERS=stub.BBOX_CODERS)
+    sys.modules['mmdet.models'].HEADS = stub.HEADS
+    m('mmdet.models.dense_heads', DETRHead=DETRHead)
+    sys.modules['mmdet.models.utils.transformer'].inverse_sigmoid = _inverse_sigmoid
+    for name in ('mmdet3d', 'mmdet3d.core', 'mmdet3d.core.bbox', 'mmdet3d.models'):
+        m(name).__path__ = []
+    m('mmdet3d.core.bbox.coders',
+      build_bbox_coder=lambda cfg, **kw: stub.build_from_cfg(cfg, stub.BBOX_CODERS))
+    m('mmdet3d.models.builder', build_loss=lambda cfg: stub.build_from_cfg(cfg, stub.LOSSES),
+      build_head=lambda cfg: stub.build_from_cfg(cfg, stub.HEADS))
+    m('h5py')
+    root = stub.REFERENCE_ROOT + '/projects/mmdet3d_plugin'
+    stub._pkg('projects.mmdet3d_plugin.core', root + '/core')
+    stub._pkg('projects.mmdet3d_plugin.core.bbox', root + '/core/bbox')
+    stub._pkg('projects.mmdet3d_plugin.core.bbox.coders', root + '/core/bbox/coders')
+    stub._pkg('projects.mmdet3d_plugin.bevformer.dense_heads', root + '/bevformer/dense_heads')
+    importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.nms_free_coder')
+    importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.layout_coder')
+    stub.ref_modules()
+    return importlib.import_module(
+        'projects.mmdet3d_plugin.bevformer.dense_heads.voxelformer_occupancy_head')
+
+
+def reference_head_cfg():
+    """exec the reference config (plain Python; `_base_` is just a list) -> model['pts_bbox_head']."""
+    ns = {}
+    exec(compile(open(REF_CFG).read(), REF_CFG, 'exec'), ns)
+    return ns['model']['pts_bbox_head'], ns['model'].get('train_cfg')
+
+
+def _plain(x):
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    return x
+
+
+def gen_head(ref):
+    from make_golden import _CameraDir, save
+    head_mod = install_head_stubs()
+    cfg, _ = reference_head_cfg()
+    assert _plain(cfg) == _plain(cases.vocc_head_cfg()), 'cases.vocc_head_cfg() drifted from vocc.py'
+    arrays = {}
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+
+    # ---- C3: vocc.py as written (15x15x4 -> 120x120x35x16), forward + occupancy backward
+    c = copy.deepcopy(cfg)
+    c.pop('type')
+    head = head_mod.VoxelFormerOccupancyHead(**c).eval()
+    syn.load_seeded(head, 7)
+    sd = head.state_dict()
+    arrays['sd_names'] = np.array(list(sd.keys()))
+    arrays['sd_shapes'] = np.array([','.join(str(d) for d in v.shape) for v in sd.values()])
+    print('  head params: %.3f M, %d state-dict entries'
+          % (sum(p.numel() for p in head.parameters()) / 1e6, len(sd)))
+    with _CameraDir(w2p, org) as metas:
+        for b in range(2):
+            head.zero_grad()
+            mlvl = T(feats[b]).unsqueeze(1)
+            outs = head(mlvl, metas[b])
+            occ = outs['occupancy_preds']
+            key = 'c3_b%d_' % b
+            arrays[key + 'occ'] = occ[0, ::997].detach().numpy()
+            arrays[key + 'occ_norm'] = np.float64(occ.detach().double().norm())
+            arrays[key + 'occ_mean'] = np.float64(occ.detach().double().mean())
+            arrays[key + 'bev'] = outs['bev_embed'][::7, 0].detach().numpy()
+            arrays[key + 'cls'] = outs['all_cls_scores'].detach().numpy()
+            arrays[key + 'bbox'] = outs['all_bbox_preds'].detach().numpy()
+            print('  c3 vp%d occ norm %.3f mean %.4f' % (b, arrays[key + 'occ_norm'],
+                                                      arrays[key + 'occ_mean']))
+            if b == 0:
+                g = T(np.random.default_rng(60).standard_normal((504000, 16)).astype(np.float32))
+                (occ[0] * g).sum().backward()
+                names, norms = [], []
+                for k, p in sorted(head.named_parameters()):
+                    if p.grad is not None and p.requires_grad:
+                        names.append(k)
+                        norms.append(float(p.grad.double().norm()))
+                arrays['c3_grad_names'] = np.array(names)
+                arrays['c3_grad_norms'] = np.array(norms, dtype=np.float64)
+                arrays['c3_grad_voxel_embedding'] = head.voxel_embedding.weight.grad[::9].numpy()
+                arrays['c3_grad_up0'] = head.up_sample[0].weight.grad[::37, ::41].numpy()
+                arrays['c3_grad_occ_proj'] = head.occ_proj.weight.grad[::53, ::29].numpy()
+
+    # ---- C2: single-scale 50x50x16 (refine_occ=False), forward only
+    c = copy.deepcopy(cases.vocc_head_cfg(bev=(16, 50, 50), refine_occ=False))
+    c.pop('type')
+    head = head_mod.VoxelFormerOccupancyHead(**c).eval()
+    syn.load_seeded(head, 8)
+    with _CameraDir(w2p, org) as metas, torch.no_grad():
+        outs = head(T(feats[0]).unsqueeze(1), metas[0])
+        occ = outs['occupancy_preds']
+        assert occ.shape == (1, 50 * 50 * 35, 16)
+        arrays['c2_b0_occ'] = occ[0, ::173].numpy()
+        arrays['c2_b0_occ_norm'] = np.float64(occ.double().norm())
+        arrays['c2_b0_bev'] = outs['bev_embed'][::97, 0].numpy()
+        print('  c2 vp0 occ norm %.3f' % arrays['c2_b0_occ_norm'])
+    save('head_vocc', **arrays)
+
+
+GENERATORS = {'head': gen_head}

@@ -1,0 +1,71 @@
+"""Head-level host logic on CPU: vocc.py dict builds, parameter names/shapes equal the
+reference's (recorded from the reference module in tests/golden/head_vocc.npz), the even-lattice
+upsample equals ConvTranspose3d, the occupancy branch equals the oracle's literal restatement."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+from util import close, golden, maxdiff, oracle, pkg
+
+
+@pytest.fixture(scope='module')
+def head():
+    pkg()
+    syn = pkg('synthetic')
+    h = pkg('registry').build_head(cases.vocc_head_cfg()).eval()
+    syn.load_seeded(h, 7)
+    return h
+
+
+def test_state_dict_equals_reference(head):
+    g = golden('head_vocc')
+    ours = [(k, ','.join(str(d) for d in v.shape)) for k, v in head.state_dict().items()]
+    theirs = list(zip([str(s) for s in g['sd_names']], [str(s) for s in g['sd_shapes']]))
+    assert ours == theirs                      # 341 entries, same order, same shapes
+    assert sum(p.numel() for p in head.parameters()) == 215991739
+
+
+def test_restated_cfg_builds_variants():
+    pkg()
+    r = pkg('registry')
+    h = r.build_head(cases.vocc_head_cfg(only_occ=True))
+    assert h.transformer.decoder is None and not hasattr(h, 'cls_branches')
+    assert h.loss_cls is None
+    with pytest.raises(NotImplementedError, match='add_layout'):
+        r.build_head(dict(cases.vocc_head_cfg(), add_layout=True))
+
+
+def test_upsample_lattice_equals_conv_transpose():
+    up = pkg('dense_heads.upsample')
+    torch.manual_seed(1)
+    x = torch.randn(2, 6, 4, 5, 7, dtype=torch.float64, requires_grad=True)
+    ws = [(torch.randn(6, 6, 3, 5, 5, dtype=torch.float64) * 0.1).requires_grad_(True) for _ in range(3)]
+    bs = [torch.randn(6, dtype=torch.float64, requires_grad=True) for _ in range(3)]
+    y = up.upsample_dense(x, ws, bs)
+    r = x
+    for w, b in zip(ws, bs):
+        r = F.conv_transpose3d(r, w, b, **up.GEOM)
+    assert y.shape == r.shape == (2, 6, 4, 40, 56)
+    assert maxdiff(y, r) < 1e-12
+    assert maxdiff(y[:, :, :, 1::2], bs[2].view(1, 6, 1, 1, 1).expand(2, 6, 4, 20, 56)) == 0.0
+    g = torch.randn_like(r)
+    for a, b in zip(torch.autograd.grad(y, [x] + ws + bs, g), torch.autograd.grad(r, [x] + ws + bs, g)):
+        assert maxdiff(a, b) < 1e-10
+
+
+def test_occupancy_branch_equals_oracle(head):
+    """a10 at full size on CPU: ours (lattice upsample) vs the oracle (ConvTranspose3d from its
+    definition, raw views kept)."""
+    o = oracle()
+    emb = torch.from_numpy(np.random.default_rng(4).standard_normal((1, 900, 768)).astype(np.float32))
+    with torch.no_grad():
+        ours = head.occupancy_from_volume(emb)
+        p = {k: v for k, v in head.state_dict().items()}
+        want = o.occ_head_forward(p, '', emb[0], (4, 15, 15), (120, 120, 35), 128, refine_occ=True,
+                                  use_torch_convt=False)
+    assert ours.shape == want.shape == (1, 504000, 16)
+    assert close(ours, want, atol=1e-4, rtol=1e-4)

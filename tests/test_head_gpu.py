@@ -1,0 +1,107 @@
+"""Head-level parity on the GPU against vectors from the reference's own
+``VoxelFormerOccupancyHead`` built from vocc.py (tests/golden/make_golden_head.py).
+fp32, tolerance 1e-4 (north_star) on the occupancy logits.  ``-m gpu``."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from util import close, close_mostly, golden, maxdiff, pkg
+
+warnings.filterwarnings('ignore')
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda'
+
+
+def _head(cfg, seed):
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    pkg()
+    h = pkg('registry').build_head(cfg).eval()
+    pkg('synthetic').load_seeded(h, seed)
+    return h.to(DEV)
+
+
+def _metas(w2p, org, idx):
+    return [{'sample_idx': 'scanA_vp%d' % b, 'world2pixel': w2p[b], 'origin': org[b]} for b in idx]
+
+
+def test_vocc_head_forward_matches_reference():
+    """C3 shape: vocc.py as written, 15x15x4 -> 120x120x35x16 (+ det branches)."""
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    head = _head(cases.vocc_head_cfg(), 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    with torch.no_grad():
+        for b in range(2):
+            outs = head(T(feats[b]).to(DEV).unsqueeze(1), _metas(w2p, org, [b]))
+            key = 'c3_b%d_' % b
+            occ = outs['occupancy_preds']
+            assert occ.shape == (1, 504000, 16)
+            assert maxdiff(outs['bev_embed'][::7, 0].cpu(), g[key + 'bev']) < 1e-4
+            assert close(occ[0, ::997].cpu(), g[key + 'occ'], atol=1e-4, rtol=1e-4)
+            assert abs(float(occ.double().norm()) - float(g[key + 'occ_norm'])) < 1e-4 * float(g[key + 'occ_norm'])
+            assert close(outs['all_cls_scores'].cpu(), g[key + 'cls'], atol=2e-4, rtol=1e-4)
+            assert close(outs['all_bbox_preds'].cpu(), g[key + 'bbox'], atol=2e-4, rtol=1e-4)
+        # two viewpoints in one batched call (device-resident cameras)
+        mlvl = T(feats).to(DEV).permute(1, 0, 2, 3).contiguous()
+        outs = head(mlvl, None, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+        for b in range(2):
+            assert close(outs['occupancy_preds'][b, ::997].cpu(), g['c3_b%d_occ' % b], atol=1e-4, rtol=1e-4)
+            assert close(outs['all_bbox_preds'][:, b].cpu(), g['c3_b%d_bbox' % b][:, 0], atol=2e-4, rtol=1e-4)
+
+
+def test_vocc_head_occupancy_backward_matches_reference():
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    head = _head(cases.vocc_head_cfg(), 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    outs = head(T(feats[0]).to(DEV).unsqueeze(1), _metas(w2p, org, [0]))
+    gg = T(np.random.default_rng(60).standard_normal((504000, 16)).astype(np.float32)).to(DEV)
+    (outs['occupancy_preds'][0] * gg).sum().backward()
+    names = [str(s) for s in g['c3_grad_names']]
+    norms = g['c3_grad_norms']
+    ours = {k: float(p.grad.double().norm()) for k, p in head.named_parameters() if p.grad is not None}
+    assert set(names) <= set(ours)
+    for name, want in zip(names, norms):
+        assert abs(ours[name] - want) <= 1e-2 * max(1e-3, abs(want)), (name, ours[name], want)
+    assert close_mostly(head.voxel_embedding.weight.grad[::9].cpu(), g['c3_grad_voxel_embedding'],
+                        atol=1e-3, rtol=1e-3, max_median=1e-4)
+    assert close_mostly(head.up_sample[0].weight.grad[::37, ::41].cpu(), g['c3_grad_up0'], atol=1e-3,
+                        rtol=1e-3, max_median=1e-4)
+    assert close_mostly(head.occ_proj.weight.grad[::53, ::29].cpu(), g['c3_grad_occ_proj'], atol=1e-3,
+                        rtol=1e-3, max_median=1e-4)
+
+
+def test_single_scale_head_forward_matches_reference():
+    """C2 shape: 50x50x16 single-scale volume (refine_occ=False), forward only."""
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    head = _head(cases.vocc_head_cfg(bev=(16, 50, 50), refine_occ=False), 8)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    with torch.no_grad():
+        outs = head(T(feats[0]).to(DEV).unsqueeze(1), _metas(w2p, org, [0]))
+    occ = outs['occupancy_preds']
+    assert occ.shape == (1, 50 * 50 * 35, 16)
+    assert maxdiff(outs['bev_embed'][::97, 0].cpu(), g['c2_b0_bev']) < 1e-4
+    assert close(occ[0, ::173].cpu(), g['c2_b0_occ'], atol=1e-4, rtol=1e-4)
+    assert abs(float(occ.double().norm()) - float(g['c2_b0_occ_norm'])) < 1e-4 * float(g['c2_b0_occ_norm'])
+
+
+def test_lift_equals_default_branch():
+    syn = pkg('synthetic')
+    head = _head(cases.vocc_head_cfg(), 7)
+    w2p, org = syn.camera_batch(1, seed=1)
+    feats = syn.vit_features(1, seed=0)
+    mlvl = T(feats[0]).to(DEV).unsqueeze(1)
+    with torch.no_grad():
+        emb, occ = head.lift(mlvl, _metas(w2p, org, [0]))
+        outs = head(mlvl, _metas(w2p, org, [0]))
+    assert torch.equal(emb[0], outs['bev_embed'][:, 0])
+    assert torch.equal(occ, outs['occupancy_preds'])

@@ -7,6 +7,7 @@ Importing the package registers the plugin classes (``SpatialCrossAttention``,
 is installed, into ``registry.py``'s otherwise."""
 from . import registry  # noqa: F401
 from . import modules  # noqa: F401
+from . import dense_heads  # noqa: F401
 from .registry import (ATTENTION, HEADS, POSITIONAL_ENCODING, TRANSFORMER,  # noqa: F401
                        TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_from_cfg)
 

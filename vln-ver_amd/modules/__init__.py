@@ -6,3 +6,5 @@ from .custom_base_transformer_layer import MyCustomBaseTransformerLayer  # noqa:
 from .voxel_encoder import VoxelFormerEncoder, VoxelFormerLayer  # noqa: F401
 from .voxel_positional_embedding import VoxelLearnedPositionalEncoding  # noqa: F401
 from .voxel_transformer import VoxelPerceptionTransformer  # noqa: F401
+from .voxel_decoder import (DetrTransformerDecoderLayer, MultiheadAttention,  # noqa: F401
+                            VoxelCustomMSDeformableAttention, VoxelDetectionTransformerDecoder)

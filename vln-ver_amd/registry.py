@@ -122,6 +122,25 @@ except Exception:
     HEADS = Registry('head')
 
 
+try:                                                            # pragma: no cover
+    from mmdet.models.builder import LOSSES
+    from mmdet.core.bbox.builder import BBOX_CODERS, BBOX_ASSIGNERS
+    from mmdet.core.bbox.match_costs.builder import MATCH_COST
+except Exception:
+    LOSSES = Registry('loss')
+    BBOX_CODERS = Registry('bbox coder')
+    BBOX_ASSIGNERS = Registry('bbox assigner')
+    MATCH_COST = Registry('match cost')
+
+
+def build_loss(cfg, default_args=None):
+    return build_from_cfg(cfg, LOSSES, default_args)
+
+
+def build_bbox_coder(cfg, default_args=None):
+    return build_from_cfg(cfg, BBOX_CODERS, default_args)
+
+
 def build_attention(cfg, default_args=None):
     return build_from_cfg(cfg, ATTENTION, default_args)
 

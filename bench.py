@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the VER 2D->3D lifting path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" = one training pass of the hot path over one batch of synthetic viewpoints:
+6x14x14x768 ViT features -> VERFormer encoder (projection, hit table, 3x fused multi-view
+gather + GEMMs) -> coarse-to-fine occupancy head (even-lattice upsample, occ_proj, occ MLP)
+-> sigmoid focal loss on [504000,16] -> backward -> gradient all-reduce (N>1) -> grad-clip ->
+AdamW.  Workload = BASELINE.json configs[2] ("vocc.py coarse-to-fine multi-scale volume, bf16
+fwd+bwd"), i.e. the config the metric "viewpoints/sec (multi-view->voxel fwd+bwd), vocc.py
+config" is quoted on.  Inputs are resident in HBM before the timed region.  One JSON line on
+rank 0 (contract in the task statement), with `roofline` (fused gather kernel, HIP-event timed
+in the timed region) and `cpu_baseline` (the CPU oracle on this host's cores, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+warnings.filterwarnings('ignore')
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0     # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=32, help='viewpoints per GPU per step')
+    ap.add_argument('--micro', type=int, default=8, help='viewpoints per head micro-batch')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+class LiftTrainer(torch.nn.Module):
+    """vocc.py head restricted to the lifting path (encoder + occupancy branch + its loss).
+    The encoder runs on the whole per-GPU batch (one fused-gather launch per layer covers all
+    viewpoints); the 120x120x35 head runs in micro-batches to bound activation memory."""
+
+    def __init__(self, head, micro, dtype):
+        super().__init__()
+        self.head = head
+        self.micro = micro
+        self.autocast = dtype == 'bf16'
+
+    def forward(self, feats, w2p, org, gt):
+        bs = feats.shape[1]
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.autocast):
+            emb = self.head(feats, None, only_bev=True, world2pixel=w2p, origin=org)   # [bs,Nq,C]
+            total = emb.new_zeros((), dtype=torch.float32)
+            for s in range(0, bs, self.micro):
+                occ = self.head.occupancy_from_volume(emb[s:s + self.micro])
+                total = total + self.head.occupancy_loss(occ, gt[s:s + self.micro]) * occ.shape[0]
+        return total / bs
+
+
+def build_model(args, dev):
+    import cases
+    pkg = importlib.import_module('vln-ver_amd')
+    syn = importlib.import_module('vln-ver_amd.synthetic')
+    if args.workload == 'c2_single_scale_fwd':
+        cfg = cases.vocc_head_cfg(bev=(16, 50, 50), refine_occ=False)
+    else:
+        cfg = cases.vocc_head_cfg()
+    torch.manual_seed(2)
+    head = pkg.registry.build_head(cfg)
+    head.init_weights()
+    # the lifting path does not touch the detection decoder / branches: freeze them so that
+    # DDP reduces (and AdamW updates) exactly the parameters the path trains
+    lift_prefixes = ('transformer.encoder.', 'transformer.level_embeds', 'transformer.cams_embeds',
+                     'voxel_embedding.', 'up_sample.', 'occ_proj.', 'occ_branches.')
+    n_train = 0
+    for k, p in head.named_parameters():
+        p.requires_grad_(k.startswith(lift_prefixes))
+        n_train += p.numel() if p.requires_grad else 0
+    return pkg, syn, head.to(dev), n_train
+
+
+def gather_algorithmic_bytes(hit_counts, B, ncam=6, nk=196, c=768, heads=8, points=8):
+    """per viewpoint and layer, forward = 6*196*768*4 + Sigma_n*(128+64+768)*4 B
+    (value once + loc + weights + output per visible (camera,voxel) pair);
+    backward = 2*value + Sigma_n*5376."""
+    sn = float(hit_counts)
+    fwd = B * ncam * nk * c * 4 + sn * (heads * points * 2 + heads * points + c) * 4
+    bwd = 2 * B * ncam * nk * c * 4 + sn * 5376
+    return fwd, bwd
+
+
+def cpu_baseline(head, syn, seconds):
+    """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this
+    host's cores: vocc.py lifting path fwd+bwd for ONE viewpoint at a time."""
+    oracle = importlib.import_module('oracle.ver_oracle')
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and k != 'code_weights')
+         for k, v in head.state_dict().items()}
+    w2p, org = syn.camera_batch(1, seed=1)
+    feats = torch.from_numpy(syn.vit_features(1, seed=0))[0].unsqueeze(1)
+    gt = torch.from_numpy(np.random.default_rng(3).integers(0, 17, size=504000))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        _, occ = oracle.lifting_forward(p, feats, torch.from_numpy(w2p[0]), torch.from_numpy(org[0]))
+        loss = oracle.focal_loss(occ[0], gt, avg_factor=(gt < 16).sum() * 1.0)
+        loss.backward()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 4:
+            break
+    return dict(value=n / dt, unit='viewpoints/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d viewpoint(s), vocc.py 15x15x4 -> 120x120x35x16 lifting path fwd+bwd, fp32, '
+                       'oracle/ver_oracle.py (torch-CPU), %.1f s' % (n, dt))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback of the product path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    hip = importlib.import_module('vln-ver_amd.hipops')
+    hip.lib()
+    pkg, syn, head, n_train = build_model(args, dev)
+    B = args.batch
+    train = args.workload == 'vocc_c2f_train'
+    model = LiftTrainer(head, args.micro, args.dtype).to(dev)
+    model.train(train)
+    ddp = model                                 # train(): dropout ON, as in the reference's step
+    if world > 1 and train:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=200)
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True) if train else None
+
+    # synthetic, HBM-resident inputs (different viewpoints per rank)
+    w2p_np, org_np = syn.camera_batch(B, seed=1 + rank)
+    feats = torch.from_numpy(syn.vit_features(B, seed=100 + rank)).to(dev).permute(1, 0, 2, 3).contiguous()
+    w2p, org = torch.from_numpy(w2p_np).to(dev), torch.from_numpy(org_np).to(dev)
+    nvox = head.voxel_num if head.refine_occ else head.bev_h * head.bev_w * head.occ_zdim
+    gt = torch.from_numpy(np.random.default_rng(7 + rank).integers(0, 17, size=(B, nvox))).to(dev)
+
+    def step():
+        if train:
+            loss = ddp(feats, w2p, org, gt)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:270 grad_clip max_norm
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16'):
+            emb = head(feats, None, only_bev=True, world2pixel=w2p, origin=org)
+            out = [head.occupancy_from_volume(emb[s:s + args.micro]) for s in range(0, B, args.micro)]
+            return out[-1].float().mean()
+
+    for _ in range(args.warmup):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = hip.KernelTimer()
+    hip.KERNEL_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    hip.KERNEL_TIMER = None
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+    assert torch.isfinite(last).all(), 'non-finite loss'
+
+    if rank == 0:
+        kt = timer.summary()
+        hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
+        sigma_n = int(hit.vis_cnt.sum())
+        fwd_b, bwd_b = gather_algorithmic_bytes(sigma_n, B)
+        roof, others = None, []
+        for name, byts in (('ver_sca_forward', fwd_b), ('ver_sca_backward', bwd_b)):
+            if name in kt and kt[name]['count']:
+                avg_ms = kt[name]['ms'] / kt[name]['count']
+                ach = byts / (avg_ms * 1e-3) / 1e9
+                obj = dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                           frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
+                           launches=kt[name]['count'], algorithmic_bytes_per_launch=int(byts),
+                           viewpoints_per_launch=B, sigma_n=sigma_n)
+                if name == 'ver_sca_forward':
+                    roof = obj
+                else:
+                    others.append(obj)
+        total_vp = B * world * args.steps
+        line = {
+            'metric': 'viewpoints/sec (multi-view->voxel fwd+bwd), vocc.py config' if train
+                      else 'viewpoints/sec (multi-view->voxel fwd), 50x50x16 single-scale',
+            'value': round(total_vp / elapsed, 3), 'unit': 'viewpoints/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic (N(0,1) ViT features, 6-camera pinhole rig, random occupancy labels; '
+                    'reference-rule random-init weights)',
+            'config': {'workload': 'vocc.py coarse-to-fine lifting path (15x15x4 -> 120x120x35x16): encoder + '
+                                   'occupancy head + focal loss, fwd+bwd+AdamW' if train else
+                                   'single-scale 50x50x16 volume, forward only',
+                       'viewpoints_per_gpu_per_step': B, 'global_viewpoints_per_step': B * world,
+                       'head_micro_batch': args.micro, 'parallelism': 'dp%d' % world,
+                       'trainable_params': n_train,
+                       'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
+                                     else 'fp32'},
+            'roofline': roof, 'roofline_other_kernels': others,
+        }
+        if world == 1 and not args.no_cpu_baseline and train:
+            line['cpu_baseline'] = cpu_baseline(head, syn, args.cpu_seconds)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 1
+#define VER_ABI_VERSION 2
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -83,9 +83,10 @@ int ver_msda_backward(const float* value, const int64_t* shapes_hw, const int64_
  *   vis_list  i32 [B, Ncam, Nq]        ascending voxel ids seen by camera c  (= the reference's
  *                                      `indexes[c]`, spatial_cross_attention.py:139-141)
  *   vis_cnt   i32 [B, Ncam]
- *   own_list  i32 [B, Ncam, Nq]        voxels whose output row the (b,c) workgroups write:
- *                                      lowest camera that sees it, or n % Ncam if none does
- *   own_cnt   i32 [B, Ncam]
+ *   zero_list i32 [B, Nq]              ascending voxel ids NOT seen by exactly one camera: their
+ *                                      output rows are zero-filled before the gather (unseen ->
+ *                                      stay zero; seen by several cameras -> atomically summed)
+ *   zero_cnt  i32 [B]
  */
 
 /* VoxelFormerEncoder.get_reference_points('3d') + point_sampling
@@ -100,21 +101,22 @@ int ver_project_points(const float* world2pixel, const float* origin, const floa
                        int B, int Ncam, int bev_z, int bev_h, int bev_w,
                        float img_w, float img_h,
                        float* uv, uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                       int32_t* own_list, int32_t* own_cnt, void* stream);
+                       int32_t* zero_list, int32_t* zero_cnt, void* stream);
 
 /* Same lists from a caller-supplied mask in the reference's layout
  *   bev_mask u8/bool [Ncam, B, Nq, D]  (spatial_cross_attention.py:87,139-141,170).
  */
 int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
                        uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                       int32_t* own_list, int32_t* own_cnt, void* stream);
+                       int32_t* zero_list, int32_t* zero_cnt, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused multi-view gather = the body of SpatialCrossAttention.forward between the three
  * input projections and output_proj (spatial_cross_attention.py:139-173 together with
  * MSDeformableAttention3D.forward :345-398): per-camera re-batching, softmax over the
  * points, location arithmetic, bilinear sampling, scatter-add over cameras and division by
- * the camera count -- without padded rows, atomics or host syncs.
+ * the camera count -- without padded rows or host syncs (fp32 atomics only on the rows of
+ * voxels seen by more than one camera).
  *
  *   value   f32|bf16 [B, Ncam, map_h*map_w, heads, head_dim]   value_proj output
  *   offsets f32 [B, Nq, heads, points, 2]     sampling_offsets output, in pixels (one level)
@@ -127,8 +129,9 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  *   in forward (<= 80 KiB keeps two workgroups per CU), twice that tile in backward.
  */
 int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
-                    const float* uv, const uint8_t* vis, const int32_t* own_list,
-                    const int32_t* own_cnt, float* slots,
+                    const float* uv, const uint8_t* vis, const int32_t* vis_list,
+                    const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
+                    float* slots,
                     int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                     int map_h, int map_w, void* stream);
 

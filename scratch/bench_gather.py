@@ -1,0 +1,37 @@
+"""Micro-benchmark of the fused gather kernels (fwd/bwd) at the vocc shape."""
+import sys, importlib, warnings, json
+warnings.filterwarnings('ignore')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import numpy as np, torch
+hip = importlib.import_module('vln-ver_amd.hipops'); syn = importlib.import_module('vln-ver_amd.synthetic')
+import cases
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+grid = (4, 15, 15) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split('x'))
+iters = 20
+dev = 'cuda'
+z, h, w = grid; nq = z*h*w
+w2p, org = syn.camera_batch(B, seed=1)
+hit = hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, z, h, w)
+g = torch.Generator(device=dev).manual_seed(0)
+value = torch.randn(B, 6, 196, 8, 96, device=dev, generator=g)
+offs = torch.randn(B, nq, 8, 8, 2, device=dev, generator=g) * 3
+logits = torch.randn(B, nq, 8, 8, device=dev, generator=g)
+gs = torch.randn(B, nq, 768, device=dev, generator=g)
+sn = int(hit.vis_cnt.sum())
+fwd_b = B*6*196*768*4 + sn*(128+64+768)*4
+bwd_b = 2*B*6*196*768*4 + sn*5376
+def timeit(fn):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+v = value.clone().requires_grad_(True); o = offs.clone().requires_grad_(True); l = logits.clone().requires_grad_(True)
+t_f = timeit(lambda: hip.sca_gather(value, offs, logits, hit, 14, 14))
+s = hip.sca_gather(v, o, l, hit, 14, 14)
+t_b = timeit(lambda: torch.autograd.grad(s, [v, o, l], gs, retain_graph=True))
+t_p = timeit(lambda: hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, z, h, w))
+print(json.dumps(dict(B=B, grid=grid, sigma_n=sn, fwd_us=round(t_f,1), fwd_GBs=round(fwd_b/t_f/1e3,1), fwd_frac=round(fwd_b/t_f/1e3/8000,4),
+                      bwd_us=round(t_b,1), bwd_GBs=round(bwd_b/t_b/1e3,1), bwd_frac=round(bwd_b/t_b/1e3/8000,4), project_us=round(t_p,1))))

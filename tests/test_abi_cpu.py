@@ -42,8 +42,8 @@ def test_argument_validation_without_gpu():
     lib = hip.lib()
     rc = lib.ver_msda_forward(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 64, None)
     assert rc == -1 and b'null' in lib.ver_last_error()
-    rc = lib.ver_sca_forward(None, 0, None, None, None, None, None, None, None, 1, 6, 1, 1, 8, 96,
-                             8, 14, 14, None)
+    rc = lib.ver_sca_forward(None, 0, None, None, None, None, None, None, None, None, None, 1, 6, 1, 1,
+                             8, 96, 8, 14, 14, None)
     assert rc == -1
 
 

@@ -101,3 +101,9 @@ def close_mostly(a, b, atol=2e-4, rtol=1e-4, max_bad_frac=0.05, max_rel_l2=2e-2,
     if not ok:
         print('close_mostly(): bad fraction %.4f, rel L2 %.3e, median %.3e' % (bad, rel, med))
     return ok
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))

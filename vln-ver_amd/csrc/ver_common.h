@@ -71,12 +71,38 @@ __device__ __forceinline__ void bilinear_setup(float loc_x, float loc_y, int H, 
     }
 }
 
-// Sum over the lanes of an aligned group of G lanes (G a power of two <= 64); every lane
-// of the group ends up with the total.
+// Cross-lane butterflies inside aligned groups of G lanes.  For G <= 16 everything stays in
+// the VALU through DPP (a row = 16 lanes): xor-1 and xor-2 are quad permutes, then
+// row_half_mirror joins the two quads of each 8, row_mirror the two halves of the row -- after
+// log2(G) steps every lane of the group holds the result.  No LDS traffic (ds_bpermute) at all.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppXor1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror
+constexpr int kDppMirror = 0x140;      // row_mirror
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, VER_WAVE);
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "group size");
+    if constexpr (G >= 2) v += dpp_mov<kDppXor1>(v);
+    if constexpr (G >= 4) v += dpp_mov<kDppXor2>(v);
+    if constexpr (G >= 8) v += dpp_mov<kDppHalfMirror>(v);
+    if constexpr (G >= 16) v += dpp_mov<kDppMirror>(v);
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, VER_WAVE);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, VER_WAVE);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group size");
+    if constexpr (G >= 2) v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    if constexpr (G >= 4) v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    if constexpr (G >= 8) v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    if constexpr (G >= 16) v = fmaxf(v, dpp_mov<kDppMirror>(v));
     return v;
 }
 

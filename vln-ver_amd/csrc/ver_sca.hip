@@ -22,6 +22,8 @@
 #include <type_traits>
 #include "ver_common.h"
 
+constexpr int kFwdThreads = 1024;
+
 // ------------------------------------------------------------------------------------------
 // projection + visibility (voxel_encoder.py:54-83,119-195).  No FMA contraction and the
 // reference's operation order, so that the strict visibility inequalities see the same
@@ -83,50 +85,64 @@ __global__ __launch_bounds__(256) void k_mask_to_vis(const uint8_t* __restrict__
     vis[(size_t)b * Nq + n] = (uint8_t)bits;
 }
 
-// ordered (ascending voxel id) compaction of the visible / owned voxels of camera c.
+// ordered (ascending voxel id) compaction: per camera the voxels it sees (= the reference's
+// `indexes[c]`), and per viewpoint (built by the camera-0 workgroup) the voxels NOT seen by exactly
+// one camera -- their output rows are zero-filled before the gather (unseen: stay zero; seen by
+// several cameras: accumulated with atomics).
 __global__ __launch_bounds__(256) void k_build_lists(const uint8_t* __restrict__ vis, int Ncam, int Nq,
                                                      int* __restrict__ vis_list, int* __restrict__ vis_cnt,
-                                                     int* __restrict__ own_list, int* __restrict__ own_cnt) {
+                                                     int* __restrict__ zero_list, int* __restrict__ zero_cnt) {
     __shared__ int wsum[2][4];
     const int c = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     int* vl = vis_list + ((size_t)b * Ncam + c) * Nq;
-    int* ol = own_list + ((size_t)b * Ncam + c) * Nq;
-    int base_v = 0, base_o = 0;
+    int* zl = zero_list + (size_t)b * Nq;
+    int base_v = 0, base_z = 0;
     for (int n0 = 0; n0 < Nq; n0 += 256) {
         const int n = n0 + tid;
         const bool valid = n < Nq;
         const unsigned m = valid ? vis[(size_t)b * Nq + n] : 0u;
         const bool is_v = valid && ((m >> c) & 1u);
-        const int owner = m ? (__ffs((int)m) - 1) : (n % Ncam);
-        const bool is_o = valid && owner == c;
-        const unsigned long long bv = __ballot(is_v), bo = __ballot(is_o);
+        const bool is_z = valid && c == 0 && __popc(m) != 1;
+        const unsigned long long bv = __ballot(is_v), bz = __ballot(is_z);
         if (lane == 0) {
             wsum[0][wave] = __popcll(bv);
-            wsum[1][wave] = __popcll(bo);
+            wsum[1][wave] = __popcll(bz);
         }
         __syncthreads();
-        int off_v = base_v, off_o = base_o, tot_v = 0, tot_o = 0;
+        int off_v = base_v, off_z = base_z, tot_v = 0, tot_z = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             if (w < wave) {
                 off_v += wsum[0][w];
-                off_o += wsum[1][w];
+                off_z += wsum[1][w];
             }
             tot_v += wsum[0][w];
-            tot_o += wsum[1][w];
+            tot_z += wsum[1][w];
         }
         if (is_v) vl[off_v + __popcll(bv & lt)] = n;
-        if (is_o) ol[off_o + __popcll(bo & lt)] = n;
+        if (is_z) zl[off_z + __popcll(bz & lt)] = n;
         base_v += tot_v;
-        base_o += tot_o;
+        base_z += tot_z;
         __syncthreads();
     }
     if (tid == 0) {
         vis_cnt[b * Ncam + c] = base_v;
-        own_cnt[b * Ncam + c] = base_o;
+        if (c == 0) zero_cnt[b] = base_z;
     }
+}
+
+// zero the output rows listed in zero_list (C floats per row), 8 rows per workgroup
+__global__ __launch_bounds__(256) void k_zero_rows(const int* __restrict__ zero_list,
+                                                   const int* __restrict__ zero_cnt, float* __restrict__ slots,
+                                                   int Nq, int C) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (e >= zero_cnt[b]) return;
+    const int n = zero_list[(size_t)b * Nq + e];
+    float4* row = reinterpret_cast<float4*>(slots + ((size_t)b * Nq + n) * C);
+    for (int i = threadIdx.x & 31; i < C / 4; i += 32) row[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -240,88 +256,297 @@ __device__ __forceinline__ void gather_camera(const VT* base, size_t rstride, co
     }
 }
 
+// Stage the [Nk][HD] value tile of one (camera, head) into LDS with LDS-DMA
+// (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPR round trip, every wave
+// keeps all of its ~18 requests in flight at once).  The LDS image is dense row-major, so the
+// lane-linear destination (wave-uniform base + lane*16) is exactly chunk q = q0 + lane; the
+// per-lane SOURCE address carries the row stride of the 768-wide token rows.
 template <int HD, typename VT>
-__device__ __forceinline__ void stage_tile(VT* tile, const VT* src, size_t rstride, int Nk, int nthreads) {
+__device__ __forceinline__ void stage_tile(VT* tile, const VT* src, size_t rstride, int Nk, int wave, int nwaves) {
     constexpr int VEC = 16 / sizeof(VT);
     constexpr int VPR = HD / VEC;
     static_assert(HD % VEC == 0, "head_dim row must be a whole number of 16-byte vectors");
-    for (int i = threadIdx.x; i < Nk * VPR; i += nthreads) {
-        const int k = i / VPR, j = i - k * VPR;
-        *reinterpret_cast<uint4*>(tile + k * HD + j * VEC) =
-            *reinterpret_cast<const uint4*>(src + (size_t)k * rstride + j * VEC);
+    const int total = Nk * VPR;
+    const int lane = threadIdx.x & 63;
+    for (int q0 = wave * 64; q0 < total; q0 += nwaves * 64) {
+        const int q = q0 + lane;
+        if (q < total) {
+            const int k = q / VPR, j = q - k * VPR;
+            const VT* g = src + (size_t)k * rstride + j * VEC;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(tile + (size_t)q0 * VEC),
+                                             16, 0, 0);
+        }
     }
 }
 
+__device__ __forceinline__ void stage_wait() {
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's LDS-DMA requests have landed
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------
+// Forward.  One workgroup of 16 waves per (viewpoint, camera, head group [, list chunk]) walks
+// its heads with a double-buffered LDS tile:
+//   * the last kFwdLoaders waves are LOADERS: they only issue LDS-DMA (global_load_lds_dwordx4)
+//     for the next head's 14x14xHD tile while the other waves work on the current one, so after
+//     the first tile the HBM stream of the value tensor hides behind compute (one barrier / head);
+//   * the other waves are CONSUMERS.  A wave takes 4 voxels per iteration, one per 16-lane DPP row,
+//     with two lane roles inside a row so that per-sample arithmetic is done once, not once per
+//     channel lane:
+//       phase A  lane = (point, corner subset): loads ITS logit / offset / uv, softmax over the P
+//                points by DPP butterfly, sets up the bilinear footprint and keeps
+//                {softmax weight * corner weight / #cams} and the tile rows of its corners;
+//       phase B  lane = channel chunk (HD/16 channels): walks the P points; the point's weights and
+//                rows arrive by DPP row_newbcast (fused into the FMAs -- no LDS traffic, no
+//                ds_bpermute), then 4 corner reads (ds_read_b128 + ds_read_b64) + FMAs.
+//     Global operand loads are software pipelined one iteration ahead (voxel ids two ahead).
+// Every (camera, visible voxel) pair is handled by the workgroup that has that camera's tile in
+// LDS.  Rows of voxels seen by exactly one camera are plain stores; rows seen by several cameras
+// were zeroed by k_zero_rows and are accumulated with fp32 atomics (2 addends commute exactly, so
+// results stay bitwise reproducible as long as no voxel is seen by more than two cameras).
+constexpr int kFwdWaves = kFwdThreads / 64;
+constexpr int kFwdLoaders = 2;
+
+#ifdef VER_DEBUG_TIMING
+__device__ long long g_dbg[256];
+#define VER_STAMP(slot, cond)                                                       \
+    do {                                                                            \
+        if ((cond) && blockIdx.x == VER_DEBUG_BLOCK && (threadIdx.x & 63) == 0)     \
+            g_dbg[slot] = (long long)__builtin_amdgcn_s_memtime();                  \
+    } while (0)
+extern "C" int ver_debug_read(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), n * sizeof(long long));
+}
+#else
+#define VER_STAMP(slot, cond) \
+    do {                      \
+    } while (0)
+#endif
+
+template <int N>
+__device__ __forceinline__ float row_bcast_f(float v) {   // every lane reads lane N of its own 16-lane row
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ unsigned row_bcast_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, false);
+}
+
+template <int HD, int G>
+__device__ __forceinline__ void emit_row(float* row, int gl, const float (&acc)[HD / G], bool single) {
+    if (single) {
+        store_ch<HD, G>(row, gl, acc);
+    } else {
+        atomic_add_ch<HD, G>(row, gl, 1.0f, acc);
+    }
+}
+
+// one point of phase B: weights/rows of point PT come from lanes PT*LPP .. PT*LPP+LPP-1 of the row
+template <int HD, int P, int PT, typename VT>
+__device__ __forceinline__ void consume_point(const VT* tile, int gl, const float (&wsel)[2], unsigned ksel,
+                                              float (&acc)[HD / 16]) {
+    constexpr int LPP = 16 / P;          // lanes per point (2 for P=8, 4 for P=4)
+    constexpr int CPN = 4 / LPP;         // corners per lane (2 / 1)
+    constexpr int CPL = HD / 16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int reg = t % CPN;
+        float w;
+        unsigned key;
+        // lane PT*LPP + t/CPN of this row holds corner t in register `reg`
+        if (t / CPN == 0) {
+            w = row_bcast_f<PT * LPP + 0>(wsel[reg]);
+            key = row_bcast_u<PT * LPP + 0>(ksel);
+        } else if (t / CPN == 1) {
+            w = row_bcast_f<PT * LPP + (LPP > 1 ? 1 : 0)>(wsel[reg]);
+            key = row_bcast_u<PT * LPP + (LPP > 1 ? 1 : 0)>(ksel);
+        } else if (t / CPN == 2) {
+            w = row_bcast_f<PT * LPP + (LPP > 2 ? 2 : 0)>(wsel[reg]);
+            key = row_bcast_u<PT * LPP + (LPP > 2 ? 2 : 0)>(ksel);
+        } else {
+            w = row_bcast_f<PT * LPP + (LPP > 3 ? 3 : 0)>(wsel[reg]);
+            key = row_bcast_u<PT * LPP + (LPP > 3 ? 3 : 0)>(ksel);
+        }
+        key = (key >> (16 * reg)) & 0xffffu;
+        float v[CPL];
+        load_ch<HD, 16, VT>(tile + (size_t)key * HD, gl, v);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) acc[j] += w * v[j];
+    }
+}
+
+template <int HD, int P, int PT, typename VT>
+struct PointLoop {
+    __device__ __forceinline__ static void run(const VT* tile, int gl, const float (&wsel)[2], unsigned ksel,
+                                               float (&acc)[HD / 16]) {
+        consume_point<HD, P, PT, VT>(tile, gl, wsel, ksel, acc);
+        PointLoop<HD, P, PT + 1, VT>::run(tile, gl, wsel, ksel, acc);
+    }
+};
+template <int HD, int P, typename VT>
+struct PointLoop<HD, P, P, VT> {
+    __device__ __forceinline__ static void run(const VT*, int, const float (&)[2], unsigned, float (&)[HD / 16]) {}
+};
+
 template <int HD, int G, int P, typename VT>
-__global__ __launch_bounds__(256) void k_sca_fwd(const VT* __restrict__ value, const float* __restrict__ offs,
-                                                 const float* __restrict__ logits,
-                                                 const float* __restrict__ uv, const uint8_t* __restrict__ vis,
-                                                 const int* __restrict__ own_list,
-                                                 const int* __restrict__ own_cnt, float* __restrict__ slots,
-                                                 int Ncam, int Nq, int D, int heads, int mh, int mw, int nchunks,
-                                                 int chunk) {
+__global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
+    const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
+    const int* __restrict__ vis_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
+    int nchunks, int chunk, int hsplit, int nbuf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    VT* tile = reinterpret_cast<VT*>(smem);
     constexpr int CPL = HD / G;
-    constexpr int VPW = VER_WAVE / G;
+    constexpr int NCONS = kFwdWaves - kFwdLoaders;                     // consumer waves
     const int Nk = mh * mw;
+    const size_t tile_elems = (size_t)Nk * HD;
+    VT* tiles = reinterpret_cast<VT*>(smem);
     int bid = blockIdx.x;
     const int ck = bid % nchunks;
     bid /= nchunks;
-    const int h = bid % heads;
-    bid /= heads;
+    const int hs = bid % hsplit;
+    bid /= hsplit;
     const int c = bid % Ncam;
     const int b = bid / Ncam;
-    const int cnt = own_cnt[b * Ncam + c];
+    const int cnt = vis_cnt[b * Ncam + c];
     const int start = ck * chunk;
     if (start >= cnt) return;
     const int end = min(cnt, start + chunk);
+    const int heads_per = heads / hsplit, h0 = hs * heads_per;
     const size_t rstride = (size_t)heads * HD;
-    const VT* vb = value + (size_t)b * Ncam * Nk * rstride + (size_t)h * HD;   // camera 0 of viewpoint b
-    stage_tile<HD, VT>(tile, vb + (size_t)c * Nk * rstride, rstride, Nk, 256);
-    __syncthreads();
+    const VT* vown = value + ((size_t)b * Ncam + c) * Nk * rstride;   // this camera, head 0
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sub = lane / G, gl = lane % G;
-    const int* list = own_list + ((size_t)b * Ncam + c) * Nq;
-    for (int i = start + wave * VPW + sub; i < end; i += 4 * VPW) {
-        const int n = list[i];
-        const unsigned m = vis[(size_t)b * Nq + n];
-        float acc[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-        if (m) {
-            const size_t qh = ((size_t)b * Nq + n) * heads + h;
-            float a[P], ox[P], oy[P];
-            softmax_points<P>(logits + qh * P, a);
-            const float* of = offs + qh * P * 2;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                ox[p] = __fdiv_rn(of[2 * p], (float)mw);
-                oy[p] = __fdiv_rn(of[2 * p + 1], (float)mh);
-            }
-            unsigned mm = m;
-            while (mm) {
-                const int cc = __ffs((int)mm) - 1;
-                mm &= mm - 1;
-                const float* u = uv + (((size_t)b * Ncam + cc) * Nq + n) * D * 2;
-                float cam[CPL];
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) cam[j] = 0.0f;
-                if (cc == c)
-                    gather_camera<HD, G, P, VT>(tile, (size_t)HD, u, D, ox, oy, a, mh, mw, gl, cam);
-                else
-                    gather_camera<HD, G, P, VT>(vb + (size_t)cc * Nk * rstride, rstride, u, D, ox, oy, a, mh,
-                                                mw, gl, cam);
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) acc[j] += cam[j];
-            }
-            const float cf = (float)__popc(m);
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) acc[j] = __fdiv_rn(acc[j], cf);
+    const bool loader = wave >= NCONS;
+    const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+
+    VER_STAMP(0, wave == 0);
+    if (loader && nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave - NCONS, kFwdLoaders);
+    VER_STAMP(1, loader);
+
+    for (int hh = 0; hh < heads_per; ++hh) {
+        const int h = h0 + hh;
+        const int cur = nbuf == 2 ? (hh & 1) : 0;
+        VT* tile = tiles + cur * tile_elems;
+        if (nbuf == 1) {
+            __syncthreads();                          // consumers are done with the previous head
+            if (loader) stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave - NCONS, kFwdLoaders);
         }
-        store_ch<HD, G>(slots + ((size_t)b * Nq + n) * heads * HD + (size_t)h * HD, gl, acc);
+        if (loader) __builtin_amdgcn_s_waitcnt(0);    // this head's tile has landed
+        VER_STAMP(8 + hh * 8 + 0, loader);
+        VER_STAMP(8 + hh * 8 + 1, wave == 0);
+        __syncthreads();
+        VER_STAMP(8 + hh * 8 + 2, wave == 0);
+        if (loader) {
+            if (nbuf == 2 && hh + 1 < heads_per)
+                stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk,
+                                   wave - NCONS, kFwdLoaders);
+            continue;
+        }
+
+        // ------------------------------------------------------------ consumers
+        if constexpr (G == 16) {
+            constexpr int LPP = 16 / P, CPN = 4 / LPP;
+            constexpr int STEP = NCONS * 4;
+            const int row = lane >> 4, lr = lane & 15;
+            const int ap = lr / LPP, asub = lr % LPP;      // phase A: point, corner subset
+            const int ad = (D == 1) ? 0 : (ap % D);
+            struct Sample {
+                unsigned m;
+                float lg;
+                float2 of, u;
+            };
+            auto load_id = [&](int base) -> int {
+                const int ia = base + row;
+                return ia < end ? list[ia] : -1;
+            };
+            auto load_sample = [&](int n) -> Sample {
+                Sample sm;
+                const int nn = n < 0 ? 0 : n;
+                const size_t qh = ((size_t)b * Nq + nn) * heads + h;
+                sm.m = n < 0 ? 0u : (unsigned)vis[(size_t)b * Nq + nn];
+                sm.lg = logits[qh * P + ap];
+                sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + ap) * 2);
+                sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
+                return sm;
+            };
+            const int base0 = start + wave * 4;
+            int n_cur = load_id(base0);
+            int n_nxt = load_id(base0 + STEP);
+            Sample s_cur = load_sample(n_cur);
+            VER_STAMP(8 + hh * 8 + 3, wave == 0);
+
+            for (int base = base0; base < end; base += STEP) {
+                const Sample s_nxt = load_sample(n_nxt);
+                const int n_nxt2 = load_id(base + 2 * STEP);
+                // ---------------- phase A
+                const unsigned m = s_cur.m;
+                float wsel[2];
+                unsigned ksel;
+                {
+                    const float mx = group_max<16>(s_cur.lg);
+                    const float e = __expf(s_cur.lg - mx);
+                    const float ssum = group_sum<16>(asub == 0 ? e : 0.0f);
+                    const float a = m ? e / (ssum * (float)__popc(m)) : 0.0f;
+                    Bilinear s;
+                    bilinear_setup<false>(s_cur.u.x + s_cur.of.x * inv_w, s_cur.u.y + s_cur.of.y * inv_h, mh, mw, s);
+                    if constexpr (CPN == 2) {
+                        wsel[0] = a * (asub ? s.w[2] : s.w[0]);
+                        wsel[1] = a * (asub ? s.w[3] : s.w[1]);
+                        ksel = asub ? ((unsigned)s.key[2] | ((unsigned)s.key[3] << 16))
+                                    : ((unsigned)s.key[0] | ((unsigned)s.key[1] << 16));
+                    } else {
+                        const float w01 = (asub & 1) ? s.w[1] : s.w[0], w23 = (asub & 1) ? s.w[3] : s.w[2];
+                        const int k01 = (asub & 1) ? s.key[1] : s.key[0], k23 = (asub & 1) ? s.key[3] : s.key[2];
+                        wsel[0] = a * ((asub & 2) ? w23 : w01);
+                        wsel[1] = 0.0f;
+                        ksel = (unsigned)((asub & 2) ? k23 : k01);
+                    }
+                }
+                // ---------------- phase B
+                float acc[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
+                PointLoop<HD, P, 0, VT>::run(tile, lr, wsel, ksel, acc);
+                if (n_cur >= 0)
+                    emit_row<HD, G>(slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD, lr, acc,
+                                    __popc(m) == 1);
+                n_cur = n_nxt;
+                n_nxt = n_nxt2;
+                s_cur = s_nxt;
+            }
+            VER_STAMP(8 + hh * 8 + 4, wave == 0);
+        } else {
+            // narrow heads (HD < 32, test sizes): plain per-lane path, G lanes per voxel
+            constexpr int VPW = VER_WAVE / G;
+            const int sub = lane / G, gl = lane % G;
+            for (int i = start + wave * VPW + sub; i < end; i += NCONS * VPW) {
+                const int nb = list[i];
+                const unsigned mb = vis[(size_t)b * Nq + nb];
+                const size_t qh = ((size_t)b * Nq + nb) * heads + h;
+                float a[P], ox[P], oy[P];
+                softmax_points<P>(logits + qh * P, a);
+                const float* of = offs + qh * P * 2;
+                const float icnt = 1.0f / (float)__popc(mb);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    a[p] *= icnt;
+                    ox[p] = of[2 * p] * inv_w;
+                    oy[p] = of[2 * p + 1] * inv_h;
+                }
+                float acc[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
+                const float* u = uv + (((size_t)b * Ncam + c) * Nq + nb) * D * 2;
+                gather_camera<HD, G, P, VT>(tile, (size_t)HD, u, D, ox, oy, a, mh, mw, gl, acc);
+                emit_row<HD, G>(slots + ((size_t)b * Nq + nb) * heads * HD + (size_t)h * HD, gl, acc,
+                                __popc(mb) == 1);
+            }
+        }
     }
 }
 
@@ -355,9 +580,10 @@ __global__ __launch_bounds__(512) void k_sca_bwd(const VT* __restrict__ value, c
     const int end = min(cnt, start + chunk);
     const size_t rstride = (size_t)heads * HD;
     const size_t tbase = ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
-    for (int i = threadIdx.x; i < Nk * HD; i += 512) gtile[i] = 0.0f;
-    if (start < cnt) stage_tile<HD, VT>(tile, value + tbase, rstride, Nk, 512);
-    __syncthreads();
+    if (start < cnt) stage_tile<HD, VT>(tile, value + tbase, rstride, Nk, threadIdx.x >> 6, 8);
+    for (int i = threadIdx.x; i < Nk * HD / 4; i += 512)
+        reinterpret_cast<float4*>(gtile)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    stage_wait();
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int sub = lane / G, gl = lane % G;
@@ -499,8 +725,8 @@ int check_sca(const void* value, int vdt, const void* a, const void* b, const vo
 extern "C" int ver_project_points(const float* world2pixel, const float* origin, const float* pc_range, int B,
                                   int Ncam, int bev_z, int bev_h, int bev_w, float img_w, float img_h,
                                   float* uv, uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                                  int32_t* own_list, int32_t* own_cnt, void* stream) {
-    VER_REQUIRE(world2pixel && origin && pc_range && uv && vis && vis_list && vis_cnt && own_list && own_cnt,
+                                  int32_t* zero_list, int32_t* zero_cnt, void* stream) {
+    VER_REQUIRE(world2pixel && origin && pc_range && uv && vis && vis_list && vis_cnt && zero_list && zero_cnt,
                 VER_EINVAL, "ver_project_points: null pointer argument");
     VER_REQUIRE(Ncam >= 1 && Ncam <= 8, VER_EUNSUPPORTED, "ver_project_points: Ncam %d outside 1..8", Ncam);
     VER_REQUIRE(B >= 0 && bev_z > 0 && bev_h > 0 && bev_w > 0, VER_EINVAL, "ver_project_points: bad grid");
@@ -516,14 +742,14 @@ extern "C" int ver_project_points(const float* world2pixel, const float* origin,
     int rc = ver_check_launch("ver_project_points/k_project");
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_lists, dim3(Ncam, B), dim3(256), 0, st, vis, Ncam, Nq, vis_list, vis_cnt,
-                       own_list, own_cnt);
+                       zero_list, zero_cnt);
     return ver_check_launch("ver_project_points/k_build_lists");
 }
 
 extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D, uint8_t* vis,
-                                  int32_t* vis_list, int32_t* vis_cnt, int32_t* own_list, int32_t* own_cnt,
+                                  int32_t* vis_list, int32_t* vis_cnt, int32_t* zero_list, int32_t* zero_cnt,
                                   void* stream) {
-    VER_REQUIRE(bev_mask && vis && vis_list && vis_cnt && own_list && own_cnt, VER_EINVAL,
+    VER_REQUIRE(bev_mask && vis && vis_list && vis_cnt && zero_list && zero_cnt, VER_EINVAL,
                 "ver_hits_from_mask: null pointer argument");
     VER_REQUIRE(Ncam >= 1 && Ncam <= 8, VER_EUNSUPPORTED, "ver_hits_from_mask: Ncam %d outside 1..8", Ncam);
     VER_REQUIRE(B >= 0 && Nq > 0 && D > 0, VER_EINVAL, "ver_hits_from_mask: bad sizes");
@@ -533,34 +759,47 @@ extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int 
     int rc = ver_check_launch("ver_hits_from_mask/k_mask_to_vis");
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_lists, dim3(Ncam, B), dim3(256), 0, st, vis, Ncam, Nq, vis_list, vis_cnt,
-                       own_list, own_cnt);
+                       zero_list, zero_cnt);
     return ver_check_launch("ver_hits_from_mask/k_build_lists");
 }
 
 extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
-                               const float* uv, const uint8_t* vis, const int32_t* own_list,
-                               const int32_t* own_cnt, float* slots, int B, int Ncam, int Nq, int D, int heads,
+                               const float* uv, const uint8_t* vis, const int32_t* vis_list,
+                               const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
+                               float* slots, int B, int Ncam, int Nq, int D, int heads,
                                int head_dim, int points, int map_h, int map_w, void* stream) {
-    int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, own_list, own_cnt, B, Ncam, Nq, D, heads,
+    int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
-    VER_REQUIRE(slots, VER_EINVAL, "ver_sca_forward: slots is null");
+    VER_REQUIRE(slots && zero_list && zero_cnt, VER_EINVAL, "ver_sca_forward: null pointer argument");
+    VER_REQUIRE((heads * head_dim) % 4 == 0, VER_EUNSUPPORTED, "ver_sca_forward: row width not a multiple of 4");
     if (B == 0 || Nq == 0) return VER_OK;
-    const size_t lds = (size_t)map_h * map_w * head_dim * sizeof(float);
-    VER_REQUIRE(lds <= kMaxLds, VER_EUNSUPPORTED,
+    const size_t tile_bytes = (size_t)map_h * map_w * head_dim * sizeof(float);
+    VER_REQUIRE(tile_bytes <= kMaxLds, VER_EUNSUPPORTED,
                 "ver_sca_forward: %dx%dx%d value tile (%zu B) exceeds the 160 KiB LDS", map_h, map_w, head_dim,
-                lds);
+                tile_bytes);
+    VER_REQUIRE(map_h * map_w <= 65536, VER_EUNSUPPORTED, "ver_sca_forward: map larger than 65536 tokens");
+    const int nbuf = 2 * tile_bytes <= kMaxLds ? 2 : 1;          // double-buffer the tile when it fits
+    const size_t lds = tile_bytes * nbuf;
     const int nchunks = (Nq + kFwdChunk - 1) / kFwdChunk;
+    // heads are walked inside a workgroup (the tile stream is double buffered); split them over
+    // several workgroups only while the grid would not yet fill the 256 CUs a few times over
+    int hsplit = 1;
+    while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < 768) hsplit *= 2;
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, st, zero_list, zero_cnt, slots, Nq,
+                       heads * head_dim);
+    rc = ver_check_launch("ver_sca_forward/k_zero_rows");
+    if (rc) return rc;
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
         auto kern = k_sca_fwd<HD, G, P, float>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
-        const unsigned blocks = (unsigned)B * Ncam * heads * nchunks;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, st, (const float*)value, offsets, logits, uv, vis,
-                           own_list, own_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk);
+        const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(kFwdThreads), lds, st, (const float*)value, offsets, logits, uv, vis,
+                           vis_list, vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsplit, nbuf);
         return ver_check_launch("ver_sca_forward");
     });
 }

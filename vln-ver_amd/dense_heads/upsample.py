@@ -109,12 +109,21 @@ def _layer_lattice(e, k, bias, prev_bias):
     return out
 
 
+def _compute_dtype(x):
+    """bf16 under ``torch.autocast`` (im2col, GEMM operands and lattices all in bf16, fp32
+    accumulation inside the GEMM), else the input's dtype."""
+    if x.is_cuda and torch.is_autocast_enabled('cuda'):
+        return torch.get_autocast_dtype('cuda')
+    return x.dtype
+
+
 def upsample_lattice(x0, weights, biases):
     """x0 [B,C,Z,H,W] -> (E_3 channels-last [B,Z,4H,4W,C], last bias).  E_3 holds the even
     positions of the reference's dense output ``up_sample(x0)`` [B,C,Z,8H,8W]."""
-    e = x0.permute(0, 2, 3, 4, 1)
-    ks = [_corr_weight(w).to(x0.dtype) for w in weights]
-    bs = [b.to(x0.dtype) for b in biases]
+    dt = _compute_dtype(x0)
+    e = x0.permute(0, 2, 3, 4, 1).to(dt)
+    ks = [_corr_weight(w).to(dt) for w in weights]
+    bs = [b.to(dt) for b in biases]
     e = _layer0(e, ks[0], bs[0])
     e = _layer_lattice(e, ks[1], bs[1], bs[0])
     e = _layer_lattice(e, ks[2], bs[2], bs[1])

@@ -264,6 +264,15 @@ class VoxelFormerOccupancyHead(BaseModule):
             occ = occ.permute(0, 3, 1, 2, 4)
         return self.occ_branches(occ.reshape(bs, -1, self.occ_dims))
 
+    def occupancy_loss(self, occupancy_preds, gt_occupancy):
+        """Occupancy term of ``loss_single`` (head:977-989): sigmoid focal loss over
+        [N, classes] logits with integer targets in [0, classes] (``classes`` = empty voxel),
+        normalised by the number of occupied voxels, NaN-guarded."""
+        preds = occupancy_preds.reshape(-1, self.occupancy_classes).float()
+        gt = gt_occupancy.reshape(-1)
+        avg = (gt < self.occupancy_classes).sum() * 1.0
+        return torch.nan_to_num(self.loss_occupancy(preds, gt, avg_factor=avg))
+
     def lift(self, mlvl_feats, img_metas=None, **kwargs):
         """The lifting path alone (encoder + occupancy branch, no detection decoder):
         -> (voxel_embed [bs,Nq,C], occupancy logits [bs, X*Y*Z, classes])."""

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward')
 
@@ -48,6 +48,40 @@ def _check(rc, what):
     if rc != 0:
         msg = lib().ver_last_error()
         raise RuntimeError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+class KernelTimer:
+    """Optional HIP-event timing of every C-ABI launch (bench.py's roofline leg).  Events are
+    recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, meta)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, meta in self.records:
+            d = out.setdefault(name, dict(count=0, ms=0.0, meta=meta))
+            d['count'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
+KERNEL_TIMER = None
+
+
+def _launch(name, fn, meta=None):
+    """Run ``fn`` (one C-ABI call) and check its return code; time it when a timer is set."""
+    timer = KERNEL_TIMER
+    if timer is None:
+        return _check(fn(), name)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    timer.records.append((name, e0, e1, meta))
+    return _check(rc, name)
 
 
 def _p(t):
@@ -116,7 +150,7 @@ MultiScaleDeformableAttnFunction_fp16 = MultiScaleDeformableAttnFunction_fp32
 class HitTable:
     """Per-batch visibility structure (layout: include/ver_ops.h, "Hit table")."""
 
-    __slots__ = ('uv', 'vis', 'vis_list', 'vis_cnt', 'own_list', 'own_cnt', 'B', 'Ncam', 'Nq', 'D')
+    __slots__ = ('uv', 'vis', 'vis_list', 'vis_cnt', 'zero_list', 'zero_cnt', 'B', 'Ncam', 'Nq', 'D')
 
     def __init__(self, B, Ncam, Nq, D, device):
         self.B, self.Ncam, self.Nq, self.D = B, Ncam, Nq, D
@@ -124,8 +158,8 @@ class HitTable:
         self.vis = torch.empty(B, Nq, dtype=torch.uint8, device=device)
         self.vis_list = torch.empty(B, Ncam, Nq, dtype=torch.int32, device=device)
         self.vis_cnt = torch.empty(B, Ncam, dtype=torch.int32, device=device)
-        self.own_list = torch.empty(B, Ncam, Nq, dtype=torch.int32, device=device)
-        self.own_cnt = torch.empty(B, Ncam, dtype=torch.int32, device=device)
+        self.zero_list = torch.empty(B, Nq, dtype=torch.int32, device=device)
+        self.zero_cnt = torch.empty(B, dtype=torch.int32, device=device)
 
     def mask(self):
         """bool [Ncam, B, Nq, 1] in the reference's bev_mask layout (for inspection/tests)."""
@@ -143,10 +177,10 @@ def project_points(world2pixel, origin, pc_range, bev_z, bev_h, bev_w, img_w=128
     nq = bev_z * bev_h * bev_w
     hit = HitTable(B, ncam, nq, 1, w2p.device)
     rng = (ctypes.c_float * 6)(*[float(v) for v in pc_range])
-    _check(lib().ver_project_points(_p(w2p), _p(org), rng, B, ncam, bev_z, bev_h, bev_w,
-                                    ctypes.c_float(img_w), ctypes.c_float(img_h), _p(hit.uv),
-                                    _p(hit.vis), _p(hit.vis_list), _p(hit.vis_cnt), _p(hit.own_list),
-                                    _p(hit.own_cnt), _stream()), 'ver_project_points')
+    _launch('ver_project_points', lambda: lib().ver_project_points(
+        _p(w2p), _p(org), rng, B, ncam, bev_z, bev_h, bev_w, ctypes.c_float(img_w), ctypes.c_float(img_h),
+        _p(hit.uv), _p(hit.vis), _p(hit.vis_list), _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt),
+        _stream()))
     return hit
 
 
@@ -158,7 +192,7 @@ def hits_from_mask(reference_points_cam, bev_mask):
     hit = HitTable(B, ncam, nq, D, mask.device)
     hit.uv.copy_(reference_points_cam.to(torch.float32).permute(1, 0, 2, 3, 4))
     _check(lib().ver_hits_from_mask(_p(mask), B, ncam, nq, D, _p(hit.vis), _p(hit.vis_list),
-                                    _p(hit.vis_cnt), _p(hit.own_list), _p(hit.own_cnt), _stream()),
+                                    _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _stream()),
            'ver_hits_from_mask')
     return hit
 
@@ -178,9 +212,10 @@ class SCAGatherFunction(Function):
         assert nk == map_h * map_w and B == hit.B and ncam == hit.Ncam
         assert offsets.shape == (B, nq, heads, points, 2) and logits.shape == (B, nq, heads, points)
         slots = value.new_empty(B, nq, heads * hd)
-        _check(lib().ver_sca_forward(_p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis),
-                                     _p(hit.own_list), _p(hit.own_cnt), _p(slots), B, ncam, nq, hit.D,
-                                     heads, hd, points, map_h, map_w, _stream()), 'ver_sca_forward')
+        _launch('ver_sca_forward', lambda: lib().ver_sca_forward(
+            _p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
+            _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(slots), B, ncam, nq, hit.D, heads, hd,
+            points, map_h, map_w, _stream()))
         ctx.save_for_backward(value, offsets, logits)
         ctx.hit, ctx.map_hw = hit, (map_h, map_w)
         return slots
@@ -198,10 +233,10 @@ class SCAGatherFunction(Function):
         g_value = torch.empty_like(value)
         g_off = torch.empty_like(offsets)
         g_log = torch.empty_like(logits)
-        _check(lib().ver_sca_backward(_p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis),
-                                      _p(hit.vis_list), _p(hit.vis_cnt), _p(gs), _p(g_value),
-                                      _p(g_off), _p(g_log), B, ncam, hit.Nq, hit.D, heads, hd, points,
-                                      map_h, map_w, _stream()), 'ver_sca_backward')
+        _launch('ver_sca_backward', lambda: lib().ver_sca_backward(
+            _p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
+            _p(hit.vis_cnt), _p(gs), _p(g_value), _p(g_off), _p(g_log), B, ncam, hit.Nq, hit.D, heads,
+            hd, points, map_h, map_w, _stream()))
         return g_value, g_off, g_log, None, None, None
 
 

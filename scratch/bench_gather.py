@@ -8,12 +8,14 @@ import cases
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 grid = (4, 15, 15) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split('x'))
 iters = 20
+BF16 = len(sys.argv) > 3 and sys.argv[3] == 'bf16'
 dev = 'cuda'
 z, h, w = grid; nq = z*h*w
 w2p, org = syn.camera_batch(B, seed=1)
 hit = hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, z, h, w)
 g = torch.Generator(device=dev).manual_seed(0)
 value = torch.randn(B, 6, 196, 8, 96, device=dev, generator=g)
+if BF16: value = value.to(torch.bfloat16)
 offs = torch.randn(B, nq, 8, 8, 2, device=dev, generator=g) * 3
 logits = torch.randn(B, nq, 8, 8, device=dev, generator=g)
 gs = torch.randn(B, nq, 768, device=dev, generator=g)
@@ -33,5 +35,5 @@ t_f = timeit(lambda: hip.sca_gather(value, offs, logits, hit, 14, 14))
 s = hip.sca_gather(v, o, l, hit, 14, 14)
 t_b = timeit(lambda: torch.autograd.grad(s, [v, o, l], gs, retain_graph=True))
 t_p = timeit(lambda: hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, z, h, w))
-print(json.dumps(dict(B=B, grid=grid, sigma_n=sn, fwd_us=round(t_f,1), fwd_GBs=round(fwd_b/t_f/1e3,1), fwd_frac=round(fwd_b/t_f/1e3/8000,4),
+print(json.dumps(dict(bf16=BF16, B=B, grid=grid, sigma_n=sn, fwd_us=round(t_f,1), fwd_GBs=round(fwd_b/t_f/1e3,1), fwd_frac=round(fwd_b/t_f/1e3/8000,4),
                       bwd_us=round(t_b,1), bwd_GBs=round(bwd_b/t_b/1e3,1), bwd_frac=round(bwd_b/t_b/1e3/8000,4), project_us=round(t_p,1))))

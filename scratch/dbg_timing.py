@@ -15,7 +15,7 @@ out = (ctypes.c_longlong*256)()
 hip.lib().ver_debug_read(out, 256)
 t = list(out)
 t0 = t[0]
-print('own_cnt', hit.own_cnt[0].tolist(), 'vis_cnt', hit.vis_cnt[0].tolist())
+print('zero_cnt', hit.zero_cnt.tolist(), 'vis_cnt', hit.vis_cnt[0].tolist())
 print('start->loader issued first tile: %d ticks' % (t[1]-t0))
 for hh in range(4):
     b = 8+hh*8

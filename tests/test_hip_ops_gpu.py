@@ -224,6 +224,32 @@ def test_sca_gather_forward_backward_vs_oracle(heads, hd, P, grid, mhw):
     assert torch.equal(again, slots.detach())
 
 
+@pytest.mark.parametrize('heads,hd,P,grid', [(8, 96, 8, (4, 15, 15)), (2, 32, 4, (2, 6, 5)), (4, 8, 8, (2, 6, 5))])
+def test_sca_gather_bf16_value(heads, hd, P, grid):
+    """value stored as bf16 (what value_proj emits under bf16 autocast): the kernel reads bf16 and
+    computes in fp32, so against the oracle evaluated on the SAME bf16-rounded values the fp32
+    tolerances still hold."""
+    hip = pkg('hipops')
+    o = oracle()
+    hit, value, offsets, logits, gslots = _random_sca_case(17, 2, grid, heads, hd, P)
+    vb = T(value).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    of = T(offsets).to(DEV).requires_grad_(True)
+    lg = T(logits).to(DEV).requires_grad_(True)
+    slots = hip.sca_gather(vb, of, lg, hit, 14, 14)
+    assert slots.dtype == torch.float32
+    slots.backward(T(gslots).to(DEV))
+    assert vb.grad.dtype == torch.bfloat16
+    mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()
+    vc = vb.detach().float().cpu().requires_grad_(True)
+    oc, lc = T(offsets).requires_grad_(True), T(logits).requires_grad_(True)
+    ref = oracle_slots(o, vc, oc, lc, hit.uv.cpu(), mask, (14, 14))
+    ref.backward(T(gslots))
+    assert maxdiff(slots.detach().cpu(), ref.detach()) < 2e-5
+    assert close(of.grad.cpu(), oc.grad)
+    assert close(lg.grad.cpu(), lc.grad)
+    assert close(vb.grad.float().cpu(), vc.grad, atol=2e-2, rtol=1e-2)      # grad rounded to bf16
+
+
 def test_sca_gather_multi_camera_and_anchors():
     """Hand-made masks: voxels seen by all 6 cameras, by none, a camera that sees nothing, and
     D=2 Z-anchors (which the reference's MSDA3D supports although vocc produces D=1)."""

@@ -306,7 +306,7 @@ __device__ __forceinline__ void stage_wait() {
 // were zeroed by k_zero_rows and are accumulated with fp32 atomics (2 addends commute exactly, so
 // results stay bitwise reproducible as long as no voxel is seen by more than two cameras).
 constexpr int kFwdWaves = kFwdThreads / 64;
-constexpr int kFwdLoaders = 2;
+constexpr int kFwdLoaders = 0;   // 0: every wave issues its share of the next tile's LDS-DMA
 
 #ifdef VER_DEBUG_TIMING
 __device__ long long g_dbg[256];
@@ -343,53 +343,53 @@ __device__ __forceinline__ void emit_row(float* row, int gl, const float (&acc)[
     }
 }
 
-// one point of phase B: weights/rows of point PT come from lanes PT*LPP .. PT*LPP+LPP-1 of the row
+// one point of phase B: weights / row byte offsets of point PT come from lanes PT*LPP .. of the row
 template <int HD, int P, int PT, typename VT>
-__device__ __forceinline__ void consume_point(const VT* tile, int gl, const float (&wsel)[2], unsigned ksel,
+__device__ __forceinline__ void consume_point(const unsigned char* tile0, const unsigned char* tile1,
+                                              const float (&wsel)[2], const unsigned (&ksel)[2],
                                               float (&acc)[HD / 16]) {
     constexpr int LPP = 16 / P;          // lanes per point (2 for P=8, 4 for P=4)
     constexpr int CPN = 4 / LPP;         // corners per lane (2 / 1)
-    constexpr int CPL = HD / 16;
+    using M = ChMap<HD, 16>;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int reg = t % CPN;
         float w;
-        unsigned key;
-        // lane PT*LPP + t/CPN of this row holds corner t in register `reg`
+        unsigned koff;                   // byte offset of the corner's tile row
         if (t / CPN == 0) {
             w = row_bcast_f<PT * LPP + 0>(wsel[reg]);
-            key = row_bcast_u<PT * LPP + 0>(ksel);
+            koff = row_bcast_u<PT * LPP + 0>(ksel[reg]);
         } else if (t / CPN == 1) {
             w = row_bcast_f<PT * LPP + (LPP > 1 ? 1 : 0)>(wsel[reg]);
-            key = row_bcast_u<PT * LPP + (LPP > 1 ? 1 : 0)>(ksel);
+            koff = row_bcast_u<PT * LPP + (LPP > 1 ? 1 : 0)>(ksel[reg]);
         } else if (t / CPN == 2) {
             w = row_bcast_f<PT * LPP + (LPP > 2 ? 2 : 0)>(wsel[reg]);
-            key = row_bcast_u<PT * LPP + (LPP > 2 ? 2 : 0)>(ksel);
+            koff = row_bcast_u<PT * LPP + (LPP > 2 ? 2 : 0)>(ksel[reg]);
         } else {
             w = row_bcast_f<PT * LPP + (LPP > 3 ? 3 : 0)>(wsel[reg]);
-            key = row_bcast_u<PT * LPP + (LPP > 3 ? 3 : 0)>(ksel);
+            koff = row_bcast_u<PT * LPP + (LPP > 3 ? 3 : 0)>(ksel[reg]);
         }
-        key = (key >> (16 * reg)) & 0xffffu;
-        float v[CPL];
-        load_ch<HD, 16, VT>(tile + (size_t)key * HD, gl, v);
+        float v[M::CPL];
+        load_vec<M::W0>(reinterpret_cast<const VT*>(tile0 + koff), v);
+        load_vec<M::W1>(reinterpret_cast<const VT*>(tile1 + koff), v + M::W0);
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) acc[j] += w * v[j];
+        for (int j = 0; j < M::CPL; ++j) acc[j] += w * v[j];
     }
 }
 
 template <int HD, int P, int PT, typename VT>
 struct PointLoop {
-    __device__ __forceinline__ static void run(const VT* tile, int gl, const float (&wsel)[2], unsigned ksel,
+    __device__ __forceinline__ static void run(const unsigned char* tile0, const unsigned char* tile1,
+                                               const float (&wsel)[2], const unsigned (&ksel)[2],
                                                float (&acc)[HD / 16]) {
-        consume_point<HD, P, PT, VT>(tile, gl, wsel, ksel, acc);
-        PointLoop<HD, P, PT + 1, VT>::run(tile, gl, wsel, ksel, acc);
+        consume_point<HD, P, PT, VT>(tile0, tile1, wsel, ksel, acc);
+        PointLoop<HD, P, PT + 1, VT>::run(tile0, tile1, wsel, ksel, acc);
     }
 };
 template <int HD, int P, typename VT>
 struct PointLoop<HD, P, P, VT> {
-    __device__ __forceinline__ static void run(const VT*, int, const float (&)[2], unsigned, float (&)[HD / 16]) {}
+    __device__ __forceinline__ static void run(const unsigned char*, const unsigned char*, const float (&)[2],
+                                               const unsigned (&)[2], float (&)[HD / 16]) {}
 };
 
 template <int HD, int G, int P, typename VT>
@@ -420,12 +420,15 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
     const VT* vown = value + ((size_t)b * Ncam + c) * Nk * rstride;   // this camera, head 0
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool loader = wave >= NCONS;
+    const bool loader = kFwdLoaders > 0 && wave >= NCONS;
+    const int dma_wave = kFwdLoaders > 0 ? wave - NCONS : wave;
+    constexpr int kDmaWaves = kFwdLoaders > 0 ? kFwdLoaders : kFwdWaves;
+    const bool issues_dma = kFwdLoaders == 0 || loader;
     const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
     const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
 
     VER_STAMP(0, wave == 0);
-    if (loader && nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave - NCONS, kFwdLoaders);
+    if (issues_dma && nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, dma_wave, kDmaWaves);
     VER_STAMP(1, loader);
 
     for (int hh = 0; hh < heads_per; ++hh) {
@@ -434,19 +437,17 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
         VT* tile = tiles + cur * tile_elems;
         if (nbuf == 1) {
             __syncthreads();                          // consumers are done with the previous head
-            if (loader) stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave - NCONS, kFwdLoaders);
+            if (issues_dma) stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, dma_wave, kDmaWaves);
         }
-        if (loader) __builtin_amdgcn_s_waitcnt(0);    // this head's tile has landed
+        if (issues_dma) __builtin_amdgcn_s_waitcnt(0);    // this wave's share of the head's tile has landed
         VER_STAMP(8 + hh * 8 + 0, loader);
         VER_STAMP(8 + hh * 8 + 1, wave == 0);
         __syncthreads();
         VER_STAMP(8 + hh * 8 + 2, wave == 0);
-        if (loader) {
-            if (nbuf == 2 && hh + 1 < heads_per)
-                stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk,
-                                   wave - NCONS, kFwdLoaders);
-            continue;
-        }
+        if (issues_dma && nbuf == 2 && hh + 1 < heads_per)
+            stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, dma_wave,
+                               kDmaWaves);
+        if (loader) continue;
 
         // ------------------------------------------------------------ consumers
         if constexpr (G == 16) {
@@ -474,6 +475,9 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                 sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
                 return sm;
             };
+            using M16 = ChMap<HD, 16>;
+            const unsigned char* tile0 = reinterpret_cast<const unsigned char*>(tile + M16::off0(lr));
+            const unsigned char* tile1 = reinterpret_cast<const unsigned char*>(tile + M16::off1(lr));
             const int base0 = start + wave * 4;
             int n_cur = load_id(base0);
             int n_nxt = load_id(base0 + STEP);
@@ -486,7 +490,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                 // ---------------- phase A
                 const unsigned m = s_cur.m;
                 float wsel[2];
-                unsigned ksel;
+                unsigned ksel[2];                      // byte offsets of this lane's corner rows
+                constexpr unsigned kRowBytes = HD * sizeof(VT);
                 {
                     const float mx = group_max<16>(s_cur.lg);
                     const float e = __expf(s_cur.lg - mx);
@@ -497,21 +502,22 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                     if constexpr (CPN == 2) {
                         wsel[0] = a * (asub ? s.w[2] : s.w[0]);
                         wsel[1] = a * (asub ? s.w[3] : s.w[1]);
-                        ksel = asub ? ((unsigned)s.key[2] | ((unsigned)s.key[3] << 16))
-                                    : ((unsigned)s.key[0] | ((unsigned)s.key[1] << 16));
+                        ksel[0] = (unsigned)(asub ? s.key[2] : s.key[0]) * kRowBytes;
+                        ksel[1] = (unsigned)(asub ? s.key[3] : s.key[1]) * kRowBytes;
                     } else {
                         const float w01 = (asub & 1) ? s.w[1] : s.w[0], w23 = (asub & 1) ? s.w[3] : s.w[2];
                         const int k01 = (asub & 1) ? s.key[1] : s.key[0], k23 = (asub & 1) ? s.key[3] : s.key[2];
                         wsel[0] = a * ((asub & 2) ? w23 : w01);
                         wsel[1] = 0.0f;
-                        ksel = (unsigned)((asub & 2) ? k23 : k01);
+                        ksel[0] = (unsigned)((asub & 2) ? k23 : k01) * kRowBytes;
+                        ksel[1] = 0u;
                     }
                 }
                 // ---------------- phase B
                 float acc[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-                PointLoop<HD, P, 0, VT>::run(tile, lr, wsel, ksel, acc);
+                PointLoop<HD, P, 0, VT>::run(tile0, tile1, wsel, ksel, acc);
                 if (n_cur >= 0)
                     emit_row<HD, G>(slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD, lr, acc,
                                     __popc(m) == 1);
@@ -709,7 +715,9 @@ int check_sca(const void* value, int vdt, const void* a, const void* b, const vo
               const void* e, const void* f, int B, int Ncam, int Nq, int D, int heads, int hd, int points,
               int mh, int mw) {
     VER_REQUIRE(value && a && b && c && d && e && f, VER_EINVAL, "ver_sca: null pointer argument");
-    VER_REQUIRE(vdt == VER_F32, VER_EUNSUPPORTED, "ver_sca: value_dtype %d not built (fp32 only)", vdt);
+    VER_REQUIRE(vdt == VER_F32 || vdt == VER_BF16, VER_EINVAL, "ver_sca: value_dtype %d is neither VER_F32 nor VER_BF16",
+                vdt);
+    VER_REQUIRE(vdt == VER_F32 || hd % 8 == 0, VER_EUNSUPPORTED, "ver_sca: bf16 value needs head_dim %% 8 == 0");
     VER_REQUIRE(B >= 0 && Nq >= 0, VER_EINVAL, "ver_sca: negative batch/voxel count");
     VER_REQUIRE(Ncam >= 1 && Ncam <= 8, VER_EUNSUPPORTED, "ver_sca: Ncam %d outside 1..8", Ncam);
     VER_REQUIRE(heads > 0 && mh > 0 && mw > 0 && D > 0, VER_EINVAL, "ver_sca: non-positive size");
@@ -774,7 +782,8 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     VER_REQUIRE(slots && zero_list && zero_cnt, VER_EINVAL, "ver_sca_forward: null pointer argument");
     VER_REQUIRE((heads * head_dim) % 4 == 0, VER_EUNSUPPORTED, "ver_sca_forward: row width not a multiple of 4");
     if (B == 0 || Nq == 0) return VER_OK;
-    const size_t tile_bytes = (size_t)map_h * map_w * head_dim * sizeof(float);
+    const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
+    const size_t tile_bytes = (size_t)map_h * map_w * head_dim * esz;
     VER_REQUIRE(tile_bytes <= kMaxLds, VER_EUNSUPPORTED,
                 "ver_sca_forward: %dx%dx%d value tile (%zu B) exceeds the 160 KiB LDS", map_h, map_w, head_dim,
                 tile_bytes);
@@ -793,14 +802,20 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     if (rc) return rc;
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
-        auto kern = k_sca_fwd<HD, G, P, float>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
-        const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(kFwdThreads), lds, st, (const float*)value, offsets, logits, uv, vis,
-                           vis_list, vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsplit, nbuf);
-        return ver_check_launch("ver_sca_forward");
+        auto launch = [&](auto kern, auto vptr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
+            const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(kFwdThreads), lds, st, vptr, offsets, logits, uv, vis, vis_list,
+                               vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsplit, nbuf);
+            return ver_check_launch("ver_sca_forward");
+        };
+        if constexpr (HD % 8 == 0) {
+            if (value_dtype == VER_BF16) return launch(k_sca_fwd<HD, G, P, uint16_t>, (const uint16_t*)value);
+        }
+        return launch(k_sca_fwd<HD, G, P, float>, (const float*)value);
     });
 }
 
@@ -815,7 +830,8 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits, VER_EINVAL,
                 "ver_sca_backward: null gradient pointer");
     if (B == 0 || Nq == 0) return VER_OK;
-    const size_t lds = (size_t)map_h * map_w * head_dim * (sizeof(float) + sizeof(float));
+    const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
+    const size_t lds = (size_t)map_h * map_w * head_dim * (sizeof(float) + esz);
     VER_REQUIRE(lds <= kMaxLds, VER_EUNSUPPORTED,
                 "ver_sca_backward: %dx%dx%d tiles (%zu B) exceed LDS", map_h, map_w, head_dim, lds);
     const int nchunks = (Nq + kBwdChunk - 1) / kBwdChunk;
@@ -828,15 +844,20 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_backward: memset: %s", hipGetErrorString(e));
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
-        auto kern = k_sca_bwd<HD, G, P, float>;
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e2 != hipSuccess)
-            return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
-        const unsigned blocks = (unsigned)B * Ncam * heads * nchunks;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, (const float*)value, offsets, logits, uv, vis,
-                           vis_list, vis_cnt, grad_slots, grad_value, grad_offsets, grad_logits, Ncam, Nq, D,
-                           heads, map_h, map_w, nchunks, kBwdChunk);
-        return ver_check_launch("ver_sca_backward");
+        auto launch = [&](auto kern, auto vptr) {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 != hipSuccess)
+                return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
+            const unsigned blocks = (unsigned)B * Ncam * heads * nchunks;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, vptr, offsets, logits, uv, vis, vis_list, vis_cnt,
+                               grad_slots, grad_value, grad_offsets, grad_logits, Ncam, Nq, D, heads, map_h, map_w,
+                               nchunks, kBwdChunk);
+            return ver_check_launch("ver_sca_backward");
+        };
+        if constexpr (HD % 8 == 0) {
+            if (value_dtype == VER_BF16) return launch(k_sca_bwd<HD, G, P, uint16_t>, (const uint16_t*)value);
+        }
+        return launch(k_sca_bwd<HD, G, P, float>, (const float*)value);
     });
 }

@@ -198,31 +198,35 @@ def hits_from_mask(reference_points_cam, bev_mask):
 
 
 class SCAGatherFunction(Function):
-    """slots = fused multi-view gather (ver_sca_forward / ver_sca_backward)."""
+    """slots = fused multi-view gather (ver_sca_forward / ver_sca_backward).
+
+    ``value`` may be fp32 or bf16 (what ``value_proj`` emits under bf16 autocast): the kernels
+    read it as stored and do all arithmetic in fp32, like the reference's fp32-forced op."""
 
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, value, offsets, logits, hit, map_h, map_w):
-        value = _gpu(value, 'value', torch.float32)
-        offsets = _gpu(offsets, 'offsets', torch.float32)
-        logits = _gpu(logits, 'logits', torch.float32)
+        if value.dtype not in (torch.float32, torch.bfloat16):
+            value = value.float()
+        value = _gpu(value, 'value')
+        offsets = _gpu(offsets, 'offsets').float().contiguous()
+        logits = _gpu(logits, 'logits').float().contiguous()
+        vdt = 1 if value.dtype == torch.bfloat16 else 0
         B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
         nq = hit.Nq
         assert nk == map_h * map_w and B == hit.B and ncam == hit.Ncam
         assert offsets.shape == (B, nq, heads, points, 2) and logits.shape == (B, nq, heads, points)
-        slots = value.new_empty(B, nq, heads * hd)
+        slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)
         _launch('ver_sca_forward', lambda: lib().ver_sca_forward(
-            _p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
+            _p(value), vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(slots), B, ncam, nq, hit.D, heads, hd,
             points, map_h, map_w, _stream()))
         ctx.save_for_backward(value, offsets, logits)
-        ctx.hit, ctx.map_hw = hit, (map_h, map_w)
+        ctx.hit, ctx.map_hw, ctx.vdt = hit, (map_h, map_w), vdt
         return slots
 
     @staticmethod
     @once_differentiable
-    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_slots):
         value, offsets, logits = ctx.saved_tensors
         hit = ctx.hit
@@ -230,14 +234,14 @@ class SCAGatherFunction(Function):
         B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
         gs = _gpu(grad_slots, 'grad_slots').float().contiguous()
-        g_value = torch.empty_like(value)
+        g_value = torch.empty(value.shape, dtype=torch.float32, device=value.device)
         g_off = torch.empty_like(offsets)
         g_log = torch.empty_like(logits)
         _launch('ver_sca_backward', lambda: lib().ver_sca_backward(
-            _p(value), 0, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
+            _p(value), ctx.vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(gs), _p(g_value), _p(g_off), _p(g_log), B, ncam, hit.Nq, hit.D, heads,
             hd, points, map_h, map_w, _stream()))
-        return g_value, g_off, g_log, None, None, None
+        return g_value.to(value.dtype), g_off, g_log, None, None, None
 
 
 def sca_gather(value, offsets, logits, hit, map_h, map_w):

@@ -107,7 +107,9 @@ def cpu_baseline(head, syn, seconds):
     """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this
     host's cores: vocc.py lifting path fwd+bwd for ONE viewpoint at a time."""
     oracle = importlib.import_module('oracle.ver_oracle')
-    torch.set_num_threads(os.cpu_count() or 1)
+    # all cores of a 256-thread host oversubscribe these small CPU ops (measured 6x slower than 8
+    # threads); 16 is near the knee.  `cores` reports what was actually used.
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     p = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and k != 'code_weights')
          for k, v in head.state_dict().items()}
     w2p, org = syn.camera_batch(1, seed=1)
@@ -120,7 +122,7 @@ def cpu_baseline(head, syn, seconds):
         loss.backward()
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 4:
+        if dt >= seconds or n >= 3:
             break
     return dict(value=n / dt, unit='viewpoints/s', cores=torch.get_num_threads(), kind='port',
                 sample='%d viewpoint(s), vocc.py 15x15x4 -> 120x120x35x16 lifting path fwd+bwd, fp32, '

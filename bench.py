@@ -149,10 +149,7 @@ def main():
     model.train(train)
     ddp = model                                 # train(): dropout ON, as in the reference's step
     if world > 1 and train:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True,
-                                                        bucket_cap_mb=200)
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+        ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True) if train else None
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 2
+#define VER_ABI_VERSION 4
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -148,6 +148,36 @@ int ver_sca_backward(const void* value, int value_dtype, const float* offsets, c
                      float* grad_value, float* grad_offsets, float* grad_logits,
                      int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                      int map_h, int map_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Data movement of the even-lattice coarse-to-fine upsample: the reference's three
+ * ConvTranspose3d(768,768,(3,5,5),s=(1,2,2),p=(2,4,4),d=(2,2,2),op=(0,1,1))
+ * (dense_heads/voxelformer_occupancy_head.py:251-258, applied at :560) are evaluated as
+ * im2col + GEMM over the channels-last data lattice.
+ *   src  f32|bf16 [B, Z, H, W, C]            channels-last lattice
+ *   col  f32|bf16 [B*Z*H*W, ntaps, C]        col[(b,z,y,x), t, :] = src[b, z+dz_t, y+dy_t, x+dx_t, :]
+ *                                             (zero outside the lattice)
+ *   taps HOST pointer to ntaps*(dz,dy,dx) int32 offsets, ntaps <= 80
+ * ver_lattice_col2im is the adjoint (gradient of im2col), in gather form (no atomics).
+ */
+int ver_lattice_im2col(const void* src, void* col, const int* taps, int ntaps,
+                       int B, int Z, int H, int W, int C, int dtype, void* stream);
+int ver_lattice_col2im(const void* grad_col, void* grad_src, const int* taps, int ntaps,
+                       int B, int Z, int H, int W, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused LayerNorm(128) + ReLU of the occupancy MLP (`occ_branches`, layers 1-2 and 4-5:
+ * dense_heads/voxelformer_occupancy_head.py:241-248, applied at :580 to 504 000 rows per
+ * viewpoint): y = relu((x - mean) * rstd * gamma + beta), eps as nn.LayerNorm (1e-5).
+ *   x, y, grad_y, grad_x  f32|bf16 [N, 128]   (dtype = VER_F32 | VER_BF16; statistics in fp32)
+ *   gamma, beta, grad_gamma, grad_beta f32 [128];  mean, rstd f32 [N] (written by forward)
+ * backward writes grad_x in full and the two parameter gradients (zeroed inside).
+ */
+int ver_ln_relu_forward(const void* x, const float* gamma, const float* beta, void* y,
+                        float* mean, float* rstd, long N, int W, float eps, int dtype, void* stream);
+int ver_ln_relu_backward(const void* x, const void* grad_y, const float* gamma, const float* beta,
+                         const float* mean, const float* rstd, void* grad_x,
+                         float* grad_gamma, float* grad_beta, long N, int W, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -321,3 +321,83 @@ def test_errors_are_loud():
         hip.sca_gather(bad, T(offsets).to(DEV), T(logits).to(DEV), hit, 14, 14)
     with pytest.raises(RuntimeError, match='GPU'):
         hip.sca_gather(T(value), T(offsets), T(logits), hit, 14, 14)
+
+
+# ------------------------------------------------------------------------------- a10: lattice im2col
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_lattice_im2col_and_adjoint(dtype):
+    """HIP im2col / col2im vs the torch slice-and-cat form (bit-exact: pure data movement;
+    col2im sums <= 27 bf16 terms in fp32)."""
+    hip = pkg('hipops')
+    up = pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    e = torch.randn(2, 4, 5, 7, 64, generator=gen).to(dtype)
+    taps = [(2 * a - 2, b - 1, c - 1) for a in range(3) for b in range(3) for c in range(2)]
+    want = up._im2col(e, taps)                      # CPU reference form
+    ed = e.to(DEV).requires_grad_(True)
+    got = hip.lattice_im2col(ed, taps)
+    assert got.dtype == dtype and torch.equal(got.cpu(), want)
+    g = torch.randn(want.shape, generator=gen).to(dtype)
+    got.backward(g.to(DEV))
+    ec = e.float().requires_grad_(True)
+    up._im2col(ec, taps).backward(g.float())
+    if dtype == torch.float32:
+        assert float((ed.grad.cpu() - ec.grad).abs().max()) <= 1e-5
+    else:                                        # result rounded to bf16 (8 mantissa bits)
+        assert close(ed.grad.float().cpu(), ec.grad, atol=1e-2, rtol=1e-2)
+    assert ed.grad.dtype == dtype
+
+
+def test_upsample_on_gpu_matches_conv_transpose():
+    up = pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(6)
+    x = torch.randn(2, 16, 4, 5, 6, generator=gen).to(DEV).requires_grad_(True)
+    ws = [(torch.randn(16, 16, 3, 5, 5, generator=gen) * 0.05).to(DEV).requires_grad_(True) for _ in range(3)]
+    bs = [torch.randn(16, generator=gen).to(DEV).requires_grad_(True) for _ in range(3)]
+    y = up.upsample_dense(x, ws, bs)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    wc = [w.detach().cpu().double().requires_grad_(True) for w in ws]
+    bc = [b.detach().cpu().double().requires_grad_(True) for b in bs]
+    r = xc
+    for w, b in zip(wc, bc):
+        r = torch.nn.functional.conv_transpose3d(r, w, b, **up.GEOM)
+    assert close(y.detach().cpu(), r.detach(), atol=1e-4, rtol=1e-4)
+    g = torch.randn(r.shape, generator=gen)
+    y.backward(g.to(DEV))
+    r.backward(g.double())
+    assert close(x.grad.cpu(), xc.grad, atol=1e-3, rtol=1e-3)
+    for a, b in zip(ws + bs, wc + bc):
+        assert close(a.grad.cpu(), b.grad, atol=1e-3, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------- a10: occupancy MLP
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_layer_norm_relu_fused(dtype):
+    """ver_ln_relu_* vs relu(F.layer_norm(x)) in fp64 (head:241-248)."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(8)
+    n = 50021                                       # not a multiple of the 16 rows per block
+    x = (torch.randn(n, 128, generator=gen) * 2 + 0.3).to(dtype)
+    gamma = torch.randn(128, generator=gen) * 0.5 + 1.0
+    beta = torch.randn(128, generator=gen) * 0.2
+    gy = torch.randn(n, 128, generator=gen).to(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    gd = gamma.to(DEV).requires_grad_(True)
+    bd = beta.to(DEV).requires_grad_(True)
+    y = hip.layer_norm_relu(xd, gd, bd, 1e-5)
+    assert y.dtype == dtype and y.shape == x.shape
+    y.backward(gy.to(DEV))
+    xr = x.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.layer_norm(xr, (128,), gr, br, 1e-5))
+    yr.backward(gy.double())
+    if dtype == torch.float32:
+        assert close(y.detach().cpu(), yr.detach(), atol=1e-5, rtol=1e-5)
+        assert close(xd.grad.cpu(), xr.grad, atol=1e-4, rtol=1e-4)
+    else:
+        assert close(y.detach().float().cpu(), yr.detach(), atol=2e-2, rtol=1e-2)
+        assert close(xd.grad.float().cpu(), xr.grad, atol=3e-2, rtol=2e-2)
+    assert close(gd.grad.cpu(), gr.grad, atol=2e-2 * (1 if dtype == torch.float32 else 20), rtol=2e-3)
+    assert close(bd.grad.cpu(), br.grad, atol=2e-2 * (1 if dtype == torch.float32 else 20), rtol=2e-3)
+    assert hip.layer_norm_relu(torch.zeros(0, 128, device=DEV), gd, bd).shape == (0, 128)

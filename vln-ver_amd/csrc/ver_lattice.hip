@@ -1,0 +1,154 @@
+// Lattice im2col / col2im for the even-lattice upsample (include/ver_ops.h, ver_lattice_*).
+//
+// The coarse-to-fine head (reference: three ConvTranspose3d, dense_heads/voxelformer_occupancy_head.py
+// :251-258,560) is evaluated as im2col + GEMM over a channels-last data lattice [B,Z,H,W,C]
+// (vln-ver_amd/dense_heads/upsample.py).  These two kernels are the data movement around the
+// GEMMs: pure HBM streaming, 16 bytes per lane, every (row, tap) a contiguous C-vector, bounds
+// handled in-kernel (no padded copy of the lattice).
+//   im2col : col[(b,z,y,x), t, :] = src[b, z+dz_t, y+dy_t, x+dx_t, :]   (0 outside the lattice)
+//   col2im : gsrc[b,z,y,x,:]      = sum_t gcol[(b, z-dz_t, y-dy_t, x-dx_t), t, :]   (gather form:
+//            the adjoint without atomics, deterministic)
+#include "ver_common.h"
+
+constexpr int kMaxTaps = 80;
+struct TapList {
+    int n;
+    signed char dz[kMaxTaps], dy[kMaxTaps], dx[kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void k_lattice_im2col(const uint4* __restrict__ src, uint4* __restrict__ col,
+                                                        TapList taps, int B, int Z, int H, int W, int CV) {
+    // one thread = one 16-byte vector of one (row, tap); vectors of a (row, tap) are consecutive
+    const long total = (long)B * Z * H * W * taps.n * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % CV);
+        long r = i / CV;
+        const int t = (int)(r % taps.n);
+        r /= taps.n;
+        const int x = (int)(r % W);
+        long q = r / W;
+        const int y = (int)(q % H);
+        q /= H;
+        const int z = (int)(q % Z);
+        const int b = (int)(q / Z);
+        const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
+        uint4 val = make_uint4(0u, 0u, 0u, 0u);
+        if (sz >= 0 && sz < Z && sy >= 0 && sy < H && sx >= 0 && sx < W)
+            val = src[((((long)b * Z + sz) * H + sy) * W + sx) * CV + v];
+        col[i] = val;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_lattice_col2im(const uint4* __restrict__ gcol, uint4* __restrict__ gsrc,
+                                                        TapList taps, int B, int Z, int H, int W, int CV) {
+    const long total = (long)B * Z * H * W * CV;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int v = (int)(i % CV);
+        long r = i / CV;
+        const int x = (int)(r % W);
+        long q = r / W;
+        const int y = (int)(q % H);
+        q /= H;
+        const int z = (int)(q % Z);
+        const int b = (int)(q / Z);
+        float acc[BF16 ? 8 : 4];
+#pragma unroll
+        for (int j = 0; j < (BF16 ? 8 : 4); ++j) acc[j] = 0.0f;
+        for (int t = 0; t < taps.n; ++t) {
+            const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
+            if (oz < 0 || oz >= Z || oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
+            const uint4 g = gcol[(((((long)b * Z + oz) * H + oy) * W + ox) * taps.n + t) * CV + v];
+            if (BF16) {
+                const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] += __uint_as_float(w[j] << 16);
+                    acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                }
+            } else {
+                acc[0] += __uint_as_float(g.x);
+                acc[1] += __uint_as_float(g.y);
+                acc[2] += __uint_as_float(g.z);
+                acc[3] += __uint_as_float(g.w);
+            }
+        }
+        uint4 o;
+        if (BF16) {
+            auto rne = [](float f) -> uint32_t {   // fp32 -> bf16, round to nearest even
+                uint32_t u = __float_as_uint(f);
+                if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+                return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+            };
+            o.x = rne(acc[0]) | (rne(acc[1]) << 16);
+            o.y = rne(acc[2]) | (rne(acc[3]) << 16);
+            o.z = rne(acc[4]) | (rne(acc[5]) << 16);
+            o.w = rne(acc[6]) | (rne(acc[7]) << 16);
+        } else {
+            o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                           __float_as_uint(acc[3]));
+        }
+        gsrc[i] = o;
+    }
+}
+
+namespace {
+int fill_taps(TapList& tl, const int* taps, int ntaps) {
+    VER_REQUIRE(taps && ntaps > 0 && ntaps <= kMaxTaps, VER_EINVAL, "ver_lattice: 1..%d taps required", kMaxTaps);
+    tl.n = ntaps;
+    for (int t = 0; t < ntaps; ++t) {
+        for (int a = 0; a < 3; ++a)
+            VER_REQUIRE(taps[3 * t + a] >= -127 && taps[3 * t + a] <= 127, VER_EINVAL, "ver_lattice: tap offset range");
+        tl.dz[t] = (signed char)taps[3 * t];
+        tl.dy[t] = (signed char)taps[3 * t + 1];
+        tl.dx[t] = (signed char)taps[3 * t + 2];
+    }
+    return VER_OK;
+}
+int check_lattice(const void* a, const void* b, int B, int Z, int H, int W, int C, int dtype) {
+    VER_REQUIRE(B >= 0 && Z > 0 && H > 0 && W > 0 && C > 0, VER_EINVAL, "ver_lattice: bad sizes");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_lattice: dtype %d", dtype);
+    VER_REQUIRE((C * (dtype == VER_BF16 ? 2 : 4)) % 16 == 0, VER_EUNSUPPORTED,
+                "ver_lattice: channel vector must be a multiple of 16 bytes");
+    if (B == 0) return VER_OK;
+    VER_REQUIRE(a && b, VER_EINVAL, "ver_lattice: null pointer argument");
+    VER_REQUIRE((((uintptr_t)a | (uintptr_t)b) & 15) == 0, VER_EINVAL, "ver_lattice: buffers must be 16-byte aligned");
+    return VER_OK;
+}
+}  // namespace
+
+extern "C" int ver_lattice_im2col(const void* src, void* col, const int* taps, int ntaps, int B, int Z, int H, int W,
+                                  int C, int dtype, void* stream) {
+    int rc = check_lattice(src, col, B, Z, H, W, C, dtype);
+    if (rc) return rc;
+    TapList tl;
+    rc = fill_taps(tl, taps, ntaps);
+    if (rc) return rc;
+    if (B == 0) return VER_OK;
+    const int CV = C * (dtype == VER_BF16 ? 2 : 4) / 16;
+    const long total = (long)B * Z * H * W * ntaps * CV;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 256L * 32 ? (total + 255) / 256 : 256L * 32);
+    hipLaunchKernelGGL(k_lattice_im2col, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+                       (uint4*)col, tl, B, Z, H, W, CV);
+    return ver_check_launch("ver_lattice_im2col");
+}
+
+extern "C" int ver_lattice_col2im(const void* gcol, void* gsrc, const int* taps, int ntaps, int B, int Z, int H, int W,
+                                  int C, int dtype, void* stream) {
+    int rc = check_lattice(gcol, gsrc, B, Z, H, W, C, dtype);
+    if (rc) return rc;
+    TapList tl;
+    rc = fill_taps(tl, taps, ntaps);
+    if (rc) return rc;
+    if (B == 0) return VER_OK;
+    const int CV = C * (dtype == VER_BF16 ? 2 : 4) / 16;
+    const long total = (long)B * Z * H * W * CV;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 256L * 32 ? (total + 255) / 256 : 256L * 32);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_lattice_col2im<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)gcol,
+                           (uint4*)gsrc, tl, B, Z, H, W, CV);
+    else
+        hipLaunchKernelGGL(k_lattice_col2im<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)gcol, (uint4*)gsrc, tl, B, Z, H, W, CV);
+    return ver_check_launch("ver_lattice_col2im");
+}

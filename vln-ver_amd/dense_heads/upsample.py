@@ -35,17 +35,37 @@ def is_reference_geometry(conv):
             tuple(conv.output_padding) == GEOM['output_padding'] and conv.groups == 1)
 
 
-def _corr_weight(weight):
-    """ConvTranspose weight [Ci,Co,3,5,5] -> correlation taps K[a,b,c] as [3,5,5,Ci,Co] with
-    K[a,b,c] = Wt[:, :, 2-a, 4-b, 4-c]."""
-    return weight.flip(2, 3, 4).permute(2, 3, 4, 0, 1)
+def _corr_weight(weight, dtype):
+    """ConvTranspose weight [Ci,Co,3,5,5] -> correlation taps as ONE contiguous [75, Ci, Co]
+    tensor in the compute dtype, tap index = (a*5+b)*5+c, K[a,b,c] = Wt[:, :, 2-a, 4-b, 4-c]
+    (one cast + one gather kernel; the per-class tap subsets below are index_select's of it)."""
+    ci, co = weight.shape[:2]
+    return weight.to(dtype).flip(2, 3, 4).permute(2, 3, 4, 0, 1).reshape(75, ci, co)
 
 
-def _im2col(e_pad, taps, zhw):
-    """e_pad [B,Z+4,H+2,W+2,C] (zero padded: 2 in z, 1 in y/x); taps: list of (dz,dy,dx) offsets
-    into the padded lattice -> [B*Z*H*W, len(taps)*C]."""
-    z, h, w = zhw
-    cols = [e_pad[:, dz:dz + z, dy:dy + h, dx:dx + w, :] for dz, dy, dx in taps]
+_IDX_CACHE = {}
+
+
+def _tap_index(tap_ids, device):
+    key = (tuple(tap_ids), str(device))
+    if key not in _IDX_CACHE:
+        _IDX_CACHE[key] = torch.tensor(tap_ids, dtype=torch.long, device=device)
+    return _IDX_CACHE[key]
+
+
+def _im2col(e, taps):
+    """e [B,Z,H,W,C] channels-last; taps: list of (dz,dy,dx) offsets (zero outside the lattice)
+    -> [B*Z*H*W, len(taps)*C].  On the GPU one HIP kernel each way (ver_lattice_im2col /
+    ver_lattice_col2im); the slice-and-cat form below only serves CPU tensors in the algebra tests."""
+    if e.is_cuda:
+        from ..hipops import lattice_im2col
+        return lattice_im2col(e.contiguous(), taps)
+    b, z, h, w, c = e.shape
+    pz = max(abs(t[0]) for t in taps)
+    py = max(abs(t[1]) for t in taps)
+    px = max(abs(t[2]) for t in taps)
+    e_pad = F.pad(e, (0, 0, px, px, py, py, pz, pz))
+    cols = [e_pad[:, pz + dz:pz + dz + z, py + dy:py + dy + h, px + dx:px + dx + w, :] for dz, dy, dx in taps]
     a = torch.cat(cols, dim=-1)
     return a.reshape(-1, a.shape[-1])
 
@@ -78,12 +98,10 @@ def _constant_pattern(z, h_in, w_in, device, dtype):
 def _layer0(e, k, bias):
     """All 75 taps hit data.  e [B,Z,H,W,C] channels-last -> E_1 [B,Z,H,W,Co]."""
     b, z, h, w, c = e.shape
-    e_pad = F.pad(e, (0, 0, 2, 2, 2, 2, 2, 2))
-    taps = [(2 * a, bb, cc) for a in range(3) for bb in range(5) for cc in range(5)]
-    cols = [e_pad[:, dz:dz + z, dy:dy + h, dx:dx + w, :] for dz, dy, dx in taps]
-    a_mat = torch.cat(cols, dim=-1).reshape(-1, 75 * c)
-    out = a_mat @ k.reshape(75 * c, -1)
-    return (out + bias).view(b, z, h, w, -1)
+    taps = [(2 * a - 2, bb - 2, cc - 2) for a in range(3) for bb in range(5) for cc in range(5)]
+    a_mat = _im2col(e, taps)
+    out = torch.addmm(bias, a_mat, k.reshape(75 * c, -1))
+    return out.view(b, z, h, w, -1)
 
 
 def _layer_lattice(e, k, bias, prev_bias):
@@ -91,21 +109,23 @@ def _layer_lattice(e, k, bias, prev_bias):
     off the lattice -> output lattice [B,Z,2H,2W,Co]."""
     b, z, h, w, c = e.shape
     co = k.shape[-1]
-    e_pad = F.pad(e, (0, 0, 1, 1, 1, 1, 2, 2))
-    # constant taps: pattern [Z*2H*2W, 75] @ (K[tap]^T prev_bias) [75, Co]
-    v = torch.einsum('abcio,i->abco', k, prev_bias).reshape(75, co)
-    const = (_constant_pattern(z, 2 * h, 2 * w, e.device, e.dtype) @ v).view(z, 2 * h, 2 * w, co)
+    # constant taps: pattern [Z*2H*2W, 75] @ (K[tap]^T prev_bias) [75, Co], bias folded in
+    v = torch.matmul(prev_bias, k)                                       # [75, Co]
+    const = torch.addmm(bias, _constant_pattern(z, 2 * h, 2 * w, e.device, e.dtype), v)
+    const = const.view(z, 2 * h, 2 * w, co)
     out = e.new_empty(b, z, 2 * h, 2 * w, co)
     for pm in (0, 1):
         bs_ = [bb for bb in range(5) if (pm + bb) % 2 == 0]
         for pn in (0, 1):
             cs_ = [cc for cc in range(5) if (pn + cc) % 2 == 0]
-            # lattice row of tap b for output row m = 2m'+pm:  m' - 1 + (pm+b)/2  (+1 for the pad)
-            taps = [(2 * a, (pm + bb) // 2, (pn + cc) // 2) for a in range(3) for bb in bs_ for cc in cs_]
-            ksub = torch.stack([k[a, bb, cc] for a in range(3) for bb in bs_ for cc in cs_])
-            a_mat = _im2col(e_pad, taps, (z, h, w))
+            # lattice row of tap b for output row m = 2m'+pm:  m' - 1 + (pm+b)/2
+            taps = [(2 * a - 2, (pm + bb) // 2 - 1, (pn + cc) // 2 - 1)
+                    for a in range(3) for bb in bs_ for cc in cs_]
+            ids = [(a * 5 + bb) * 5 + cc for a in range(3) for bb in bs_ for cc in cs_]
+            ksub = k.index_select(0, _tap_index(ids, k.device))
+            a_mat = _im2col(e, taps)
             res = (a_mat @ ksub.reshape(-1, co)).view(b, z, h, w, co)
-            out[:, :, pm::2, pn::2, :] = res + const[None, :, pm::2, pn::2, :] + bias
+            out[:, :, pm::2, pn::2, :] = res + const[None, :, pm::2, pn::2, :]
     return out
 
 
@@ -122,7 +142,7 @@ def upsample_lattice(x0, weights, biases):
     positions of the reference's dense output ``up_sample(x0)`` [B,C,Z,8H,8W]."""
     dt = _compute_dtype(x0)
     e = x0.permute(0, 2, 3, 4, 1).to(dt)
-    ks = [_corr_weight(w).to(dt) for w in weights]
+    ks = [_corr_weight(w, dt) for w in weights]
     bs = [b.to(dt) for b in biases]
     e = _layer0(e, ks[0], bs[0])
     e = _layer_lattice(e, ks[1], bs[1], bs[0])

@@ -198,7 +198,24 @@ class VoxelFormerOccupancyHead(BaseModule):
             occ = self.occ_proj(x)
             occ = occ.view(bs, ox, oy, self.occ_zdim, self.occ_dims).permute(0, 3, 1, 2, 4)
         occ = occ.reshape(bs, -1, self.occ_dims)
-        return self.occ_branches(occ)
+        return self._occ_mlp(occ)
+
+    def _occ_mlp(self, x):
+        """``occ_branches`` (head:241-248).  On the GPU each LayerNorm(128)+ReLU pair is one fused
+        HIP pass (``ver_ln_relu_*``); Linear layers stay hipBLASLt GEMMs."""
+        mods = list(self.occ_branches)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.LayerNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    and x.is_cuda and tuple(m.normalized_shape) == (128,) and m.elementwise_affine):
+                from ..hipops import layer_norm_relu
+                x = layer_norm_relu(x, m.weight, m.bias, m.eps)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
     # ------------------------------------------------------------------ forward
     def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, **kwargs):
@@ -262,7 +279,7 @@ class VoxelFormerOccupancyHead(BaseModule):
             occ = self.occ_proj(x)
             occ = occ.view(bs, self.bev_h, self.bev_w, self.occ_zdim, self.occ_dims)
             occ = occ.permute(0, 3, 1, 2, 4)
-        return self.occ_branches(occ.reshape(bs, -1, self.occ_dims))
+        return self._occ_mlp(occ.reshape(bs, -1, self.occ_dims))
 
     def occupancy_loss(self, occupancy_preds, gt_occupancy):
         """Occupancy term of ``loss_single`` (head:977-989): sigmoid focal loss over

@@ -13,9 +13,10 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 4
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
-           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward')
+           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
+           'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward')
 
 _lib = None
 
@@ -246,3 +247,84 @@ class SCAGatherFunction(Function):
 
 def sca_gather(value, offsets, logits, hit, map_h, map_w):
     return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w)
+
+
+# ------------------------------------------------------------------------------------------
+class LatticeIm2colFunction(Function):
+    """col = im2col(lattice) for the even-lattice upsample (ver_lattice_im2col / _col2im).
+    lattice [B,Z,H,W,C] channels-last, fp32 or bf16 -> [B*Z*H*W, ntaps*C]."""
+
+    @staticmethod
+    def forward(ctx, lattice, taps):
+        lattice = _gpu(lattice, 'lattice')
+        if lattice.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('lattice must be fp32 or bf16')
+        B, Z, H, W, C = lattice.shape
+        flat = [int(v) for t in taps for v in t]
+        arr = (ctypes.c_int * len(flat))(*flat)
+        dt = 1 if lattice.dtype == torch.bfloat16 else 0
+        col = torch.empty(B * Z * H * W, len(taps) * C, dtype=lattice.dtype, device=lattice.device)
+        _launch('ver_lattice_im2col', lambda: lib().ver_lattice_im2col(
+            _p(lattice), _p(col), arr, len(taps), B, Z, H, W, C, dt, _stream()))
+        ctx.geom = (B, Z, H, W, C, dt, arr, len(taps))
+        return col
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_col):
+        B, Z, H, W, C, dt, arr, ntaps = ctx.geom
+        want = torch.bfloat16 if dt else torch.float32
+        g = _gpu(grad_col, 'grad_col').to(want).contiguous()
+        grad = torch.empty(B, Z, H, W, C, dtype=want, device=g.device)
+        _launch('ver_lattice_col2im', lambda: lib().ver_lattice_col2im(
+            _p(g), _p(grad), arr, ntaps, B, Z, H, W, C, dt, _stream()))
+        return grad, None
+
+
+def lattice_im2col(lattice, taps):
+    return LatticeIm2colFunction.apply(lattice, taps)
+
+
+# ------------------------------------------------------------------------------------------
+class LayerNormReluFunction(Function):
+    """relu(layer_norm(x)) over rows of 128 channels (ver_ln_relu_forward / _backward);
+    x fp32 or bf16 [..., 128], output in x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _gpu(x, 'x')
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('x must be fp32 or bf16')
+        w = x.shape[-1]
+        n = x.numel() // w
+        gamma = _gpu(gamma, 'gamma').float().contiguous()
+        beta = _gpu(beta, 'beta').float().contiguous()
+        dt = 1 if x.dtype == torch.bfloat16 else 0
+        y = torch.empty_like(x)
+        mean = torch.empty(n, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(n, dtype=torch.float32, device=x.device)
+        _launch('ver_ln_relu_forward', lambda: lib().ver_ln_relu_forward(
+            _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), ctypes.c_long(n), w,
+            ctypes.c_float(eps), dt, _stream()))
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.dt = dt
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        w = x.shape[-1]
+        n = x.numel() // w
+        gy = _gpu(grad_y, 'grad_y').to(x.dtype).contiguous()
+        gx = torch.empty_like(x)
+        gg = torch.empty(w, dtype=torch.float32, device=x.device)
+        gb = torch.empty(w, dtype=torch.float32, device=x.device)
+        _launch('ver_ln_relu_backward', lambda: lib().ver_ln_relu_backward(
+            _p(x), _p(gy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(gx), _p(gg), _p(gb),
+            ctypes.c_long(n), w, ctx.dt, _stream()))
+        return gx, gg, gb, None
+
+
+def layer_norm_relu(x, gamma, beta, eps=1e-5):
+    return LayerNormReluFunction.apply(x, gamma, beta, eps)

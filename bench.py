@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--backend', default='nccl', help='nccl (= RCCL); gloo only to exercise the N>1 path on one GPU')
     return ap.parse_args()
 
 
@@ -103,6 +104,26 @@ def gather_algorithmic_bytes(hit_counts, B, ncam=6, nk=196, c=768, heads=8, poin
     return fwd, bwd
 
 
+def measured_traffic_per_viewpoint(kernel):
+    """HBM bytes per viewpoint and launch from the committed rocprofv3 PMC passes
+    (profiles/*_gather_microbench_pmc_fetch_write.csv: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
+    separate runs of scratch/bench_gather.py at 64 viewpoints per launch).  Units are KiB;
+    FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md
+    section HBM), so this is an upper bound on the read side."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_pmc_fetch_write.csv')))
+    if not files:
+        return None, None
+    vals = {}
+    for row in csv.reader(l for l in open(files[-1]) if not l.startswith('#')):
+        if len(row) == 4 and kernel in row[0] and row[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            vals[row[1]] = float(row[2])
+    if len(vals) != 2:
+        return None, None
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0 / 64.0, os.path.basename(files[-1])
+
+
 def cpu_baseline(head, syn, seconds):
     """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this
     host's cores: vocc.py lifting path fwd+bwd for ONE viewpoint at a time."""
@@ -135,11 +156,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback of the product path)'
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     hip = importlib.import_module('vln-ver_amd.hipops')
     hip.lib()
     pkg, syn, head, n_train = build_model(args, dev)
@@ -149,7 +174,8 @@ def main():
     model.train(train)
     ddp = model                                 # train(): dropout ON, as in the reference's step
     if world > 1 and train:
-        ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev)
+        ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev,
+                                                                  bf16_gradients=args.backend == 'nccl')
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True) if train else None
 
@@ -205,8 +231,10 @@ def main():
             if name in kt and kt[name]['count']:
                 avg_ms = kt[name]['ms'] / kt[name]['count']
                 ach = byts / (avg_ms * 1e-3) / 1e9
+                tpv, src = measured_traffic_per_viewpoint('k_sca_fwd' if name == 'ver_sca_forward' else 'k_sca_bwd')
                 obj = dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                           frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(avg_ms * 1e3, 2),
+                           frac=round(ach / HBM_PEAK_GBS, 4), traffic=int(tpv * B) if tpv else None,
+                           traffic_source=src, avg_launch_us=round(avg_ms * 1e3, 2),
                            launches=kt[name]['count'], algorithmic_bytes_per_launch=int(byts),
                            viewpoints_per_launch=B, sigma_n=sigma_n)
                 if name == 'ver_sca_forward':

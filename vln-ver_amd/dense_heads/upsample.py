@@ -110,8 +110,10 @@ def _layer_lattice(e, k, bias, prev_bias):
     b, z, h, w, c = e.shape
     co = k.shape[-1]
     # constant taps: pattern [Z*2H*2W, 75] @ (K[tap]^T prev_bias) [75, Co], bias folded in
+    # (a [75]-batch of 1-row GEMMs; a single fp32 gemv over the raw weight measured slower end to end
+    # because its backward materialises a dense fp32 outer product per layer)
     v = torch.matmul(prev_bias, k)                                       # [75, Co]
-    const = torch.addmm(bias, _constant_pattern(z, 2 * h, 2 * w, e.device, e.dtype), v)
+    const = torch.addmm(bias, _constant_pattern(z, 2 * h, 2 * w, e.device, e.dtype), v)   # [.., Co]
     const = const.view(z, 2 * h, 2 * w, co)
     out = e.new_empty(b, z, 2 * h, 2 * w, co)
     for pm in (0, 1):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 4
+#define VER_ABI_VERSION 5
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -75,6 +75,24 @@ int ver_msda_backward(const float* value, const int64_t* shapes_hw, const int64_
                       float* grad_value, float* grad_loc, float* grad_attn_w,
                       int B, int num_keys, int heads, int head_dim, int levels, int points,
                       int Nq, int im2col_step, void* stream);
+
+/* 3-D (trilinear) twin used by the detection decoder: the reference's in-tree
+ *   voxel_multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_locations,
+ *   attention_weights) (bevformer/modules/voxel_temporal_self_attention.py:275-335), called from
+ *   VoxelCustomMSDeformableAttention.forward (bevformer/modules/voxel_decoder.py:312-313).
+ *   shapes_dhw i64 [levels,3] = (D,H,W); loc f32 [B,Nq,heads,levels,points,3] = (x,y,z) in [0,1];
+ *   flat key index = (z*H + y)*W + x; 5-D grid_sample semantics (pixel = loc*size - 0.5, zeros).
+ *   Gradient buffers of the backward are caller-allocated and ZERO-INITIALISED.
+ */
+int ver_msda3d_forward(const float* value, const int64_t* shapes_dhw, const int64_t* level_start,
+                       const float* loc, const float* attn_w, float* out,
+                       int B, int num_keys, int heads, int head_dim, int levels, int points,
+                       int Nq, void* stream);
+int ver_msda3d_backward(const float* value, const int64_t* shapes_dhw, const int64_t* level_start,
+                        const float* loc, const float* attn_w, const float* grad_out,
+                        float* grad_value, float* grad_loc, float* grad_attn_w,
+                        int B, int num_keys, int heads, int head_dim, int levels, int points,
+                        int Nq, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Hit table: the per-viewpoint visibility structure shared by the three encoder layers.

@@ -131,3 +131,28 @@ def vocc_head_cfg(bev=(4, 15, 15), refine_occ=True, only_occ=False):
         loss_iou=dict(type='GIoULoss', loss_weight=0.0),
         loss_occupancy=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25,
                             loss_weight=1.0))
+
+
+def msda3d_inputs(seed, batch, shapes, heads, head_dim, num_query, points, lo=-0.2, hi=1.2):
+    """Random operands of the 3-D (trilinear) deformable sampling op of the detection decoder
+    (voxel_temporal_self_attention.py:275-335): shapes [[D,H,W],...], loc (x,y,z)."""
+    rng = np.random.default_rng(seed)
+    shapes = np.asarray(shapes, dtype=np.int64).reshape(-1, 3)
+    nlev = shapes.shape[0]
+    sizes = shapes[:, 0] * shapes[:, 1] * shapes[:, 2]
+    value = rng.standard_normal((batch, int(sizes.sum()), heads, head_dim)).astype(np.float32)
+    loc = rng.uniform(lo, hi, (batch, num_query, heads, nlev, points, 3)).astype(np.float32)
+    logits = rng.standard_normal((batch, num_query, heads, nlev * points))
+    logits -= logits.max(-1, keepdims=True)
+    w = np.exp(logits)
+    w /= w.sum(-1, keepdims=True)
+    w = w.reshape(batch, num_query, heads, nlev, points).astype(np.float32)
+    grad_out = rng.standard_normal((batch, num_query, heads * head_dim)).astype(np.float32)
+    lsi = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    return dict(value=value, shapes=shapes, level_start=lsi, loc=loc, w=w, grad_out=grad_out)
+
+
+MSDA3D_CASES = {
+    'vocc_decoder': dict(seed=21, batch=1, shapes=[[4, 15, 15]], heads=8, head_dim=96, num_query=100, points=4),
+    'two_levels': dict(seed=22, batch=1, shapes=[[2, 3, 5], [1, 2, 2]], heads=2, head_dim=5, num_query=23, points=3),
+}

@@ -262,7 +262,21 @@ def gen_encoder_vocc(ref):
     save('encoder_vocc', **arrays)
 
 
-GENERATORS = {'msda_core': gen_msda_core, 'point_sampling': gen_point_sampling,
+def gen_msda3d_core(ref):
+    """next-row 1: the reference's own in-tree 3-D op, forward + autograd backward."""
+    fn = ref['voxel_temporal_self_attention'].voxel_multi_scale_deformable_attn_pytorch
+    for name, kw in cases.MSDA3D_CASES.items():
+        c = cases.msda3d_inputs(**kw)
+        value = T(c['value']).requires_grad_(True)
+        loc = T(c['loc']).requires_grad_(True)
+        w = T(c['w']).requires_grad_(True)
+        out = fn(value, T(c['shapes']), loc, w)
+        out.backward(T(c['grad_out']))
+        save('msda3d_core_' + name, out=out.detach().numpy(), grad_value=value.grad[:, ::3].numpy(),
+             grad_loc=loc.grad.numpy(), grad_w=w.grad.numpy())
+
+
+GENERATORS = {'msda_core': gen_msda_core, 'msda3d_core': gen_msda3d_core, 'point_sampling': gen_point_sampling,
               'small_modules': gen_small_modules, 'encoder_vocc': gen_encoder_vocc}
 
 

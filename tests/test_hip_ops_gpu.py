@@ -401,3 +401,31 @@ def test_layer_norm_relu_fused(dtype):
     assert close(gd.grad.cpu(), gr.grad, atol=2e-2 * (1 if dtype == torch.float32 else 20), rtol=2e-3)
     assert close(bd.grad.cpu(), br.grad, atol=2e-2 * (1 if dtype == torch.float32 else 20), rtol=2e-3)
     assert hip.layer_norm_relu(torch.zeros(0, 128, device=DEV), gd, bd).shape == (0, 128)
+
+
+# ------------------------------------------------------------------------------- next row 1: decoder op
+@pytest.mark.parametrize('name', list(cases.MSDA3D_CASES))
+def test_voxel_msda_forward_backward(name):
+    """3-D (trilinear) sampling op of the detection decoder: HIP vs the reference's in-tree
+    function (golden) and vs the oracle."""
+    hip = pkg('hipops')
+    o = oracle()
+    g = golden('msda3d_core_' + name)
+    c = cases.msda3d_inputs(**cases.MSDA3D_CASES[name])
+    value = T(c['value']).to(DEV).requires_grad_(True)
+    loc = T(c['loc']).to(DEV).requires_grad_(True)
+    w = T(c['w']).to(DEV).requires_grad_(True)
+    out = hip.voxel_msda(value, T(c['shapes']).to(DEV), T(c['level_start']).to(DEV), loc, w)
+    out.backward(T(c['grad_out']).to(DEV))
+    assert maxdiff(out.detach().cpu(), g['out']) < 2e-5
+    assert close(value.grad.cpu()[:, ::3], g['grad_value'])
+    assert close(loc.grad.cpu(), g['grad_loc'])
+    assert close(w.grad.cpu(), g['grad_w'])
+    vc, lc, wc = T(c['value']).requires_grad_(True), T(c['loc']).requires_grad_(True), T(c['w']).requires_grad_(True)
+    ref = o.voxel_msda_core(vc, c['shapes'].tolist(), lc, wc)
+    ref.backward(T(c['grad_out']))
+    assert maxdiff(out.detach().cpu(), ref.detach()) < 2e-5
+    assert close(value.grad.cpu(), vc.grad)
+    far = torch.full_like(loc, 3.0)
+    assert float(hip.voxel_msda(value.detach(), T(c['shapes']).to(DEV), T(c['level_start']).to(DEV), far,
+                                w.detach()).abs().max()) == 0.0

@@ -177,3 +177,21 @@ def test_msda3d_init_pattern():
     bias = o.msda3d_init(8, 1, 8).view(8, 1, 8, 2)
     assert maxdiff(bias[0, 0, :, 0], torch.arange(1, 9).float()) < 1e-6   # head 0 -> +x ring
     assert float(bias.abs().max()) == pytest.approx(8.0, abs=1e-5)
+
+
+@pytest.mark.parametrize('name', list(cases.MSDA3D_CASES))
+def test_voxel_msda_core_forward_backward(name):
+    """next-row 1: 3-D (trilinear) sampling op of the detection decoder vs the reference's own
+    in-tree function (voxel_temporal_self_attention.py:275-335)."""
+    o = oracle()
+    g = golden('msda3d_core_' + name)
+    c = cases.msda3d_inputs(**cases.MSDA3D_CASES[name])
+    value = T(c['value']).requires_grad_(True)
+    loc = T(c['loc']).requires_grad_(True)
+    w = T(c['w']).requires_grad_(True)
+    out = o.voxel_msda_core(value, c['shapes'].tolist(), loc, w)
+    out.backward(T(c['grad_out']))
+    assert maxdiff(out.detach(), g['out']) < 2e-5
+    assert close(value.grad[:, ::3], g['grad_value'])
+    assert close(loc.grad, g['grad_loc'])
+    assert close(w.grad, g['grad_w'])

@@ -71,6 +71,50 @@ __device__ __forceinline__ void bilinear_setup(float loc_x, float loc_y, int H, 
     }
 }
 
+// Trilinear footprint of one sample on a D x H x W volume (5-D grid_sample semantics of the
+// detection decoder's op, voxel_temporal_self_attention.py:301-323: pixel = loc*size - 0.5,
+// zero padding).  Corner k = dz*4 + dy*2 + dx.
+struct Trilinear {
+    float w[8];
+    int key[8];
+    float gx[8], gy[8], gz[8];
+    bool any;
+};
+
+template <bool GRAD>
+__device__ __forceinline__ void trilinear_setup(float loc_x, float loc_y, float loc_z, int D, int H, int W,
+                                                Trilinear& s) {
+    const float x = loc_x * (float)W - 0.5f, y = loc_y * (float)H - 0.5f, z = loc_z * (float)D - 0.5f;
+    s.any = (x > -1.0f) && (y > -1.0f) && (z > -1.0f) && (x < (float)W) && (y < (float)H) && (z < (float)D);
+    if (!s.any) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s.w[k] = 0.0f;
+            s.key[k] = 0;
+            if (GRAD) s.gx[k] = s.gy[k] = s.gz[k] = 0.0f;
+        }
+        return;
+    }
+    const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
+    const int x0 = (int)xf, y0 = (int)yf, z0 = (int)zf;
+    const float lx = x - xf, ly = y - yf, lz = z - zf;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+        const bool ok = xi >= 0 && xi <= W - 1 && yi >= 0 && yi <= H - 1 && zi >= 0 && zi <= D - 1;
+        const float wx = dx ? lx : 1.0f - lx, wy = dy ? ly : 1.0f - ly, wz = dz ? lz : 1.0f - lz;
+        s.w[k] = ok ? wx * wy * wz : 0.0f;
+        const int cx = min(max(xi, 0), W - 1), cy = min(max(yi, 0), H - 1), cz = min(max(zi, 0), D - 1);
+        s.key[k] = (cz * H + cy) * W + cx;
+        if (GRAD) {
+            s.gx[k] = ok ? (dx ? wy * wz : -wy * wz) : 0.0f;
+            s.gy[k] = ok ? (dy ? wx * wz : -wx * wz) : 0.0f;
+            s.gz[k] = ok ? (dz ? wx * wy : -wx * wy) : 0.0f;
+        }
+    }
+}
+
 // Cross-lane butterflies inside aligned groups of G lanes.  For G <= 16 everything stays in
 // the VALU through DPP (a row = 16 lanes): xor-1 and xor-2 are quad permutes, then
 // row_half_mirror joins the two quads of each 8, row_mirror the two halves of the row -- after

@@ -122,6 +122,128 @@ __global__ __launch_bounds__(256) void k_msda_bwd(const float* __restrict__ valu
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 3-D (trilinear) variant for the detection decoder: the reference's in-tree
+// voxel_multi_scale_deformable_attn_pytorch (voxel_temporal_self_attention.py:275-335) called
+// from VoxelCustomMSDeformableAttention.forward (voxel_decoder.py:312-313).  shapes [L,3] =
+// (D,H,W), loc [...,3] = (x,y,z).  Same lane organisation as the 2-D kernels above.
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_msda3d_fwd(const float* __restrict__ value,
+                                                    const int64_t* __restrict__ shapes,
+                                                    const int64_t* __restrict__ lstart,
+                                                    const float* __restrict__ loc,
+                                                    const float* __restrict__ aw, float* __restrict__ out,
+                                                    int B, int Nk, int heads, int hd, int L, int P, int Nq) {
+    const int gpb = 256 / G;
+    const long gid = (long)blockIdx.x * gpb + threadIdx.x / G;
+    const int lane = threadIdx.x % G;
+    if (gid >= (long)B * Nq * heads) return;
+    const int h = (int)(gid % heads);
+    const int b = (int)(gid / heads / Nq);
+    const float* lp = loc + gid * L * P * 3;
+    const float* wp = aw + gid * L * P;
+    const long vstride = (long)heads * hd;
+    const float* vb = value + (long)b * Nk * vstride + (long)h * hd;
+    float acc[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = 0.0f;
+    for (int l = 0; l < L; ++l) {
+        const int D = (int)shapes[3 * l], H = (int)shapes[3 * l + 1], W = (int)shapes[3 * l + 2];
+        const float* vl = vb + (long)lstart[l] * vstride;
+        for (int p = 0; p < P; ++p) {
+            Trilinear s;
+            const float* q = lp + (l * P + p) * 3;
+            trilinear_setup<false>(q[0], q[1], q[2], D, H, W, s);
+            if (!s.any) continue;
+            const float a = wp[l * P + p];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+                const int ch = lane + i * G;
+                if (ch < hd) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v += s.w[k] * vl[(long)s.key[k] * vstride + ch];
+                    acc[i] += a * v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int ch = lane + i * G;
+        if (ch < hd) out[gid * hd + ch] = acc[i];
+    }
+}
+
+template <int G, int NC>
+__global__ __launch_bounds__(256) void k_msda3d_bwd(const float* __restrict__ value,
+                                                    const int64_t* __restrict__ shapes,
+                                                    const int64_t* __restrict__ lstart,
+                                                    const float* __restrict__ loc,
+                                                    const float* __restrict__ aw,
+                                                    const float* __restrict__ gout, float* gvalue,
+                                                    float* __restrict__ gloc, float* __restrict__ gaw, int B,
+                                                    int Nk, int heads, int hd, int L, int P, int Nq) {
+    const int gpb = 256 / G;
+    const long gid = (long)blockIdx.x * gpb + threadIdx.x / G;
+    const int lane = threadIdx.x % G;
+    if (gid >= (long)B * Nq * heads) return;
+    const int h = (int)(gid % heads);
+    const int b = (int)(gid / heads / Nq);
+    const float* lp = loc + gid * L * P * 3;
+    const float* wp = aw + gid * L * P;
+    const long vstride = (long)heads * hd;
+    const long voff = (long)b * Nk * vstride + (long)h * hd;
+    float g[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int ch = lane + i * G;
+        g[i] = ch < hd ? gout[gid * hd + ch] : 0.0f;
+    }
+    for (int l = 0; l < L; ++l) {
+        const int D = (int)shapes[3 * l], H = (int)shapes[3 * l + 1], W = (int)shapes[3 * l + 2];
+        const long lbase = voff + (long)lstart[l] * vstride;
+        for (int p = 0; p < P; ++p) {
+            Trilinear s;
+            const float* q = lp + (l * P + p) * 3;
+            trilinear_setup<true>(q[0], q[1], q[2], D, H, W, s);
+            const float a = wp[l * P + p];
+            float sa = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+            if (s.any) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (s.w[k] == 0.0f && s.gx[k] == 0.0f && s.gy[k] == 0.0f && s.gz[k] == 0.0f) continue;
+                    float d = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        const int ch = lane + i * G;
+                        if (ch < hd) {
+                            const long idx = lbase + (long)s.key[k] * vstride + ch;
+                            d += g[i] * value[idx];
+                            atomicAdd(gvalue + idx, s.w[k] * a * g[i]);
+                        }
+                    }
+                    sa += s.w[k] * d;
+                    sx += s.gx[k] * d;
+                    sy += s.gy[k] * d;
+                    sz += s.gz[k] * d;
+                }
+            }
+            sa = group_sum<G>(sa);
+            sx = group_sum<G>(sx);
+            sy = group_sum<G>(sy);
+            sz = group_sum<G>(sz);
+            if (lane == 0) {
+                const long o = gid * L * P + l * P + p;
+                gaw[o] = sa;
+                gloc[o * 3] = (float)W * a * sx;
+                gloc[o * 3 + 1] = (float)H * a * sy;
+                gloc[o * 3 + 2] = (float)D * a * sz;
+            }
+        }
+    }
+}
+
 namespace {
 
 template <typename F>
@@ -193,5 +315,46 @@ extern "C" int ver_msda_backward(const float* value, const int64_t* shapes_hw, c
                            loc, attn_w, grad_out, grad_value, grad_loc, grad_attn_w, B, num_keys, heads,
                            head_dim, levels, points, Nq);
         return ver_check_launch("ver_msda_backward");
+    });
+}
+
+extern "C" int ver_msda3d_forward(const float* value, const int64_t* shapes_dhw, const int64_t* level_start,
+                                  const float* loc, const float* attn_w, float* out, int B, int num_keys,
+                                  int heads, int head_dim, int levels, int points, int Nq, void* stream) {
+    int rc = check_common(value, shapes_dhw, level_start, loc, attn_w, B, num_keys, heads, head_dim, levels, points,
+                          Nq);
+    if (rc) return rc;
+    const long total = (long)B * Nq * heads;
+    if (total == 0) return VER_OK;
+    VER_REQUIRE(out, VER_EINVAL, "ver_msda3d_forward: out is null");
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_group(head_dim, [&](auto g, auto nc) {
+        constexpr int G = decltype(g)::value, NC = decltype(nc)::value;
+        const int gpb = 256 / G;
+        hipLaunchKernelGGL((k_msda3d_fwd<G, NC>), dim3((unsigned)((total + gpb - 1) / gpb)), dim3(256), 0, st, value,
+                           shapes_dhw, level_start, loc, attn_w, out, B, num_keys, heads, head_dim, levels, points, Nq);
+        return ver_check_launch("ver_msda3d_forward");
+    });
+}
+
+extern "C" int ver_msda3d_backward(const float* value, const int64_t* shapes_dhw, const int64_t* level_start,
+                                   const float* loc, const float* attn_w, const float* grad_out, float* grad_value,
+                                   float* grad_loc, float* grad_attn_w, int B, int num_keys, int heads, int head_dim,
+                                   int levels, int points, int Nq, void* stream) {
+    int rc = check_common(value, shapes_dhw, level_start, loc, attn_w, B, num_keys, heads, head_dim, levels, points,
+                          Nq);
+    if (rc) return rc;
+    const long total = (long)B * Nq * heads;
+    if (total == 0) return VER_OK;
+    VER_REQUIRE(grad_out && grad_value && grad_loc && grad_attn_w, VER_EINVAL,
+                "ver_msda3d_backward: null gradient pointer");
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch_group(head_dim, [&](auto g, auto nc) {
+        constexpr int G = decltype(g)::value, NC = decltype(nc)::value;
+        const int gpb = 256 / G;
+        hipLaunchKernelGGL((k_msda3d_bwd<G, NC>), dim3((unsigned)((total + gpb - 1) / gpb)), dim3(256), 0, st, value,
+                           shapes_dhw, level_start, loc, attn_w, grad_out, grad_value, grad_loc, grad_attn_w, B,
+                           num_keys, heads, head_dim, levels, points, Nq);
+        return ver_check_launch("ver_msda3d_backward");
     });
 }

@@ -13,10 +13,11 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
-           'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward')
+           'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
+           'ver_msda3d_forward', 'ver_msda3d_backward')
 
 _lib = None
 
@@ -328,3 +329,42 @@ class LayerNormReluFunction(Function):
 
 def layer_norm_relu(x, gamma, beta, eps=1e-5):
     return LayerNormReluFunction.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------
+class VoxelMSDeformAttnFunction(Function):
+    """3-D (trilinear) deformable sampling of the detection decoder
+    (voxel_temporal_self_attention.py:275-335) on ver_msda3d_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+        value = _gpu(value, 'value').float().contiguous()
+        loc = _gpu(sampling_locations, 'sampling_locations').float().contiguous()
+        aw = _gpu(attention_weights, 'attention_weights').float().contiguous()
+        shapes = _gpu(spatial_shapes, 'spatial_shapes').to(torch.int64).contiguous()
+        lsi = _gpu(level_start_index, 'level_start_index').to(torch.int64).contiguous()
+        bs, nk, heads, hd = value.shape
+        _, nq, _, nl, npt, _ = loc.shape
+        out = value.new_empty(bs, nq, heads * hd)
+        _launch('ver_msda3d_forward', lambda: lib().ver_msda3d_forward(
+            _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw), _p(out), bs, nk, heads, hd, nl, npt, nq, _stream()))
+        ctx.save_for_backward(value, shapes, lsi, loc, aw)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, aw = ctx.saved_tensors
+        bs, nk, heads, hd = value.shape
+        _, nq, _, nl, npt, _ = loc.shape
+        gv, gl, ga = torch.zeros_like(value), torch.zeros_like(loc), torch.zeros_like(aw)
+        go = _gpu(grad_output, 'grad_output').float().contiguous()
+        _launch('ver_msda3d_backward', lambda: lib().ver_msda3d_backward(
+            _p(value), _p(shapes), _p(lsi), _p(loc), _p(aw), _p(go), _p(gv), _p(gl), _p(ga), bs, nk, heads,
+            hd, nl, npt, nq, _stream()))
+        return gv, None, None, gl, ga
+
+
+def voxel_msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    return VoxelMSDeformAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
+                                           attention_weights)

@@ -5,10 +5,10 @@ bevformer/modules/voxel_decoder.py:53-337 and the mmcv / mmdet layers its config
 (vocc.py:138-166): ``VoxelDetectionTransformerDecoder``, ``VoxelCustomMSDeformableAttention``,
 ``DetrTransformerDecoderLayer``, ``MultiheadAttention``.
 
-STATUS: host-side torch implementation (dense GEMMs on MFMA via hipBLASLt; the 100-query
-trilinear sampling through ``F.grid_sample``).  It exists so that the vocc.py ``model`` dict
-builds unchanged and the default head branch runs end to end; the hand-written trilinear
-gather kernel is the next widening step ("what comes next")."""
+Dense projections / self-attention are hipBLASLt GEMMs (MFMA) through torch; the 3-D
+(trilinear) deformable sampling runs on the hand-written HIP kernels ``ver_msda3d_forward`` /
+``ver_msda3d_backward`` (same lane organisation as the 2-D drop-in op).  100 queries x 8 heads x
+4 points per viewpoint: launch-latency territory, not a roofline kernel."""
 import math
 
 import torch
@@ -123,7 +123,14 @@ class VoxelCustomMSDeformableAttention(BaseModule):
                              f'but get {reference_points.shape[-1]} instead.')
         normalizer = offsets.new_tensor([[s[2], s[1], s[0]] for s in shapes])
         loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
-        output = voxel_multi_scale_deformable_attn(value.float(), shapes, loc.float(), weights.float())
+        if not value.is_cuda:
+            raise RuntimeError('VoxelCustomMSDeformableAttention runs only on the GPU (HIP kernels); '
+                               'there is no CPU fallback in this package')
+        from ..hipops import voxel_msda
+        if level_start_index is None:
+            sizes = spatial_shapes.prod(1)
+            level_start_index = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+        output = voxel_msda(value, spatial_shapes, level_start_index, loc, weights)
         output = self.output_proj(output.to(query.dtype))
         if not self.batch_first:
             output = output.permute(1, 0, 2)

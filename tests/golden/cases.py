@@ -156,3 +156,30 @@ MSDA3D_CASES = {
     'vocc_decoder': dict(seed=21, batch=1, shapes=[[4, 15, 15]], heads=8, head_dim=96, num_query=100, points=4),
     'two_levels': dict(seed=22, batch=1, shapes=[[2, 3, 5], [1, 2, 2]], heads=2, head_dim=5, num_query=23, points=3),
 }
+
+
+def detection_gt(seed=31, num_gt=5):
+    """Synthetic ground truth for the detection losses: boxes [G,9] = (cx,cy,cz,w,l,h,yaw,vx,vy)
+    inside the vocc.py range, labels in [0,17)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform([-5, -5, -1.2], [5, 5, 1.7], (num_gt, 3))
+    d = rng.uniform(0.3, 2.0, (num_gt, 3))
+    yaw = rng.uniform(-3.1, 3.1, (num_gt, 1))
+    boxes = np.concatenate([c, d, yaw, np.zeros((num_gt, 2))], 1).astype(np.float32)
+    labels = rng.integers(0, CLASS_NUM, num_gt).astype(np.int64)
+    return boxes, labels
+
+
+def occupancy_loss_inputs(seed=32, n=4000, classes=16):
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((n, classes)) * 2 - 2).astype(np.float32)
+    gt = rng.integers(0, classes + 1, n).astype(np.int64)
+    gt[rng.uniform(size=n) < 0.7] = classes          # most voxels empty
+    return logits, gt
+
+
+VOCC_TRAIN_CFG = dict(                                  # projects/configs/verformer/vocc.py:197-207 (`pts`)
+    grid_size=[512, 512, 1], voxel_size=[0.2, 0.2, 8], point_cloud_range=list(PC_RANGE), out_size_factor=4,
+    assigner=dict(type='HungarianAssigner3D', cls_cost=dict(type='FocalLossCost', weight=2.0),
+                  reg_cost=dict(type='BBox3DL1Cost', weight=0.25), iou_cost=dict(type='IoUCost', weight=0.0),
+                  pc_range=list(PC_RANGE)))

@@ -24,14 +24,104 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_CFG = stub.REFERENCE_ROOT + '/projects/configs/verformer/vocc.py'
 
 
-class _Loss(nn.Module):
-    def __init__(self, use_sigmoid=False, gamma=2.0, alpha=0.25, loss_weight=1.0, **kw):
+def _weight_reduce(loss, weight, reduction, avg_factor):
+    """mmdet.models.losses.utils.weight_reduce_loss."""
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return {'mean': loss.mean, 'sum': loss.sum, 'none': lambda: loss}[reduction]()
+    assert reduction == 'mean'
+    return loss.sum() / avg_factor
+
+
+class FocalLoss(nn.Module):
+    """mmdet 2.14.0 FocalLoss, CPU path (py_sigmoid_focal_loss)."""
+
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0):
         super().__init__()
-        self.use_sigmoid, self.gamma, self.alpha, self.loss_weight = use_sigmoid, gamma, alpha, loss_weight
+        self.use_sigmoid, self.gamma, self.alpha = use_sigmoid, gamma, alpha
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        import torch.nn.functional as F
+        nc = pred.size(1)
+        t = F.one_hot(target, num_classes=nc + 1)[:, :nc].type_as(pred)
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        fw = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
+        loss = F.binary_cross_entropy_with_logits(pred, t, reduction='none') * fw
+        if weight is not None and weight.shape != loss.shape:
+            weight = weight.view(-1, 1)
+        return self.loss_weight * _weight_reduce(loss, weight, reduction_override or self.reduction, avg_factor)
 
 
-for _n in ('FocalLoss', 'L1Loss', 'GIoULoss'):
-    stub.LOSSES.register_module(name=_n)(type(_n, (_Loss,), {}))
+class L1Loss(nn.Module):
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        if target.numel() == 0:
+            return pred.sum() * 0
+        return self.loss_weight * _weight_reduce((pred - target).abs(), weight,
+                                                 reduction_override or self.reduction, avg_factor)
+
+
+class GIoULoss(nn.Module):
+    def __init__(self, eps=1e-6, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.loss_weight = loss_weight
+
+
+for _c in (FocalLoss, L1Loss, GIoULoss):
+    stub.LOSSES.register_module()(_c)
+
+
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class BaseAssigner:
+    pass
+
+
+class _Sampling:
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :] if gt_bboxes.numel() else gt_bboxes.view(-1, 4)
+
+
+class PseudoSampler:
+    """mmdet 2.14.0 PseudoSampler.sample."""
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+        pos = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        return _Sampling(pos, neg, bboxes, gt_bboxes, assign_result)
+
+
+class FocalLossCost:
+    """mmdet 2.14.0 FocalLossCost."""
+
+    def __init__(self, weight=1., alpha=0.25, gamma=2, eps=1e-12):
+        self.weight, self.alpha, self.gamma, self.eps = weight, alpha, gamma, eps
+
+    def __call__(self, cls_pred, gt_labels):
+        p = cls_pred.sigmoid()
+        neg = -(1 - p + self.eps).log() * (1 - self.alpha) * p.pow(self.gamma)
+        pos = -(p + self.eps).log() * self.alpha * (1 - p).pow(self.gamma)
+        return (pos[:, gt_labels] - neg[:, gt_labels]) * self.weight
+
+
+class IoUCost:
+    def __init__(self, iou_mode='giou', weight=1.):
+        self.weight = weight
+
+
+stub.MATCH_COST.register_module()(FocalLossCost)
+stub.MATCH_COST.register_module()(IoUCost)
 
 
 class BaseBBoxCoder:
@@ -58,6 +148,9 @@ class DETRHead(stub.BaseModule):
         self.loss_bbox = stub.build_from_cfg(loss_bbox, stub.LOSSES)
         self.loss_iou = stub.build_from_cfg(loss_iou, stub.LOSSES)
         self.cls_out_channels = num_classes if self.loss_cls.use_sigmoid else num_classes + 1
+        if train_cfg:
+            self.assigner = stub.build_from_cfg(train_cfg['assigner'], stub.BBOX_ASSIGNERS)
+            self.sampler = PseudoSampler()
         self.positional_encoding = stub.build_positional_encoding(positional_encoding)
         self.transformer = stub.build_transformer(transformer)
         self.embed_dims = self.transformer.embed_dims
@@ -76,7 +169,11 @@ def install_head_stubs():
     m('mmdet.core', multi_apply=lambda f, *a, **k: tuple(map(list, zip(*map(f, *a)))),
       reduce_mean=lambda t: t).__path__ = []
     m('mmdet.core.bbox', BaseBBoxCoder=BaseBBoxCoder).__path__ = []
-    m('mmdet.core.bbox.builder', BBOX_CODERS=stub.BBOX_CODERS)
+    m('mmdet.core.bbox.builder', BBOX_CODERS=stub.BBOX_CODERS, BBOX_ASSIGNERS=stub.BBOX_ASSIGNERS)
+    m('mmdet.core.bbox.assigners', AssignResult=AssignResult, BaseAssigner=BaseAssigner)
+    m('mmdet.core.bbox.match_costs',
+      build_match_cost=lambda cfg: stub.build_from_cfg(cfg, stub.MATCH_COST)).__path__ = []
+    m('mmdet.core.bbox.match_costs.builder', MATCH_COST=stub.MATCH_COST)
     sys.modules['mmdet.models'].HEADS = stub.HEADS
     m('mmdet.models.dense_heads', DETRHead=DETRHead)
     sys.modules['mmdet.models.utils.transformer'].inverse_sigmoid = _inverse_sigmoid
@@ -92,6 +189,10 @@ def install_head_stubs():
     stub._pkg('projects.mmdet3d_plugin.core.bbox', root + '/core/bbox')
     stub._pkg('projects.mmdet3d_plugin.core.bbox.coders', root + '/core/bbox/coders')
     stub._pkg('projects.mmdet3d_plugin.bevformer.dense_heads', root + '/bevformer/dense_heads')
+    stub._pkg('projects.mmdet3d_plugin.core.bbox.assigners', root + '/core/bbox/assigners')
+    stub._pkg('projects.mmdet3d_plugin.core.bbox.match_costs', root + '/core/bbox/match_costs')
+    importlib.import_module('projects.mmdet3d_plugin.core.bbox.assigners.hungarian_assigner_3d')
+    importlib.import_module('projects.mmdet3d_plugin.core.bbox.match_costs.match_cost')
     importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.nms_free_coder')
     importlib.import_module('projects.mmdet3d_plugin.core.bbox.coders.layout_coder')
     stub.ref_modules()
@@ -178,4 +279,33 @@ def gen_head(ref):
     save('head_vocc', **arrays)
 
 
-GENERATORS = {'head': gen_head}
+def gen_loss(ref):
+    """next-row 2: the reference head's own ``loss_single`` (head:903-990: Hungarian targets via
+    its HungarianAssigner3D, focal / L1 / occupancy losses) on the stored decoder outputs of the
+    vocc.py head (viewpoint 0, last decoder layer) and synthetic ground truth."""
+    from make_golden import save
+    head_mod = install_head_stubs()
+    cfg, train_cfg = reference_head_cfg()
+    assert _plain(train_cfg['pts']) == _plain(cases.VOCC_TRAIN_CFG), 'cases.VOCC_TRAIN_CFG drifted from vocc.py'
+    c = copy.deepcopy(cfg)
+    c.pop('type')
+    # a light head is enough for the losses: same classes / ranges, tiny transformer is not possible
+    # (768 is hard-wired), so build the real one once (no forward needed)
+    head = head_mod.VoxelFormerOccupancyHead(train_cfg=train_cfg['pts'], **c)
+    g = np.load(os.path.join(HERE, 'head_vocc.npz'))
+    cls = T(g['c3_b0_cls'][-1]).clone().requires_grad_(True)            # [1,100,17]
+    box = T(g['c3_b0_bbox'][-1]).clone().requires_grad_(True)           # [1,100,10]
+    boxes, labels = cases.detection_gt()
+    logits, gt_occ = cases.occupancy_loss_inputs()
+    occ = T(logits).requires_grad_(True)
+    lc, lb, lo, lf = head.loss_single(cls, box, occ, None, [T(boxes)], T(labels), None, T(gt_occ), None)
+    (lc + lb + lo).backward()
+    res = head.assigner.assign(box[0].detach(), cls[0].detach(), T(boxes), T(labels), None)
+    print('  loss_cls %.6f loss_bbox %.6f loss_occ %.6f; matched queries %s'
+          % (float(lc), float(lb), float(lo), torch.nonzero(res.gt_inds > 0).squeeze(-1).tolist()))
+    save('loss_vocc', loss_cls=np.float64(lc.detach()), loss_bbox=np.float64(lb.detach()),
+         loss_occ=np.float64(lo.detach()), gt_inds=res.gt_inds.numpy(), assigned_labels=res.labels.numpy(),
+         grad_cls=cls.grad.numpy(), grad_box=box.grad.numpy(), grad_occ=occ.grad.numpy())
+
+
+GENERATORS = {'head': gen_head, 'loss': gen_loss}

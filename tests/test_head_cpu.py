@@ -69,3 +69,39 @@ def test_occupancy_branch_equals_oracle(head):
                                   use_torch_convt=False)
     assert ours.shape == want.shape == (1, 504000, 16)
     assert close(ours, want, atol=1e-4, rtol=1e-4)
+
+
+def test_detection_and_occupancy_losses_match_reference():
+    """next-row 2: our loss_single (Hungarian targets + focal / L1 / occupancy focal) vs the
+    reference head's own loss_single (tests/golden/loss_vocc.npz)."""
+    pkg()
+    T = torch.from_numpy
+    g = golden('loss_vocc')
+    gh = golden('head_vocc')
+    h = pkg('registry').build_head(dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG))
+    cls = T(gh['c3_b0_cls'][-1]).clone().requires_grad_(True)
+    box = T(gh['c3_b0_bbox'][-1]).clone().requires_grad_(True)
+    boxes, labels = cases.detection_gt()
+    logits, gt_occ = cases.occupancy_loss_inputs()
+    occ = T(logits).requires_grad_(True)
+    res = h.assigner.assign(box[0].detach(), cls[0].detach(), T(boxes), T(labels))
+    assert res.gt_inds.tolist() == g['gt_inds'].tolist()                 # same Hungarian matching
+    assert res.labels.tolist() == g['assigned_labels'].tolist()
+    lc, lb, lo = h.loss_single(cls, box, occ, [T(boxes)], [T(labels)], T(gt_occ))
+    assert float(lc) == pytest.approx(float(g['loss_cls']), rel=1e-5)
+    assert float(lb) == pytest.approx(float(g['loss_bbox']), rel=1e-5)
+    assert float(lo) == pytest.approx(float(g['loss_occ']), rel=1e-5)
+    (lc + lb + lo).backward()
+    assert close(cls.grad, g['grad_cls'], atol=1e-5, rtol=1e-4)
+    assert close(box.grad, g['grad_box'], atol=1e-6, rtol=1e-4)
+    assert close(occ.grad, g['grad_occ'], atol=1e-7, rtol=1e-4)
+    # the dict of the reference's loss(): last layer + d0..d4
+    preds = dict(all_cls_scores=T(gh['c3_b0_cls']), all_bbox_preds=T(gh['c3_b0_bbox']),
+                 occupancy_preds=T(logits)[None])
+    d = h.loss([T(boxes)[:, :7]], [labels], T(gt_occ)[None], preds)
+    assert sorted(d) == sorted(['loss_cls', 'loss_bbox', 'loss_occupancy', 'loss_flow'] +
+                               ['d%d.loss_%s' % (i, k) for i in range(5) for k in ('cls', 'bbox')])
+    assert float(d['loss_cls']) == pytest.approx(float(g['loss_cls']), rel=1e-5)
+    # empty ground truth: everything is background, box loss is zero
+    lc0, lb0, _ = h.loss_single(cls.detach(), box.detach(), None, [T(boxes)[:0]], [T(labels)[:0]])
+    assert float(lb0) == 0.0 and float(lc0) > 0.0

@@ -23,6 +23,9 @@ from ..modules.voxel_decoder import inverse_sigmoid
 from ..registry import (HEADS, build_bbox_coder, build_loss, build_positional_encoding,
                         build_transformer)
 from . import coders, losses  # noqa: F401  (registers NMSFreeCoder / FocalLoss / ...)
+from .assigner import SamplingResult, build_assigner
+from .coders import normalize_bbox
+from ..ddp import reduce_mean
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
 
@@ -94,6 +97,14 @@ class VoxelFormerOccupancyHead(BaseModule):
         self.num_query, self.num_classes, self.in_channels = num_query, num_classes, in_channels
         self.num_reg_fcs = num_reg_fcs
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.assigner = None
+        if train_cfg:                                   # mmdet DETRHead: assigner + PseudoSampler
+            assert 'assigner' in train_cfg, 'assigner should be provided when train_cfg is set.'
+            assert loss_cls['loss_weight'] == train_cfg['assigner']['cls_cost']['weight'], \
+                'The classification weight for loss and matcher should be exactly the same.'
+            assert loss_bbox['loss_weight'] == train_cfg['assigner']['reg_cost']['weight'], \
+                'The regression L1 weight for loss and matcher should be exactly the same.'
+            self.assigner = build_assigner(train_cfg['assigner'])
         self.loss_cls = build_loss(loss_cls) if loss_cls is not None else None
         self.loss_bbox = build_loss(loss_bbox) if loss_bbox is not None else None
         self.loss_iou = build_loss(loss_iou) if loss_iou is not None else None
@@ -289,6 +300,85 @@ class VoxelFormerOccupancyHead(BaseModule):
         gt = gt_occupancy.reshape(-1)
         avg = (gt < self.occupancy_classes).sum() * 1.0
         return torch.nan_to_num(self.loss_occupancy(preds, gt, avg_factor=avg))
+
+    # ------------------------------------------------------------------ detection losses
+    def _get_target_single(self, cls_score, bbox_pred, gt_labels, gt_bboxes):
+        """head:642-705 for one sample."""
+        num_bboxes = bbox_pred.size(0)
+        gt_c = gt_bboxes.shape[-1]
+        if gt_bboxes.dim() == 1:
+            gt_bboxes = gt_bboxes[None]
+        assign_result = self.assigner.assign(bbox_pred, cls_score, gt_bboxes, gt_labels, None)
+        sr = SamplingResult(assign_result, bbox_pred, gt_bboxes)
+        labels = gt_bboxes.new_full((num_bboxes,), self.num_classes, dtype=torch.long)
+        labels[sr.pos_inds] = gt_labels if gt_labels.dim() < 1 else gt_labels[sr.pos_assigned_gt_inds]
+        label_weights = gt_bboxes.new_ones(num_bboxes)
+        bbox_targets = torch.zeros_like(bbox_pred)[..., :gt_c]
+        bbox_weights = torch.zeros_like(bbox_pred)
+        bbox_weights[sr.pos_inds] = 1.0
+        bbox_targets[sr.pos_inds] = sr.pos_gt_bboxes
+        return labels, label_weights, bbox_targets, bbox_weights, sr.pos_inds, sr.neg_inds
+
+    def loss_single(self, cls_scores, bbox_preds, occupancy_preds, gt_bboxes_list, gt_labels_list,
+                    gt_occupancy=None):
+        """One decoder layer's losses (head:903-990): Hungarian targets, sigmoid focal loss with
+        the (all-reduced) positive count as normaliser, code-weighted L1 on normalised boxes with
+        non-finite targets dropped, occupancy focal loss; NaN-guarded.
+        cls_scores [bs,Nq,C], bbox_preds [bs,Nq,10]; gt_bboxes_list / gt_labels_list per sample."""
+        num_imgs = cls_scores.size(0)
+        out = [self._get_target_single(cls_scores[i], bbox_preds[i], gt_labels_list[i], gt_bboxes_list[i])
+               for i in range(num_imgs)]
+        labels = torch.cat([o[0] for o in out], 0)
+        label_weights = torch.cat([o[1] for o in out], 0)
+        bbox_targets = torch.cat([o[2] for o in out], 0)
+        bbox_weights = torch.cat([o[3] for o in out], 0)
+        num_total_pos = sum(o[4].numel() for o in out)
+        num_total_neg = sum(o[5].numel() for o in out)
+        cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
+        cls_avg_factor = num_total_pos * 1.0 + num_total_neg * self.bg_cls_weight
+        if self.sync_cls_avg_factor:
+            cls_avg_factor = float(reduce_mean(cls_scores.new_tensor([cls_avg_factor])))
+        cls_avg_factor = max(cls_avg_factor, 1)
+        loss_cls = self.loss_cls(cls_scores, labels, label_weights, avg_factor=cls_avg_factor)
+        num_total_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([num_total_pos])), min=1).item()
+        bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
+        normalized = normalize_bbox(bbox_targets, self.pc_range)
+        isnotnan = torch.isfinite(normalized).all(dim=-1)
+        bbox_weights = bbox_weights * self.code_weights
+        loss_bbox = self.loss_bbox(bbox_preds[isnotnan, :10], normalized[isnotnan, :10],
+                                   bbox_weights[isnotnan, :10], avg_factor=num_total_pos)
+        if occupancy_preds is not None:
+            loss_occ = self.occupancy_loss(occupancy_preds, gt_occupancy)
+        else:
+            loss_occ = torch.zeros_like(loss_cls)
+        return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox), loss_occ
+
+    def loss(self, gt_bboxes_list, gt_labels_list, gt_occupancy, preds_dicts):
+        """Loss dict of the reference (head:1251-1384): last decoder layer -> ``loss_cls``,
+        ``loss_bbox``, ``loss_occupancy``, ``loss_flow`` (zero); earlier layers -> ``d{i}.loss_*``.
+        gt_bboxes_list: per sample [G, 7..9] boxes (gravity centre + dims + yaw [+ vel]);
+        gt_occupancy: int64 [bs, voxel_num] with ``occupancy_classes`` = empty."""
+        all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
+        occ = preds_dicts['occupancy_preds']
+        padded = []
+        for g in gt_bboxes_list:                       # pad velocity columns (head:1316-1317)
+            g = g.to(all_box.device)
+            if g.shape[-1] < 9:
+                g = torch.cat([g, g.new_zeros(g.shape[0], 9 - g.shape[-1])], dim=1)
+            padded.append(g)
+        labels = [torch.as_tensor(x, device=all_box.device).long() for x in gt_labels_list]
+        nl = len(all_cls)
+        losses = {}
+        for lvl in range(nl):
+            last = lvl == nl - 1
+            lc, lb, lo = self.loss_single(all_cls[lvl], all_box[lvl], occ if last else None, padded, labels,
+                                          gt_occupancy if last else None)
+            if last:
+                losses.update(loss_cls=lc, loss_bbox=lb, loss_occupancy=lo, loss_flow=torch.zeros_like(lc))
+            else:
+                losses['d%d.loss_cls' % lvl] = lc
+                losses['d%d.loss_bbox' % lvl] = lb
+        return losses
 
     def lift(self, mlvl_feats, img_metas=None, **kwargs):
         """The lifting path alone (encoder + occupancy branch, no detection decoder):

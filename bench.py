@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='viewpoints per GPU per step')
     ap.add_argument('--micro', type=int, default=8, help='viewpoints per head micro-batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd'])
+    ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd', 'vocc_full_train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL); gloo only to exercise the N>1 path on one GPU')
@@ -72,6 +72,24 @@ class LiftTrainer(torch.nn.Module):
         return total / bs
 
 
+class FullTrainer(torch.nn.Module):
+    """BASELINE.json configs[4]: the whole vocc.py head (encoder, 6-layer detection decoder, cls/reg
+    branches, coarse-to-fine occupancy) with the reference's loss dict (Hungarian targets on the
+    host, focal + L1 + occupancy focal)."""
+
+    def __init__(self, head, dtype):
+        super().__init__()
+        self.head = head
+        self.autocast = dtype == 'bf16'
+
+    def forward(self, feats, w2p, org, gt, gt_boxes, gt_labels):
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.autocast):
+            outs = self.head(feats, None, world2pixel=w2p, origin=org)
+        outs = {k: (v.float() if torch.is_tensor(v) else v) for k, v in outs.items()}
+        losses = self.head.loss(gt_boxes, gt_labels, gt, outs)
+        return sum(losses.values())
+
+
 def build_model(args, dev):
     import cases
     pkg = importlib.import_module('vln-ver_amd')
@@ -80,9 +98,14 @@ def build_model(args, dev):
         cfg = cases.vocc_head_cfg(bev=(16, 50, 50), refine_occ=False)
     else:
         cfg = cases.vocc_head_cfg()
+    if args.workload == 'vocc_full_train':
+        cfg = dict(cfg, train_cfg=cases.VOCC_TRAIN_CFG)
     torch.manual_seed(2)
     head = pkg.registry.build_head(cfg)
     head.init_weights()
+    if args.workload == 'vocc_full_train':
+        n_train = sum(p.numel() for p in head.parameters() if p.requires_grad)
+        return pkg, syn, head.to(dev), n_train
     # the lifting path does not touch the detection decoder / branches: freeze them so that
     # DDP reduces (and AdamW updates) exactly the parameters the path trains
     lift_prefixes = ('transformer.encoder.', 'transformer.level_embeds', 'transformer.cams_embeds',
@@ -169,8 +192,9 @@ def main():
     hip.lib()
     pkg, syn, head, n_train = build_model(args, dev)
     B = args.batch
-    train = args.workload == 'vocc_c2f_train'
-    model = LiftTrainer(head, args.micro, args.dtype).to(dev)
+    train = args.workload in ('vocc_c2f_train', 'vocc_full_train')
+    full = args.workload == 'vocc_full_train'
+    model = (FullTrainer(head, args.dtype) if full else LiftTrainer(head, args.micro, args.dtype)).to(dev)
     model.train(train)
     ddp = model                                 # train(): dropout ON, as in the reference's step
     if world > 1 and train:
@@ -186,9 +210,15 @@ def main():
     nvox = head.voxel_num if head.refine_occ else head.bev_h * head.bev_w * head.occ_zdim
     gt = torch.from_numpy(np.random.default_rng(7 + rank).integers(0, 17, size=(B, nvox))).to(dev)
 
+    if full:
+        import cases
+        gts = [cases.detection_gt(seed=40 + rank * 1000 + i, num_gt=3 + i % 5) for i in range(B)]
+        gt_boxes = [torch.from_numpy(g[0][:, :7]).to(dev) for g in gts]
+        gt_labels = [torch.from_numpy(g[1]).to(dev) for g in gts]
+
     def step():
         if train:
-            loss = ddp(feats, w2p, org, gt)
+            loss = ddp(feats, w2p, org, gt, gt_boxes, gt_labels) if full else ddp(feats, w2p, org, gt)
             loss.backward()
             torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:270 grad_clip max_norm
             opt.step()
@@ -250,7 +280,9 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (N(0,1) ViT features, 6-camera pinhole rig, random occupancy labels; '
                     'reference-rule random-init weights)',
-            'config': {'workload': 'vocc.py coarse-to-fine lifting path (15x15x4 -> 120x120x35x16): encoder + '
+            'config': {'workload': ('vocc.py full multi-task head (encoder + detection decoder + cls/reg branches + '
+                                    'coarse-to-fine occupancy), reference loss dict, fwd+bwd+AdamW') if full else
+                                   'vocc.py coarse-to-fine lifting path (15x15x4 -> 120x120x35x16): encoder + '
                                    'occupancy head + focal loss, fwd+bwd+AdamW' if train else
                                    'single-scale 50x50x16 volume, forward only',
                        'viewpoints_per_gpu_per_step': B, 'global_viewpoints_per_step': B * world,
@@ -260,7 +292,7 @@ def main():
                                      else 'fp32'},
             'roofline': roof, 'roofline_other_kernels': others,
         }
-        if world == 1 and not args.no_cpu_baseline and train:
+        if world == 1 and not args.no_cpu_baseline and train and not full:
             line['cpu_baseline'] = cpu_baseline(head, syn, args.cpu_seconds)
         else:
             line['cpu_baseline'] = None

@@ -308,4 +308,31 @@ def gen_loss(ref):
          grad_cls=cls.grad.numpy(), grad_box=box.grad.numpy(), grad_occ=occ.grad.numpy())
 
 
-GENERATORS = {'head': gen_head, 'loss': gen_loss}
+def gen_post(ref):
+    """next-rows 3/4: the reference's get_occupancy_prediction (head:1505-1540) and SSCMetrics
+    (datasets/occupancy_metrics.py, imported directly: pure numpy)."""
+    from make_golden import save
+    import importlib.util
+    head_mod = install_head_stubs()
+    logits, gt = cases.occupancy_loss_inputs(seed=33, n=6000)
+    obj = head_mod.VoxelFormerOccupancyHead.__new__(head_mod.VoxelFormerOccupancyHead)
+    obj.occ_loss_type, obj.occupancy_classes, obj.flow_gt_dimension = 'focal_loss', 16, 2
+    res = head_mod.VoxelFormerOccupancyHead.get_occupancy_prediction(
+        obj, dict(occupancy_preds=T(logits)[None], flow_preds=None))
+    sparse = res['occupancy_preds'].numpy()
+    spec = importlib.util.spec_from_file_location(
+        'ref_occ_metrics', stub.REFERENCE_ROOT + '/projects/mmdet3d_plugin/datasets/occupancy_metrics.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    m = mod.SSCMetrics(n_classes=17)
+    dense = np.full(6000, 16, dtype=np.int64)
+    dense[sparse[:, 0]] = sparse[:, 1]
+    m.add_batch(dense, gt)
+    m.add_batch(dense[::-1].copy(), gt)
+    st = m.get_stats()
+    print('  sparse voxels %d, iou %.3f miou %.3f' % (len(sparse), st['iou'], st['miou']))
+    save('post_vocc', sparse=sparse, hist=m.hist, iou=np.float64(st['iou']), precision=np.float64(st['precision']),
+         recall=np.float64(st['recall']), iou_ssc=st['iou_ssc'], miou=np.float64(st['miou']))
+
+
+GENERATORS = {'head': gen_head, 'loss': gen_loss, 'post': gen_post}

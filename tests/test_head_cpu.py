@@ -105,3 +105,40 @@ def test_detection_and_occupancy_losses_match_reference():
     # empty ground truth: everything is background, box loss is zero
     lc0, lb0, _ = h.loss_single(cls.detach(), box.detach(), None, [T(boxes)[:0]], [T(labels)[:0]])
     assert float(lb0) == 0.0 and float(lc0) > 0.0
+
+
+def test_occupancy_postprocessing_and_metrics_match_reference(tmp_path):
+    """next-rows 3/4: sparse occupancy prediction, SSC metrics, volume export layout."""
+    pkg()
+    T = torch.from_numpy
+    g = golden('post_vocc')
+    metrics = pkg('occupancy_metrics')
+    vio = pkg('volume_io')
+    h = pkg('registry').build_head(cases.vocc_head_cfg(only_occ=True))
+    logits, gt = cases.occupancy_loss_inputs(seed=33, n=6000)
+    res = h.get_occupancy_prediction(dict(occupancy_preds=T(logits)[None], flow_preds=None))
+    assert np.array_equal(res['occupancy_preds'].numpy(), g['sparse'])
+    dense = metrics.dense_labels(res['occupancy_preds'].numpy(), 6000, 16)
+    m = metrics.SSCMetrics(17)
+    m.add_batch(dense, gt)
+    m.add_batch(dense[::-1].copy(), gt)
+    st = m.get_stats()
+    assert np.array_equal(m.hist, g['hist'])
+    for k in ('iou', 'precision', 'recall', 'miou'):
+        assert float(st[k]) == pytest.approx(float(g[k]), rel=1e-12)
+    assert np.allclose(st['iou_ssc'], g['iou_ssc'], rtol=1e-12)
+    # volume export: float64, raw (C,Z,H,W) reinterpretation of the [Nq,C] buffer, key = sample_idx
+    emb = torch.arange(900 * 768, dtype=torch.float32).view(900, 768)
+    w = vio.VolumeWriter(str(tmp_path / 'vols'))
+    vol = h.export_volume(w, 'scanA_vp0', emb)
+    back = vio.read_volume(str(tmp_path / 'vols'), 'scanA_vp0')
+    assert back.dtype == np.float64 and back.shape == (768, 4, 15, 15) and np.array_equal(back, vol)
+    assert back[1, 0, 0, 0] == 900.0 and back[0, 0, 0, 1] == 1.0       # flat[c*900 + k*225 + j*15 + i]
+    # feature store: CLS token dropped
+    os_dir = tmp_path / 'feats'
+    os_dir.mkdir()
+    for d in range(6):
+        np.save(str(os_dir / ('scanA_vp0_i1_%d.npy' % d)), np.full((1, 197, 768), d, dtype=np.float32))
+    fs = vio.FeatureStore(str(os_dir))
+    v = fs.viewpoint('scanA_vp0')
+    assert v.shape == (6, 1, 196, 768) and float(v[3].mean()) == 3.0

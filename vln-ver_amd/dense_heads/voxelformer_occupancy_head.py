@@ -380,6 +380,21 @@ class VoxelFormerOccupancyHead(BaseModule):
                 losses['d%d.loss_bbox' % lvl] = lb
         return losses
 
+    def get_occupancy_prediction(self, occ_results, occ_threshold=0.25):
+        """head:1505-1540 (focal-loss branch): sigmoid, threshold as an extra "empty" column,
+        arg-max -> sparse ``(voxel index, class)`` pairs of the occupied voxels."""
+        p = occ_results['occupancy_preds'].reshape(-1, self.occupancy_classes).sigmoid()
+        p = torch.cat((p, torch.ones_like(p)[:, :1] * occ_threshold), dim=-1)
+        occ_class = p.argmax(dim=-1)
+        occ_index, = torch.where(occ_class < self.occupancy_classes)
+        occ_results['occupancy_preds'] = torch.stack([occ_index, occ_class[occ_index]], dim=-1)
+        occ_results['flow_preds'] = None
+        return occ_results
+
+    def export_volume(self, writer, key, voxel_embed_sample):
+        """``getbev`` dump of head:627-638 for one sample ([Nq,C] encoder output)."""
+        return writer.write(key, voxel_embed_sample, (self.bev_z, self.bev_h, self.bev_w), self.embed_dims)
+
     def lift(self, mlvl_feats, img_metas=None, **kwargs):
         """The lifting path alone (encoder + occupancy branch, no detection decoder):
         -> (voxel_embed [bs,Nq,C], occupancy logits [bs, X*Y*Z, classes])."""

@@ -686,6 +686,310 @@ __global__ __launch_bounds__(512) void k_sca_bwd(const VT* __restrict__ value, c
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward, split in two atomic-free (in LDS) kernels for head_dim >= 32 (16-lane groups):
+//
+//  k_sca_bwd_off  d(offsets), d(logits): the forward kernel's structure (double-buffered LDS-DMA
+//     tiles over heads, phase A / phase B, DPP broadcast).  Phase B forms the per-corner dots
+//     <g, V[row]> (16-lane DPP butterflies); the phase-A lane that owns the corner picks its dot
+//     up and combines it with its own bilinear weight / slope; softmax backward is a second
+//     butterfly over the row.  Rows of voxels seen by one camera are plain stores, others fp32
+//     atomics on the zeroed buffers.
+//  k_sca_bwd_val  d(value): does not need the value tile at all.  Per (viewpoint, camera, head) and
+//     sub-chunk of 160 visible voxels: grad rows -> LDS, every (voxel, point, corner) becomes an
+//     event {tile row, softmax*corner weight/#cams}; the events are counting-sorted by tile row with
+//     integer LDS atomics, and each 16-lane group then accumulates ITS tile rows in registers
+//     (4 rows x HD/16 channels per lane) from the LDS-resident grad rows.  One plain store per
+//     tile row at the end; no floating-point atomics (the retired kernel spent 52 % of its wave
+//     cycles waiting on ds_add_f32, which retires ~0.5 lane/clk/CU).
+constexpr int kValSub = 160;           // voxels per sub-chunk of k_sca_bwd_val
+constexpr int kValThreads = 1024;
+constexpr int kValMaxRows = 256;       // tile rows (map_h*map_w) the register accumulators cover
+
+template <int HD, int P, typename VT>
+__global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
+    const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
+    const int* __restrict__ vis_cnt, const float* __restrict__ gslots, float* goffs, float* glogits, int Ncam,
+    int Nq, int D, int heads, int mh, int mw, int nchunks, int chunk, int hsplit, int nbuf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CPL = HD / 16;
+    constexpr int LPP = 16 / P, CPN = 4 / LPP;
+    constexpr int STEP = kFwdWaves * 4;
+    using M16 = ChMap<HD, 16>;
+    const int Nk = mh * mw;
+    const size_t tile_elems = (size_t)Nk * HD;
+    VT* tiles = reinterpret_cast<VT*>(smem);
+    int bid = blockIdx.x;
+    const int ck = bid % nchunks;
+    bid /= nchunks;
+    const int hs = bid % hsplit;
+    bid /= hsplit;
+    const int c = bid % Ncam;
+    const int b = bid / Ncam;
+    const int cnt = vis_cnt[b * Ncam + c];
+    const int start = ck * chunk;
+    if (start >= cnt) return;
+    const int end = min(cnt, start + chunk);
+    const int heads_per = heads / hsplit, h0 = hs * heads_per;
+    const size_t rstride = (size_t)heads * HD;
+    const VT* vown = value + ((size_t)b * Ncam + c) * Nk * rstride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = lane >> 4, lr = lane & 15;
+    const int ap = lr / LPP, asub = lr % LPP;
+    const int ad = (D == 1) ? 0 : (ap % D);
+    const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+    constexpr unsigned kRowBytes = HD * sizeof(VT);
+
+    if (nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave, kFwdWaves);
+    for (int hh = 0; hh < heads_per; ++hh) {
+        const int h = h0 + hh;
+        const int cur = nbuf == 2 ? (hh & 1) : 0;
+        VT* tile = tiles + cur * tile_elems;
+        if (nbuf == 1) {
+            __syncthreads();
+            stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave, kFwdWaves);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (nbuf == 2 && hh + 1 < heads_per)
+            stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, wave,
+                               kFwdWaves);
+        const unsigned char* tile0 = reinterpret_cast<const unsigned char*>(tile + M16::off0(lr));
+        const unsigned char* tile1 = reinterpret_cast<const unsigned char*>(tile + M16::off1(lr));
+
+        for (int base = start + wave * 4; base < end; base += STEP) {
+            const int ia = base + row;
+            const bool alive = ia < end;
+            const int n = alive ? list[ia] : 0;
+            const unsigned m = alive ? (unsigned)vis[(size_t)b * Nq + n] : 0u;
+            const size_t qh = ((size_t)b * Nq + n) * heads + h;
+            const float lg = logits[qh * P + ap];
+            const float2 of = *reinterpret_cast<const float2*>(offs + (qh * P + ap) * 2);
+            const float2 u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + ad) * 2);
+            float g[CPL];
+            load_ch<HD, 16, float>(gslots + ((size_t)b * Nq + n) * heads * HD + (size_t)h * HD, lr, g);
+            const float icnt = m ? 1.0f / (float)__popc(m) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) g[j] *= icnt;
+            // ---------------- phase A
+            const float mx = group_max<16>(lg);
+            const float e = __expf(lg - mx);
+            const float a = e / group_sum<16>(asub == 0 ? e : 0.0f);
+            Bilinear s;
+            bilinear_setup<true>(u.x + of.x * inv_w, u.y + of.y * inv_h, mh, mw, s);
+            float wsel[2], gxs[2], gys[2];
+            unsigned ksel[2];
+            if constexpr (CPN == 2) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    wsel[r] = asub ? s.w[2 + r] : s.w[r];
+                    gxs[r] = asub ? s.gx[2 + r] : s.gx[r];
+                    gys[r] = asub ? s.gy[2 + r] : s.gy[r];
+                    ksel[r] = (unsigned)(asub ? s.key[2 + r] : s.key[r]) * kRowBytes;
+                }
+            } else {
+                const int q = asub & 3;
+                wsel[0] = q == 0 ? s.w[0] : q == 1 ? s.w[1] : q == 2 ? s.w[2] : s.w[3];
+                gxs[0] = q == 0 ? s.gx[0] : q == 1 ? s.gx[1] : q == 2 ? s.gx[2] : s.gx[3];
+                gys[0] = q == 0 ? s.gy[0] : q == 1 ? s.gy[1] : q == 2 ? s.gy[2] : s.gy[3];
+                ksel[0] = (unsigned)(q == 0 ? s.key[0] : q == 1 ? s.key[1] : q == 2 ? s.key[2] : s.key[3]) * kRowBytes;
+                wsel[1] = gxs[1] = gys[1] = 0.0f;
+                ksel[1] = 0u;
+            }
+            // ---------------- phase B: dots of the grad row with the four corner rows of every point
+            float dsel[2] = {0.0f, 0.0f};
+            auto one_point = [&](auto pt_c) {
+                constexpr int PT = decltype(pt_c)::value;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int reg = t % CPN;
+                    unsigned koff;
+                    if (t / CPN == 0) koff = row_bcast_u<PT * LPP + 0>(ksel[reg]);
+                    else if (t / CPN == 1) koff = row_bcast_u<PT * LPP + (LPP > 1 ? 1 : 0)>(ksel[reg]);
+                    else if (t / CPN == 2) koff = row_bcast_u<PT * LPP + (LPP > 2 ? 2 : 0)>(ksel[reg]);
+                    else koff = row_bcast_u<PT * LPP + (LPP > 3 ? 3 : 0)>(ksel[reg]);
+                    float v[CPL];
+                    load_vec<M16::W0>(reinterpret_cast<const VT*>(tile0 + koff), v);
+                    load_vec<M16::W1>(reinterpret_cast<const VT*>(tile1 + koff), v + M16::W0);
+                    float d = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) d += g[j] * v[j];
+                    d = group_sum<16>(d);
+                    if (ap == PT && asub == t / CPN) dsel[reg] = d;
+                }
+            };
+            one_point(std::integral_constant<int, 0>());
+            one_point(std::integral_constant<int, 1>());
+            one_point(std::integral_constant<int, 2>());
+            one_point(std::integral_constant<int, 3>());
+            if constexpr (P == 8) {
+                one_point(std::integral_constant<int, 4>());
+                one_point(std::integral_constant<int, 5>());
+                one_point(std::integral_constant<int, 6>());
+                one_point(std::integral_constant<int, 7>());
+            }
+            // ---------------- back in the phase-A role: combine the point's corners, softmax backward
+            float sa = wsel[0] * dsel[0] + wsel[1] * dsel[1];
+            float sx = gxs[0] * dsel[0] + gxs[1] * dsel[1];
+            float sy = gys[0] * dsel[0] + gys[1] * dsel[1];
+            sa = group_sum<LPP>(sa);
+            sx = group_sum<LPP>(sx);
+            sy = group_sum<LPP>(sy);
+            const float dot = group_sum<16>(asub == 0 ? a * sa : 0.0f);
+            if (alive && m && asub == 0) {
+                float* go = goffs + (qh * P + ap) * 2;
+                float* gw = glogits + qh * P + ap;
+                const float gx = a * sx, gy = a * sy, gl = a * (sa - dot);   // d x_pix / d offset = 1
+                if (!(m & (m - 1))) {
+                    *reinterpret_cast<float2*>(go) = make_float2(gx, gy);
+                    *gw = gl;
+                } else {
+                    atomicAdd(go, gx);
+                    atomicAdd(go + 1, gy);
+                    atomicAdd(gw, gl);
+                }
+            }
+        }
+    }
+}
+
+template <int HD, int P>
+__global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
+    const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ uv,
+    const uint8_t* __restrict__ vis, const int* __restrict__ vis_list, const int* __restrict__ vis_cnt,
+    const float* __restrict__ gslots, float* gvalue, int Ncam, int Nq, int D, int heads, int mh, int mw,
+    int nchunks, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CPL = HD / 16;
+    constexpr int NEV = kValSub * P * 4;               // events per sub-chunk
+    constexpr int NR = kValMaxRows / 64;               // tile rows per lane group
+    float* G = reinterpret_cast<float*>(smem);                                   // [kValSub][HD]
+    float* ev_coef = G + kValSub * HD;                                           // [NEV]
+    unsigned short* ev_key = reinterpret_cast<unsigned short*>(ev_coef + NEV);   // [NEV]
+    unsigned short* sorted = ev_key + NEV;                                       // [NEV]
+    int* rcnt = reinterpret_cast<int*>(sorted + NEV);                            // [kValMaxRows]
+    int* rstart = rcnt + kValMaxRows;                                            // [kValMaxRows]
+    int* rcur = rstart + kValMaxRows;                                            // [kValMaxRows]
+    const int Nk = mh * mw;
+    int bid = blockIdx.x;
+    const int ck = bid % nchunks;
+    bid /= nchunks;
+    const int h = bid % heads;
+    bid /= heads;
+    const int c = bid % Ncam;
+    const int b = bid / Ncam;
+    const int cnt = vis_cnt[b * Ncam + c];
+    const int start = ck * chunk;
+    const bool atomic_flush = nchunks > 1;             // gvalue pre-zeroed by the host wrapper then
+    if (start >= cnt && (atomic_flush || ck != 0)) return;
+    const int end = min(cnt, start + chunk);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int gidx = tid >> 4, lr = tid & 15;           // 64 lane groups of 16
+    const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+    float acc[NR][CPL];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) acc[j][i] = 0.0f;
+
+    for (int s0 = start; s0 < end; s0 += kValSub) {
+        const int nsub = min(kValSub, end - s0);
+        for (int i = tid; i < kValMaxRows; i += kValThreads) rcnt[i] = 0;
+        // grad rows of the sub-chunk's voxels, scaled by 1/#cams
+        for (int v = gidx; v < nsub; v += kValThreads / 16) {
+            const int n = list[s0 + v];
+            const float icnt = 1.0f / (float)__popc((unsigned)vis[(size_t)b * Nq + n]);
+            float g[CPL];
+            load_ch<HD, 16, float>(gslots + ((size_t)b * Nq + n) * heads * HD + (size_t)h * HD, lr, g);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) g[j] *= icnt;
+            store_ch<HD, 16>(G + v * HD, lr, g);
+        }
+        __syncthreads();
+        // events: one lane per (voxel, point); groups of P lanes share a voxel (softmax butterfly)
+        for (int q0 = wave * 64; q0 < nsub * P; q0 += kValThreads) {
+            const int q = q0 + lane;
+            const bool live = q < nsub * P;
+            const int v = live ? q / P : 0, p = q % P;
+            const int n = list[s0 + v];
+            const size_t qh = ((size_t)b * Nq + n) * heads + h;
+            const float lg = logits[qh * P + p];
+            const float2 of = *reinterpret_cast<const float2*>(offs + (qh * P + p) * 2);
+            const int d = (D == 1) ? 0 : (p % D);
+            const float2 u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + d) * 2);
+            const float mx = group_max<P>(lg);
+            const float e = __expf(lg - mx);
+            const float a = e / group_sum<P>(e);
+            Bilinear s;
+            bilinear_setup<false>(u.x + of.x * inv_w, u.y + of.y * inv_h, mh, mw, s);
+            if (live) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float coef = a * s.w[t];
+                    ev_coef[q * 4 + t] = coef;
+                    ev_key[q * 4 + t] = (unsigned short)s.key[t];
+                    if (coef != 0.0f) atomicAdd(&rcnt[s.key[t]], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {                                 // exclusive scan over the (<= 256) tile rows
+            int loc[4], run = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                loc[i] = run;
+                run += rcnt[lane * 4 + i];
+            }
+            int inc = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, VER_WAVE);
+                if (lane >= o) inc += t;
+            }
+            const int base = inc - run;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rstart[lane * 4 + i] = base + loc[i];
+                rcur[lane * 4 + i] = base + loc[i];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nsub * P * 4; e += kValThreads)
+            if (ev_coef[e] != 0.0f) sorted[atomicAdd(&rcur[ev_key[e]], 1)] = (unsigned short)e;
+        __syncthreads();
+        // every lane group accumulates its tile rows from the LDS-resident grad rows
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int r = gidx + 64 * j;
+            if (r < Nk) {
+                const int i0 = rstart[r], i1 = i0 + rcnt[r];
+                for (int i = i0; i < i1; ++i) {
+                    const int e = sorted[i];
+                    const float coef = ev_coef[e];
+                    float g[CPL];
+                    load_ch<HD, 16, float>(G + (e / (P * 4)) * HD, lr, g);
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) acc[j][k] += coef * g[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const size_t rstride = (size_t)heads * HD;
+    float* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = gidx + 64 * j;
+        if (r < Nk) {
+            if (!atomic_flush) store_ch<HD, 16>(gv + (size_t)r * rstride, lr, acc[j]);
+            else atomic_add_ch<HD, 16>(gv + (size_t)r * rstride, lr, 1.0f, acc[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 namespace {
 
 constexpr int kFwdChunk = 2048;
@@ -832,8 +1136,6 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
     const size_t lds = (size_t)map_h * map_w * head_dim * (sizeof(float) + esz);
-    VER_REQUIRE(lds <= kMaxLds, VER_EUNSUPPORTED,
-                "ver_sca_backward: %dx%dx%d tiles (%zu B) exceed LDS", map_h, map_w, head_dim, lds);
     const int nchunks = (Nq + kBwdChunk - 1) / kBwdChunk;
     hipStream_t st = (hipStream_t)stream;
     const size_t nsmall = (size_t)B * Nq * heads * points;
@@ -844,6 +1146,50 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_backward: memset: %s", hipGetErrorString(e));
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
+        if constexpr (G == 16) {
+            if (map_h * map_w <= kValMaxRows) {
+                // ---- d(offsets), d(logits): forward-shaped kernel
+                const size_t tile_bytes = (size_t)map_h * map_w * head_dim * esz;
+                const int nbuf = 2 * tile_bytes <= kMaxLds ? 2 : 1;
+                const size_t lds_off = tile_bytes * nbuf;
+                const int nch = (Nq + kFwdChunk - 1) / kFwdChunk;
+                int hsplit = 1;
+                while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nch < 768) hsplit *= 2;
+                auto launch_off = [&](auto kern, auto vptr) {
+                    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_off);
+                    if (e2 != hipSuccess)
+                        return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
+                    hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * hsplit * nch), dim3(kFwdThreads), lds_off, st, vptr,
+                                       offsets, logits, uv, vis, vis_list, vis_cnt, grad_slots, grad_offsets,
+                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, nch, kFwdChunk, hsplit, nbuf);
+                    return ver_check_launch("ver_sca_backward/k_sca_bwd_off");
+                };
+                int r2;
+                if (value_dtype == VER_BF16) {
+                    if constexpr (HD % 8 == 0) r2 = launch_off(k_sca_bwd_off<HD, P, uint16_t>, (const uint16_t*)value);
+                    else r2 = ver_fail(VER_EUNSUPPORTED, "bf16 value needs head_dim %% 8 == 0");
+                } else {
+                    r2 = launch_off(k_sca_bwd_off<HD, P, float>, (const float*)value);
+                }
+                if (r2) return r2;
+                // ---- d(value): event sort, no value tile
+                const size_t lds_val = (size_t)kValSub * HD * 4 + (size_t)kValSub * P * 4 * (4 + 2 + 2) +
+                                       3 * kValMaxRows * sizeof(int);
+                auto kv = k_sca_bwd_val<HD, P>;
+                hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(kv),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_val);
+                if (e3 != hipSuccess)
+                    return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e3));
+                hipLaunchKernelGGL(kv, dim3((unsigned)B * Ncam * heads * nchunks), dim3(kValThreads), lds_val, st, offsets,
+                                   logits, uv, vis, vis_list, vis_cnt, grad_slots, grad_value, Ncam, Nq, D, heads,
+                                   map_h, map_w, nchunks, kBwdChunk);
+                return ver_check_launch("ver_sca_backward/k_sca_bwd_val");
+            }
+        }
+        // narrow heads / large maps: single-kernel LDS-atomic path
+        VER_REQUIRE(lds <= kMaxLds, VER_EUNSUPPORTED, "ver_sca_backward: %dx%dx%d tiles (%zu B) exceed LDS", map_h,
+                    map_w, head_dim, lds);
         auto launch = [&](auto kern, auto vptr) {
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -104,3 +104,24 @@ def test_lift_equals_default_branch():
         outs = head(mlvl, _metas(w2p, org, [0]))
     assert torch.equal(emb[0], outs['bev_embed'][:, 0])
     assert torch.equal(occ, outs['occupancy_preds'])
+
+
+def test_vocc_head_bf16_autocast_within_1e2():
+    """BASELINE.json north_star: 1e-2 in bf16.  The bench's arithmetic (bf16 autocast GEMMs and
+    lattices, bf16 value tile, fp32 gather / LayerNorm statistics / loss) against the reference's
+    fp32 vectors: occupancy logits within 1e-2 relative L2 and 3e-2 absolute on |logit| ~ 5."""
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    head = _head(cases.vocc_head_cfg(), 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        emb, occ = head.lift(T(feats[0]).to(DEV).unsqueeze(1), _metas(w2p, org, [0]))
+    occ = occ.float()
+    want = T(g['c3_b0_occ'])
+    got = occ[0, ::997].cpu()
+    assert rel_l2(got, want) < 1e-2
+    assert maxdiff(got, want) < 1e-1
+    assert float((got - want).abs().mean()) < 2e-2
+    assert abs(float(occ.double().norm()) - float(g['c3_b0_occ_norm'])) < 1e-2 * float(g['c3_b0_occ_norm'])
+    assert rel_l2(emb[0, ::7].float().cpu(), T(g['c3_b0_bev'])) < 1e-2

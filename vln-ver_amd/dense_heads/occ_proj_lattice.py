@@ -1,0 +1,158 @@
+"""``occ_proj`` on the even lattice.
+
+After the coarse-to-fine upsample the reference re-interprets the dense volume
+``Y [bs, C, Z, 8H, 8W]`` (contiguous) as ``[bs, Z, 8H, 8W, C]`` *without* permuting
+(dense_heads/voxelformer_occupancy_head.py:564), permutes/flattens it to rows of ``Z*C``
+features (:570) and applies ``occ_proj = Linear(Z*C, 35*128)`` (:571).  Three quarters of ``Y``
+are the last ConvTranspose3d's bias (odd rows / columns), so every 3072-wide
+input row is ~3/4 constants whose positions depend only on the row's position:
+
+    out[row] = bias + sum_{data cols j} W[:, j] * E[perm(row, j)]          (gathered GEMM, K/4)
+                    + sum_k  b_up[chan(row, k)] * (sum_{non-data cols of token k} W[:, j])
+
+Rows are grouped by their data-column pattern (5 patterns at the vocc.py sizes: the pattern
+depends on ``b % 5`` only); per group one GEMM ``[rows, ~768] x [~768, 4480]`` replaces the
+``[rows, 3072] x [3072, 4480]`` slice of the dense product: 99 instead of 396 GFLOP per viewpoint,
+and the 4x larger dense volume is never materialised.  Pure index bookkeeping + torch GEMMs
+(autograd-differentiable); the index tables are built once per geometry by brute force from the
+definition of the two raw views, so they are correct by construction for any (C, Z, H, W).
+"""
+import numpy as np
+import torch
+
+_PLAN_CACHE = {}
+
+
+class _Plan:
+    pass
+
+
+def _build_plan(C, Z, Hf, Wf):
+    """Index tables for a dense volume [C, Z, Hf, Wf] whose data sits on even (y, x)."""
+    assert Hf % 2 == 0 and Wf % 2 == 0
+    Hl, Wl = Hf // 2, Wf // 2
+    rows = Hf * Wf                                   # (a, b) positions of the reinterpreted tensor
+    feat = Z * C
+    k = np.arange(Z, dtype=np.int32)[None, :, None]
+    ab = np.arange(rows, dtype=np.int32)[:, None, None]
+    cp = np.arange(C, dtype=np.int32)[None, None, :]
+    f = (k * rows + ab) * C + cp                     # flat index into Y for feature (k, c') of row (a,b)
+    c, rem = np.divmod(f, Z * Hf * Wf)
+    z, rem = np.divmod(rem, Hf * Wf)
+    y, x = np.divmod(rem, Wf)
+    data = (y % 2 == 0) & (x % 2 == 0)               # [rows, Z, C]
+    lat = ((c * Z + z) * Hl + y // 2) * Wl + x // 2  # flat index into the lattice [C, Z, Hl, Wl]
+    data2 = data.reshape(rows, feat)
+    lat2 = lat.reshape(rows, feat)
+    # channel of each (row, token): constant within a token iff tokens do not straddle channels
+    cmin, cmax = c.min(axis=2), c.max(axis=2)
+    if not np.array_equal(cmin, cmax):
+        return None                                   # geometry without whole tokens per channel
+    chan = cmin                                       # [rows, Z]
+    # group rows by data pattern
+    packed = np.packbits(data2, axis=1)
+    _, first, inverse = np.unique(packed, axis=0, return_index=True, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    plan = _Plan()
+    plan.groups = []
+    plan.rows, plan.feat, plan.lattice_size = rows, feat, C * Z * Hl * Wl
+    order = []
+    for gi, r0 in enumerate(first):
+        members = np.nonzero(inverse == gi)[0]
+        cols = np.nonzero(data2[r0])[0]
+        ncols = np.nonzero(~data2[r0])[0]
+        g = _Plan()
+        g.rows = members
+        g.cols = cols
+        g.gather = lat2[np.ix_(members, cols)]        # [n_rows, n_cols] lattice indices
+        # per token k: which non-data columns belong to it (for the constant term)
+        g.ncols_by_token = [ncols[(ncols // C) == kk] for kk in range(Z)]
+        g.chan = chan[members]                        # [n_rows, Z]
+        plan.groups.append(g)
+        order.append(members)
+    plan.order = np.concatenate(order)                # row permutation: grouped -> original
+    inv = np.empty_like(plan.order)
+    inv[plan.order] = np.arange(rows)
+    plan.inverse_order = inv
+    return plan
+
+
+class _PermuteGather(torch.autograd.Function):
+    """y = x[:, perm] for a PERMUTATION ``perm`` of x's columns: the backward is the gather with the
+    inverse permutation (deterministic, no atomic index_add)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return x.index_select(1, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv_perm, = ctx.saved_tensors
+        return g.index_select(1, inv_perm), None, None
+
+
+def get_plan(C, Z, Hf, Wf, device):
+    key = (C, Z, Hf, Wf, str(device))
+    if key not in _PLAN_CACHE:
+        host_key = (C, Z, Hf, Wf, 'host')
+        if host_key not in _PLAN_CACHE:
+            _PLAN_CACHE[host_key] = _build_plan(C, Z, Hf, Wf)
+        plan = _PLAN_CACHE[host_key]
+        if plan is None:
+            _PLAN_CACHE[key] = None
+        else:
+            dev = _Plan()
+            dev.rows, dev.feat, dev.lattice_size = plan.rows, plan.feat, plan.lattice_size
+            dev.groups = []
+            for g in plan.groups:
+                d = _Plan()
+                d.n_rows, d.n_cols = g.gather.shape
+                d.gather = torch.from_numpy(g.gather.reshape(-1).astype(np.int64)).to(device)
+                d.cols = torch.from_numpy(g.cols.astype(np.int64)).to(device)
+                d.ncols_by_token = [torch.from_numpy(n.astype(np.int64)).to(device) for n in g.ncols_by_token]
+                d.chan = torch.from_numpy(g.chan.astype(np.int64)).to(device)
+                dev.groups.append(d)
+            dev.inverse_order = torch.from_numpy(plan.inverse_order.astype(np.int64)).to(device)
+            perm = np.concatenate([g.gather.reshape(-1) for g in plan.groups]).astype(np.int64)
+            dev.is_permutation = perm.size == plan.lattice_size and np.array_equal(np.sort(perm), np.arange(perm.size))
+            if dev.is_permutation:
+                inv = np.empty_like(perm)
+                inv[perm] = np.arange(perm.size)
+                dev.perm = torch.from_numpy(perm).to(device)
+                dev.inv_perm = torch.from_numpy(inv).to(device)
+            _PLAN_CACHE[key] = dev
+    return _PLAN_CACHE[key]
+
+
+def occ_proj_from_lattice(e, up_bias, weight, bias):
+    """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C]; up_bias: bias of
+    the last ConvTranspose3d [C]; weight [out, Z*C], bias [out] of ``occ_proj``.
+    Returns ``(out_grouped [bs, Hf*Wf, out], inverse_order)`` with
+    ``out_grouped.index_select(1, inverse_order).view(bs, Hf, Wf, out)`` equal to what
+    ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` returns -- or None when the
+    geometry has no whole-token structure (the caller then takes the dense path)."""
+    bs, Z, Hl, Wl, C = e.shape
+    plan = get_plan(C, Z, 2 * Hl, 2 * Wl, e.device)
+    if plan is None:
+        return None
+    dt = e.dtype
+    lat = e.permute(0, 4, 1, 2, 3).reshape(bs, -1)                    # channel-first lattice, flat
+    w = weight.to(dt)
+    outs = []
+    a_all = _PermuteGather.apply(lat, plan.perm, plan.inv_perm) if plan.is_permutation else None
+    off = 0
+    for g in plan.groups:
+        if a_all is not None:
+            a = a_all[:, off:off + g.n_rows * g.n_cols].reshape(bs * g.n_rows, g.n_cols)
+            off += g.n_rows * g.n_cols
+        else:
+            a = lat.index_select(1, g.gather).view(bs * g.n_rows, g.n_cols)
+        wsel = w.index_select(1, g.cols)                              # [out, n_cols]
+        # constant part: sum_k b_up[chan[row,k]] * sum_{non-data cols of token k} W[:, col]
+        s = torch.stack([weight.index_select(1, n).sum(1) for n in g.ncols_by_token])     # [Z, out] fp32
+        const = torch.addmm(bias, up_bias[g.chan], s).to(dt)          # [n_rows, out]
+        o = (a @ wsel.t()).view(bs, g.n_rows, -1) + const[None]
+        outs.append(o)
+    # rows are in group order; ``inverse_order`` maps them back to (a, b) = a*Wf + b
+    return torch.cat(outs, dim=1), plan.inverse_order

@@ -26,6 +26,7 @@ from . import coders, losses  # noqa: F401  (registers NMSFreeCoder / FocalLoss 
 from .assigner import SamplingResult, build_assigner
 from .coders import normalize_bbox
 from ..ddp import reduce_mean
+from .occ_proj_lattice import occ_proj_from_lattice
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
 
@@ -196,6 +197,17 @@ class VoxelFormerOccupancyHead(BaseModule):
         voxel_embed = voxel_embed.contiguous()
         if self.refine_occ:
             x = voxel_embed.view(bs, c, self.bev_z, self.bev_h, self.bev_w)          # raw view :558
+            convs = list(self.up_sample)
+            if (self.bev_z != self.occ_zdim and len(convs) == 3 and all(is_reference_geometry(m) for m in convs)
+                    and 8 * self.bev_h == self.occ_xdim and 8 * self.bev_w == self.occ_ydim):
+                # lattice path: neither the dense volume nor its 3/4 constant columns are formed
+                e, b_up = upsample_lattice(x, [m.weight for m in convs], [m.bias for m in convs])
+                res = occ_proj_from_lattice(e, convs[-1].bias, self.occ_proj.weight, self.occ_proj.bias)
+                if res is not None:
+                    grouped, inv = res
+                    occ = grouped.view(bs, grouped.shape[1], self.occ_zdim, self.occ_dims).permute(0, 2, 1, 3)
+                    occ = occ.index_select(2, inv).reshape(bs, -1, self.occ_dims)    # [bs, Z*X*Y, dims] :572-579
+                    return self._occ_mlp(occ)
             x = self._upsample(x).contiguous()
             x = x.view(bs, self.bev_z, self.occ_xdim, self.occ_ydim, c)              # raw view :564
             ox, oy = self.occ_xdim, self.occ_ydim

@@ -141,7 +141,7 @@ def measured_traffic_per_viewpoint(kernel):
     vals = {}
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith('#')):
         if len(row) == 4 and kernel in row[0] and row[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
-            vals[row[1]] = float(row[2])
+            vals[row[1]] = vals.get(row[1], 0.0) + float(row[2])      # backward = two kernels
     if len(vals) != 2:
         return None, None
     return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0 / 64.0, os.path.basename(files[-1])

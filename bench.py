@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='viewpoints per GPU per step')
-    ap.add_argument('--micro', type=int, default=8, help='viewpoints per head micro-batch')
+    ap.add_argument('--micro', type=int, default=32, help='viewpoints per head micro-batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd', 'vocc_full_train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 5
+#define VER_ABI_VERSION 6
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -196,6 +196,23 @@ int ver_ln_relu_forward(const void* x, const float* gamma, const float* beta, vo
 int ver_ln_relu_backward(const void* x, const void* grad_y, const float* gamma, const float* beta,
                          const float* mean, const float* rstd, void* grad_x,
                          float* grad_gamma, float* grad_beta, long N, int W, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sigmoid focal loss of the occupancy term (dense_heads/voxelformer_occupancy_head.py:977-989 ->
+ * mmdet 2.14 `FocalLoss(use_sigmoid=True)` / py_sigmoid_focal_loss, configured at
+ * projects/configs/verformer/vocc.py:190-195), weight=None:
+ *   logits f32|bf16 [N, C] (C % 8 == 0), target int64 [N] in [0, C] (C = background)
+ *   forward : partial[b] = sum of the elementwise loss over the elements workgroup b visited,
+ *             b < ver_focal_loss_blocks(N, C); the caller adds the partials (and applies
+ *             loss_weight / avg_factor)
+ *   backward: grad[n,c] = scale[0] * d loss[n,c] / d logits[n,c]   (scale: device scalar; grad in
+ *             the logits' dtype)
+ */
+int ver_focal_loss_blocks(long N, int C);
+int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,
+                           float gamma, float alpha, int dtype, void* stream);
+int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
+                            long N, int C, float gamma, float alpha, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -403,6 +403,74 @@ def test_layer_norm_relu_fused(dtype):
     assert hip.layer_norm_relu(torch.zeros(0, 128, device=DEV), gd, bd).shape == (0, 128)
 
 
+def test_row_linear_split_k_gradients():
+    """row_linear (batched split-K weight/bias gradient) vs F.linear in fp64."""
+    rl = pkg('dense_heads.row_linear')
+    gen = torch.Generator(device='cpu').manual_seed(9)
+    n = 3 * rl._CHUNK + 517                        # three full chunks + a tail
+    x = torch.randn(n, 128, generator=gen)
+    w = torch.randn(16, 128, generator=gen) * 0.1
+    b = torch.randn(16, generator=gen)
+    gy = torch.randn(n, 16, generator=gen)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = rl.row_linear(xd, wd, bd)
+    y.backward(gy.to(DEV))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(gy.double())
+    assert close(y.detach().cpu(), yr.detach(), atol=1e-4, rtol=1e-4)
+    assert close(xd.grad.cpu(), xr.grad, atol=1e-4, rtol=1e-4)
+    assert close(wd.grad.cpu(), wr.grad, atol=2e-3, rtol=1e-4)
+    assert close(bd.grad.cpu(), br.grad, atol=2e-3, rtol=1e-4)
+    # bf16 rows (autocast): gradients within bf16 rounding of the fp64 ones
+    xd2, wd2, bd2 = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y2 = rl.row_linear(xd2, wd2, bd2)
+    assert y2.dtype == torch.bfloat16
+    y2.backward(gy.to(DEV).bfloat16())
+    assert pkg('hipops') is not None and torch.isfinite(wd2.grad).all()
+    rel = (wd2.grad.cpu().double() - wr.grad).norm() / wr.grad.norm()
+    assert rel < 1e-2, rel
+    assert (bd2.grad.cpu().double() - br.grad).norm() / br.grad.norm() < 1e-2
+
+
+# ------------------------------------------------------------------------------- next row 2: occupancy loss
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('gamma,alpha', [(2.0, 0.25), (1.5, 0.4)])
+def test_focal_loss_fused(dtype, gamma, alpha):
+    """ver_focal_loss_* vs the oracle's restatement of mmdet's sigmoid focal loss (head:977-989),
+    evaluated in fp64 on the same (dtype-rounded) logits."""
+    hip = pkg('hipops')
+    orc = oracle()
+    gen = torch.Generator(device='cpu').manual_seed(10)
+    n, c = 70001, 16
+    logits = (torch.randn(n, c, generator=gen) * 4).to(dtype)
+    logits[0, :4] = torch.tensor([60.0, -60.0, 0.0, 20.0]).to(dtype)      # saturated sigmoid both ways
+    target = torch.randint(0, c + 1, (n,), generator=gen)
+    target[0] = 0
+    avg = float((target < c).sum())
+    ld = logits.to(DEV).requires_grad_(True)
+    s = hip.sigmoid_focal_loss_sum(ld, target.to(DEV), gamma, alpha)
+    (s / avg * 0.7).backward()
+    lr = logits.double().requires_grad_(True)
+    ref = orc.focal_loss(lr, target, gamma=gamma, alpha=alpha, avg_factor=avg, loss_weight=0.7)
+    ref.backward()
+    assert abs(float(s) / avg * 0.7 - float(ref)) <= 1e-5 * abs(float(ref))
+    assert ld.grad.dtype == dtype
+    if dtype == torch.float32:
+        assert close(ld.grad.cpu(), lr.grad, atol=1e-9, rtol=1e-4)
+    else:
+        assert close(ld.grad.float().cpu(), lr.grad, atol=1e-9, rtol=1e-2)
+    # the registered loss routes large GPU inputs through the kernel and gives the same value
+    loss_mod = pkg('dense_heads.losses').FocalLoss(gamma=gamma, alpha=alpha, loss_weight=0.7)
+    got = loss_mod(logits.to(DEV), target.to(DEV), avg_factor=avg)
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    # empty input
+    z = hip.sigmoid_focal_loss_sum(torch.zeros(0, 16, device=DEV, dtype=dtype),
+                                   torch.zeros(0, dtype=torch.long, device=DEV))
+    assert float(z) == 0.0
+
+
 # ------------------------------------------------------------------------------- next row 1: decoder op
 @pytest.mark.parametrize('name', list(cases.MSDA3D_CASES))
 def test_voxel_msda_forward_backward(name):

@@ -1,0 +1,180 @@
+// Sigmoid focal loss over [N, C] logits with integer targets, forward (sum) and backward
+// (include/ver_ops.h: ver_focal_loss_forward / ver_focal_loss_backward).
+//
+// The occupancy term of the reference's loss (dense_heads/voxelformer_occupancy_head.py:977-989,
+// `loss_occupancy = FocalLoss(use_sigmoid, gamma=2, alpha=0.25)` of vocc.py:190-195 -> mmdet's
+// py_sigmoid_focal_loss) runs over 504 000 x 16 logits per viewpoint.  As separate elementwise ops
+// that is ~15 HBM passes over an fp32 [N,16] tensor each way; here one read-only pass for the sum
+// and one read+write pass for the gradient, straight from the bf16 (or fp32) logits.
+//
+//   t = one_hot(target)[:, :C] (target == C -> background, all zero)      p = sigmoid(x)
+//   loss = (alpha t + (1-alpha)(1-t)) * (t ? 1-p : p)^gamma * bce_with_logits(x, t)
+//   t=1: d/dx = alpha (1-p)^g [ g p log p - (1-p) ]       t=0: d/dx = (1-alpha) p^g [ p - g (1-p) log(1-p) ]
+//
+// One thread owns 8 consecutive classes of a row (C % 8 == 0): one 16-byte (bf16) or two 16-byte
+// (fp32) loads.  The sum is reduced per workgroup into `partial[blockIdx]` (the caller adds the
+// <= 4096 partials: deterministic, no float atomics).
+#include "ver_common.h"
+
+namespace {
+struct Term {
+    float loss, grad;
+};
+
+template <bool G2>
+__device__ __forceinline__ Term focal_term(float x, bool pos, float gamma, float alpha) {
+    // log p = -softplus(-x), log(1-p) = -softplus(x); softplus(z) = max(z,0) + log1p(exp(-|z|))
+    const float e = __expf(-fabsf(x));
+    const float l1p = log1pf(e);
+    const float sp_pos = fmaxf(x, 0.0f) + l1p;    // softplus(x)  = -log(1-p)
+    const float sp_neg = fmaxf(-x, 0.0f) + l1p;   // softplus(-x) = -log(p)
+    const float inv = 1.0f / (1.0f + e);
+    const float p = x >= 0.0f ? inv : e * inv;
+    const float q = 1.0f - p;
+    Term t;
+    if (pos) {
+        const float m = G2 ? q * q : powf(q, gamma);
+        t.loss = alpha * m * sp_neg;
+        t.grad = alpha * m * (-gamma * p * sp_neg - q);
+    } else {
+        const float m = G2 ? p * p : powf(p, gamma);
+        t.loss = (1.0f - alpha) * m * sp_pos;
+        t.grad = (1.0f - alpha) * m * (p + gamma * q * sp_pos);
+    }
+    return t;
+}
+
+template <bool BF16>
+__device__ __forceinline__ void load_x8(const void* base, long v, float (&x)[8]) {
+    if (BF16) {
+        const uint4 t = reinterpret_cast<const uint4*>(base)[v];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[2 * j] = __uint_as_float(w[j] << 16);
+            x[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+    } else {
+        const float4 a = reinterpret_cast<const float4*>(base)[2 * v];
+        const float4 b = reinterpret_cast<const float4*>(base)[2 * v + 1];
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+        x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    }
+}
+
+__device__ __forceinline__ uint32_t to_bf16(float f) {   // round to nearest even
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+}  // namespace
+
+template <bool BF16, bool G2>
+__global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logits, const int64_t* __restrict__ target,
+                                                   float* __restrict__ partial, long nvec, int vec_per_row,
+                                                   float gamma, float alpha) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const long row = v / vec_per_row;
+        const int c0 = (int)(v - row * vec_per_row) * 8;
+        const int tgt = (int)target[row];
+        float x[8];
+        load_x8<BF16>(logits, v, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += focal_term<G2>(x[j], tgt == c0 + j, gamma, alpha).loss;
+    }
+    acc = group_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <bool BF16, bool G2>
+__global__ __launch_bounds__(256) void k_focal_bwd(const void* __restrict__ logits, const int64_t* __restrict__ target,
+                                                   const float* __restrict__ scale, void* __restrict__ grad, long nvec,
+                                                   int vec_per_row, float gamma, float alpha) {
+    const float s = scale[0];
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        const long row = v / vec_per_row;
+        const int c0 = (int)(v - row * vec_per_row) * 8;
+        const int tgt = (int)target[row];
+        float x[8], g[8];
+        load_x8<BF16>(logits, v, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = s * focal_term<G2>(x[j], tgt == c0 + j, gamma, alpha).grad;
+        if (BF16) {
+            uint4 t;
+            t.x = to_bf16(g[0]) | (to_bf16(g[1]) << 16);
+            t.y = to_bf16(g[2]) | (to_bf16(g[3]) << 16);
+            t.z = to_bf16(g[4]) | (to_bf16(g[5]) << 16);
+            t.w = to_bf16(g[6]) | (to_bf16(g[7]) << 16);
+            reinterpret_cast<uint4*>(grad)[v] = t;
+        } else {
+            reinterpret_cast<float4*>(grad)[2 * v] = make_float4(g[0], g[1], g[2], g[3]);
+            reinterpret_cast<float4*>(grad)[2 * v + 1] = make_float4(g[4], g[5], g[6], g[7]);
+        }
+    }
+}
+
+namespace {
+int check_focal(const char* who, const void* logits, const int64_t* target, long N, int C, int dtype) {
+    VER_REQUIRE(N >= 0 && C > 0, VER_EINVAL, "%s: bad shape N=%ld C=%d", who, N, C);
+    VER_REQUIRE(C % 8 == 0, VER_EUNSUPPORTED, "%s: class count %d is not a multiple of 8", who, C);
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "%s: dtype %d", who, dtype);
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(logits && target, VER_EINVAL, "%s: null pointer argument", who);
+    VER_REQUIRE(((uintptr_t)logits & 15) == 0, VER_EINVAL, "%s: logits must be 16-byte aligned", who);
+    return VER_OK;
+}
+}  // namespace
+
+extern "C" int ver_focal_loss_blocks(long N, int C) {
+    const long nvec = N * (long)(C / 8);
+    const long want = (nvec + 255) / 256;
+    return (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+}
+
+extern "C" int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,
+                                      float gamma, float alpha, int dtype, void* stream) {
+    int rc = check_focal("ver_focal_loss_forward", logits, target, N, C, dtype);
+    if (rc) return rc;
+    VER_REQUIRE(partial, VER_EINVAL, "ver_focal_loss_forward: null partial-sum buffer");
+    const int blocks = ver_focal_loss_blocks(N, C);
+    const long nvec = N * (long)(C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const bool g2 = gamma == 2.0f;
+#define VER_FOCAL_FWD(BF, G2)                                                                                   \
+    hipLaunchKernelGGL((k_focal_fwd<BF, G2>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, C / 8, \
+                       gamma, alpha)
+    if (dtype == VER_BF16) {
+        if (g2) VER_FOCAL_FWD(true, true); else VER_FOCAL_FWD(true, false);
+    } else {
+        if (g2) VER_FOCAL_FWD(false, true); else VER_FOCAL_FWD(false, false);
+    }
+#undef VER_FOCAL_FWD
+    return ver_check_launch("ver_focal_loss_forward");
+}
+
+extern "C" int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
+                                       long N, int C, float gamma, float alpha, int dtype, void* stream) {
+    int rc = check_focal("ver_focal_loss_backward", logits, target, N, C, dtype);
+    if (rc) return rc;
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(scale && grad, VER_EINVAL, "ver_focal_loss_backward: null pointer argument");
+    VER_REQUIRE(((uintptr_t)grad & 15) == 0, VER_EINVAL, "ver_focal_loss_backward: grad must be 16-byte aligned");
+    const int blocks = ver_focal_loss_blocks(N, C);
+    const long nvec = N * (long)(C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const bool g2 = gamma == 2.0f;
+#define VER_FOCAL_BWD(BF, G2)                                                                                       \
+    hipLaunchKernelGGL((k_focal_bwd<BF, G2>), dim3(blocks), dim3(256), 0, st, logits, target, scale, grad, nvec, C / 8, \
+                       gamma, alpha)
+    if (dtype == VER_BF16) {
+        if (g2) VER_FOCAL_BWD(true, true); else VER_FOCAL_BWD(true, false);
+    } else {
+        if (g2) VER_FOCAL_BWD(false, true); else VER_FOCAL_BWD(false, false);
+    }
+#undef VER_FOCAL_BWD
+    return ver_check_launch("ver_focal_loss_backward");
+}

@@ -1,7 +1,7 @@
 """Losses named by vocc.py:182-195 ("next" row 2 of SURVEY.md 8f), restated from the published
 behaviour of mmdet 2.14.0 (mmdet is not vendored by the reference).
-Elementwise torch for now; the [504000,16] occupancy focal loss is the candidate for a fused
-HBM-bound HIP kernel."""
+The [N,16] occupancy focal loss (N = 504 000 x viewpoints) runs on the fused HIP kernels
+(``ver_focal_loss_*``) when it is on the GPU; small / weighted cases are elementwise torch ops."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -49,6 +49,11 @@ class FocalLoss(nn.Module):
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         reduction = reduction_override if reduction_override else self.reduction
+        if (pred.is_cuda and weight is None and reduction == 'mean' and avg_factor is not None
+                and pred.dim() == 2 and pred.size(1) % 8 == 0 and pred.size(0) >= 4096
+                and pred.dtype in (torch.float32, torch.bfloat16)):
+            from ..hipops import sigmoid_focal_loss_sum
+            return self.loss_weight * (sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha) / avg_factor)
         return self.loss_weight * sigmoid_focal_loss(pred, target, weight, self.gamma, self.alpha,
                                                      reduction, avg_factor)
 

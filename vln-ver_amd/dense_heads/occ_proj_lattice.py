@@ -92,6 +92,24 @@ class _PermuteGather(torch.autograd.Function):
         return g.index_select(1, inv_perm), None, None
 
 
+class _PermuteRows(torch.autograd.Function):
+    """y = x.index_select(2, perm) for a permutation; backward = index_select with its inverse."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return x.index_select(2, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv_perm, = ctx.saved_tensors
+        return g.index_select(2, inv_perm), None, None
+
+
+def permute_rows(x, perm, inv_perm):
+    return _PermuteRows.apply(x, perm, inv_perm)
+
+
 def get_plan(C, Z, Hf, Wf, device):
     key = (C, Z, Hf, Wf, str(device))
     if key not in _PLAN_CACHE:
@@ -114,6 +132,7 @@ def get_plan(C, Z, Hf, Wf, device):
                 d.chan = torch.from_numpy(g.chan.astype(np.int64)).to(device)
                 dev.groups.append(d)
             dev.inverse_order = torch.from_numpy(plan.inverse_order.astype(np.int64)).to(device)
+            dev.order = torch.from_numpy(plan.order.astype(np.int64)).to(device)
             perm = np.concatenate([g.gather.reshape(-1) for g in plan.groups]).astype(np.int64)
             dev.is_permutation = perm.size == plan.lattice_size and np.array_equal(np.sort(perm), np.arange(perm.size))
             if dev.is_permutation:
@@ -128,7 +147,7 @@ def get_plan(C, Z, Hf, Wf, device):
 def occ_proj_from_lattice(e, up_bias, weight, bias):
     """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C]; up_bias: bias of
     the last ConvTranspose3d [C]; weight [out, Z*C], bias [out] of ``occ_proj``.
-    Returns ``(out_grouped [bs, Hf*Wf, out], inverse_order)`` with
+    Returns ``(out_grouped [bs, Hf*Wf, out], inverse_order, order)`` with
     ``out_grouped.index_select(1, inverse_order).view(bs, Hf, Wf, out)`` equal to what
     ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` returns -- or None when the
     geometry has no whole-token structure (the caller then takes the dense path)."""
@@ -155,4 +174,4 @@ def occ_proj_from_lattice(e, up_bias, weight, bias):
         o = (a @ wsel.t()).view(bs, g.n_rows, -1) + const[None]
         outs.append(o)
     # rows are in group order; ``inverse_order`` maps them back to (a, b) = a*Wf + b
-    return torch.cat(outs, dim=1), plan.inverse_order
+    return torch.cat(outs, dim=1), plan.inverse_order, plan.order

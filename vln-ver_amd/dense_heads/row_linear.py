@@ -1,0 +1,60 @@
+"""Linear layers over millions of rows (``occ_branches``, head:241-248: 504 000 voxels x bs rows
+of width 128).
+
+Forward and d(input) are ordinary GEMMs.  d(weight) = G^T X is a [out x rows] x [rows x in]
+product with out, in <= 128 and rows = 4e6..16e6: a GEMM library sees ONE or two output tiles
+and runs it on one or two CUs (measured 4.7 ms per layer for 8 viewpoints = 14 % of the step).
+``row_linear`` splits the row dimension into chunks, runs them as one batched GEMM (thousands of
+workgroups) and adds the fp32 partials; the bias gradient is the same batched product with a
+row of ones.  Used on CUDA tensors only; CPU tensors take ``F.linear``.
+"""
+import torch
+import torch.nn.functional as F
+
+_CHUNK = 8000            # 504000 = 63 * 8000
+
+
+class _RowLinear(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = weight.to(x.dtype)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        if bias is None:
+            return x @ w.t()
+        return torch.addmm(bias.to(x.dtype), x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        n, o = g.shape
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        s = n // _CHUNK
+        main = s * _CHUNK
+        gw = x.new_zeros((o, x.shape[1]), dtype=torch.float32)
+        gb = x.new_zeros((o,), dtype=torch.float32) if ctx.has_bias else None
+        if s:
+            g3 = g[:main].view(s, _CHUNK, o)
+            gw += torch.bmm(g3.transpose(1, 2), x[:main].view(s, _CHUNK, -1)).sum(0, dtype=torch.float32)
+            if ctx.has_bias:
+                ones = g.new_ones((1, 1, _CHUNK)).expand(s, 1, _CHUNK)
+                gb += torch.bmm(ones, g3).sum((0, 1), dtype=torch.float32)
+        if main < n:
+            gw += (g[main:].t() @ x[main:]).float()
+            if ctx.has_bias:
+                gb += g[main:].sum(0, dtype=torch.float32)
+        return gx, gw, gb
+
+
+def row_linear(x, weight, bias):
+    """``F.linear`` for x [..., in] with a split-K weight gradient (see module docstring)."""
+    if not x.is_cuda:
+        return F.linear(x, weight, bias)
+    if torch.is_autocast_enabled('cuda'):
+        x = x.to(torch.get_autocast_dtype('cuda'))
+    shape = x.shape
+    with torch.autocast('cuda', enabled=False):
+        y = _RowLinear.apply(x.reshape(-1, shape[-1]), weight, bias)
+    return y.view(*shape[:-1], -1)

@@ -26,7 +26,8 @@ from . import coders, losses  # noqa: F401  (registers NMSFreeCoder / FocalLoss 
 from .assigner import SamplingResult, build_assigner
 from .coders import normalize_bbox
 from ..ddp import reduce_mean
-from .occ_proj_lattice import occ_proj_from_lattice
+from .occ_proj_lattice import occ_proj_from_lattice, permute_rows
+from .row_linear import row_linear
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
 
@@ -204,10 +205,13 @@ class VoxelFormerOccupancyHead(BaseModule):
                 e, b_up = upsample_lattice(x, [m.weight for m in convs], [m.bias for m in convs])
                 res = occ_proj_from_lattice(e, convs[-1].bias, self.occ_proj.weight, self.occ_proj.bias)
                 if res is not None:
-                    grouped, inv = res
-                    occ = grouped.view(bs, grouped.shape[1], self.occ_zdim, self.occ_dims).permute(0, 2, 1, 3)
-                    occ = occ.index_select(2, inv).reshape(bs, -1, self.occ_dims)    # [bs, Z*X*Y, dims] :572-579
-                    return self._occ_mlp(occ)
+                    # ``occ_branches`` is row-wise: run it on the rows as the GEMMs left them
+                    # ([bs, (a,b) grouped, Z, dims]) and bring only the 8x narrower logits into the
+                    # reference's (Z, X, Y) voxel order (:572-579)
+                    grouped, inv, order = res
+                    logits = self._occ_mlp(grouped.view(bs, grouped.shape[1], self.occ_zdim, self.occ_dims))
+                    logits = permute_rows(logits.permute(0, 2, 1, 3), inv, order)
+                    return logits.reshape(bs, -1, logits.shape[-1])
             x = self._upsample(x).contiguous()
             x = x.view(bs, self.bev_z, self.occ_xdim, self.occ_ydim, c)              # raw view :564
             ox, oy = self.occ_xdim, self.occ_ydim
@@ -225,7 +229,8 @@ class VoxelFormerOccupancyHead(BaseModule):
 
     def _occ_mlp(self, x):
         """``occ_branches`` (head:241-248).  On the GPU each LayerNorm(128)+ReLU pair is one fused
-        HIP pass (``ver_ln_relu_*``); Linear layers stay hipBLASLt GEMMs."""
+        HIP pass (``ver_ln_relu_*``); Linear layers are hipBLASLt GEMMs with a split-K weight
+        gradient (``row_linear``)."""
         mods = list(self.occ_branches)
         i = 0
         while i < len(mods):
@@ -235,6 +240,9 @@ class VoxelFormerOccupancyHead(BaseModule):
                 from ..hipops import layer_norm_relu
                 x = layer_norm_relu(x, m.weight, m.bias, m.eps)
                 i += 2
+            elif isinstance(m, nn.Linear) and x.is_cuda:
+                x = row_linear(x, m.weight, m.bias)
+                i += 1
             else:
                 x = m(x)
                 i += 1
@@ -308,7 +316,9 @@ class VoxelFormerOccupancyHead(BaseModule):
         """Occupancy term of ``loss_single`` (head:977-989): sigmoid focal loss over
         [N, classes] logits with integer targets in [0, classes] (``classes`` = empty voxel),
         normalised by the number of occupied voxels, NaN-guarded."""
-        preds = occupancy_preds.reshape(-1, self.occupancy_classes).float()
+        preds = occupancy_preds.reshape(-1, self.occupancy_classes)
+        if not (preds.is_cuda and preds.dtype == torch.bfloat16):     # the fused loss reads bf16 as is
+            preds = preds.float()
         gt = gt_occupancy.reshape(-1)
         avg = (gt < self.occupancy_classes).sum() * 1.0
         return torch.nan_to_num(self.loss_occupancy(preds, gt, avg_factor=avg))

@@ -13,11 +13,12 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
-           'ver_msda3d_forward', 'ver_msda3d_backward')
+           'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
+           'ver_focal_loss_backward')
 
 _lib = None
 
@@ -329,6 +330,49 @@ class LayerNormReluFunction(Function):
 
 def layer_norm_relu(x, gamma, beta, eps=1e-5):
     return LayerNormReluFunction.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------------------
+class SigmoidFocalLossSumFunction(Function):
+    """sum over all elements of mmdet's sigmoid focal loss (ver_focal_loss_forward / _backward):
+    logits fp32|bf16 [N, C] with C % 8 == 0, target int64 [N] in [0, C]; returns an fp32 scalar."""
+
+    @staticmethod
+    def forward(ctx, logits, target, gamma, alpha):
+        logits = _gpu(logits, 'logits')
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('logits must be fp32 or bf16')
+        logits = logits.contiguous()
+        target = _gpu(target, 'target').to(torch.int64).contiguous()
+        n, c = logits.shape
+        if target.shape != (n,):
+            raise ValueError('target must be [N]')
+        dt = 1 if logits.dtype == torch.bfloat16 else 0
+        blocks = lib().ver_focal_loss_blocks(ctypes.c_long(n), c)
+        partial = torch.zeros(blocks, dtype=torch.float32, device=logits.device)
+        _launch('ver_focal_loss_forward', lambda: lib().ver_focal_loss_forward(
+            _p(logits), _p(target), _p(partial), ctypes.c_long(n), c, ctypes.c_float(gamma),
+            ctypes.c_float(alpha), dt, _stream()))
+        ctx.save_for_backward(logits, target)
+        ctx.cfg = (gamma, alpha, dt)
+        return partial.sum()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        logits, target = ctx.saved_tensors
+        gamma, alpha, dt = ctx.cfg
+        n, c = logits.shape
+        scale = _gpu(grad_out, 'grad_out').float().reshape(1).contiguous()
+        grad = torch.empty_like(logits)
+        _launch('ver_focal_loss_backward', lambda: lib().ver_focal_loss_backward(
+            _p(logits), _p(target), _p(scale), _p(grad), ctypes.c_long(n), c, ctypes.c_float(gamma),
+            ctypes.c_float(alpha), dt, _stream()))
+        return grad, None, None, None
+
+
+def sigmoid_focal_loss_sum(logits, target, gamma=2.0, alpha=0.25):
+    return SigmoidFocalLossSumFunction.apply(logits, target, float(gamma), float(alpha))
 
 
 # ------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 6
+#define VER_ABI_VERSION 8
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -213,6 +213,35 @@ int ver_focal_loss_forward(const void* logits, const int64_t* target, float* par
                            float gamma, float alpha, int dtype, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused occupancy MLP = the reference's `occ_branches` Sequential
+ * (dense_heads/voxelformer_occupancy_head.py:241-248; applied at :580):
+ *   Linear(128,128) LayerNorm ReLU Linear(128,128) LayerNorm ReLU Linear(128,16)
+ * bf16 operands, fp32 accumulation / LayerNorm statistics (the arithmetic of the reference's
+ * layers under bf16 autocast); the hidden activations never leave the registers.
+ *   pack    : W1, W2 f32 [128,128], W3 f32 [16,128] (nn.Linear layout [out,in]) -> `image`
+ *             (ver_occ_mlp_image_bytes() bytes, 16-byte aligned): MFMA weight fragments
+ *   vectors : f32 [ver_occ_mlp_vector_floats()] = b1 gamma1 beta1 b2 gamma2 beta2 (128 each) b3 (16)
+ *   forward : x bf16 [N,128] -> logits bf16 [N,16]
+ */
+long ver_occ_mlp_image_bytes(void);
+int ver_occ_mlp_vector_floats(void);
+int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W3, void* image, void* stream);
+int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits,
+                        long N, int width, int classes, float eps, void* stream);
+/*   backward: re-computes the forward from x, then
+ *     grad_x  bf16 [N,128]                      d loss / d x
+ *     grad_a1, grad_a2 bf16 [N,128]             gradients w.r.t. the outputs of Linear 1 / Linear 2
+ *     h1, h2  bf16 [N,128]                      inputs of Linear 2 / Linear 3 (post-ReLU activations)
+ *     param_grads f32 [4][128]                  d gamma1, d beta1, d gamma2, d beta2 (zeroed inside)
+ *   grad_a*, h* are stored in FRAGMENT feature order: column 32t + 8g + j of a row holds feature
+ *   32t + (j < 4 ? 4g + j : 16 + 4g + j - 4); the caller forms dW2 = grad_a2^T h1, dW1 = grad_a1^T x,
+ *   dW3 = grad_logits^T h2 and the bias gradients (column sums) from them and un-permutes.
+ */
+int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
+                         void* grad_x, void* grad_a1, void* grad_a2, void* h1, void* h2,
+                         float* param_grads, long N, int width, int classes, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -434,6 +434,73 @@ def test_row_linear_split_k_gradients():
     assert (bd2.grad.cpu().double() - br.grad).norm() / br.grad.norm() < 1e-2
 
 
+def _occ_mlp_reference(x, p, round_hidden=True):
+    """occ_branches in fp64 on bf16-rounded operands; hidden activations rounded to bf16 as the
+    fused kernel (and the layer-by-layer bf16 autocast path) hands them on."""
+    F = torch.nn.functional
+    r = (lambda t: t.bfloat16().double()) if round_hidden else (lambda t: t)
+    h = r(torch.relu(F.layer_norm(F.linear(x, p['w1'], p['b1']), (128,), p['g1'], p['be1'], 1e-5)))
+    h = r(torch.relu(F.layer_norm(F.linear(h, p['w2'], p['b2']), (128,), p['g2'], p['be2'], 1e-5)))
+    return F.linear(h, p['w3'], p['b3'])
+
+
+def _occ_mlp_params(gen):
+    p = dict(w1=torch.randn(128, 128, generator=gen) * 0.12, b1=torch.randn(128, generator=gen) * 0.3,
+             g1=torch.randn(128, generator=gen) * 0.3 + 1.0, be1=torch.randn(128, generator=gen) * 0.3,
+             w2=torch.randn(128, 128, generator=gen) * 0.12, b2=torch.randn(128, generator=gen) * 0.3,
+             g2=torch.randn(128, generator=gen) * 0.3 + 1.0, be2=torch.randn(128, generator=gen) * 0.3,
+             w3=torch.randn(16, 128, generator=gen) * 0.12, b3=torch.randn(16, generator=gen) * 0.3)
+    return p
+
+
+def test_occ_mlp_fused_forward():
+    """ver_occ_mlp_forward (MFMA chain in registers) vs occ_branches evaluated in fp64 (head:241-248)."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(11)
+    p = _occ_mlp_params(gen)
+    n = 64 * 37 + 21                                 # ragged: not a multiple of the 64-row wave block
+    x = (torch.randn(n, 128, generator=gen) * 1.5).bfloat16()
+    image = hip.occ_mlp_pack(p['w1'].to(DEV), p['w2'].to(DEV), p['w3'].to(DEV))
+    vec = hip.occ_mlp_vectors(*(p[k].to(DEV) for k in ('b1', 'g1', 'be1', 'b2', 'g2', 'be2', 'b3')))
+    got = hip.occ_mlp_forward(x.to(DEV), image, vec)
+    assert got.shape == (n, 16) and got.dtype == torch.bfloat16
+    pr = {k: (v.bfloat16().double() if k.startswith('w') else v.double()) for k, v in p.items()}
+    ref = _occ_mlp_reference(x.double(), pr)
+    err = (got.float().cpu().double() - ref).abs()
+    assert float(err.max()) <= 1e-2 * float(ref.abs().max()) + 2e-2, float(err.max())
+    assert float((got.float().cpu().double() - ref).norm() / ref.norm()) < 5e-3
+    assert hip.occ_mlp_forward(torch.zeros(0, 128, device=DEV, dtype=torch.bfloat16), image, vec).shape == (0, 16)
+
+
+def test_occ_mlp_fused_backward():
+    """ver_occ_mlp_backward (re-computed chain + dgrad chain in registers, row-reduced weight
+    gradients) vs autograd through the fp64 reference on the same bf16-rounded operands."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(12)
+    p = _occ_mlp_params(gen)
+    n = 8000 * 2 + 16 * 31 + 5
+    x = (torch.randn(n, 128, generator=gen) * 1.5).bfloat16()
+    gy = (torch.randn(n, 16, generator=gen) * 0.1).bfloat16()
+    keys = ('w1', 'b1', 'g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+    pd = {k: p[k].to(DEV).requires_grad_(True) for k in keys}
+    xd = x.to(DEV).requires_grad_(True)
+    out = hip.occ_mlp(xd, *(pd[k] for k in keys))
+    out.backward(gy.to(DEV))
+    pr = {k: (v.bfloat16().double() if k.startswith('w') else v.double()).requires_grad_(True) for k, v in p.items()}
+    xr = x.double().requires_grad_(True)
+    ref = _occ_mlp_reference(xr, pr, round_hidden=False)
+    ref.backward(gy.double())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(out.detach().float(), ref.detach()) < 5e-3
+    assert xd.grad.dtype == torch.bfloat16
+    assert rel(xd.grad.float(), xr.grad) < 6e-2, rel(xd.grad.float(), xr.grad)
+    for k in keys:
+        assert pd[k].grad.shape == p[k].shape
+        assert rel(pd[k].grad, pr[k].grad) < 8e-2, (k, rel(pd[k].grad, pr[k].grad))
+
+
 # ------------------------------------------------------------------------------- next row 2: occupancy loss
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('gamma,alpha', [(2.0, 0.25), (1.5, 0.4)])

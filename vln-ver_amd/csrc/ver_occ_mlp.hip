@@ -1,0 +1,518 @@
+// Fused occupancy MLP (`occ_branches`, dense_heads/voxelformer_occupancy_head.py:241-248, applied at
+// :580 to 504 000 voxels per viewpoint):
+//
+//     x[N,128] -> Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,128) -> LayerNorm -> ReLU
+//              -> Linear(128,16) -> logits[N,16]
+//
+// As separate GEMM / LayerNorm kernels every stage is one HBM round trip over [N,128] (N = 16e6 rows
+// for 32 viewpoints: 37 GB forward, 70 GB backward).  Here a wave keeps a block of rows in registers
+// through the whole chain: forward reads x once and writes the logits; backward re-computes the
+// forward from x, runs the chain backwards and writes d(x) plus the four bf16 tensors the
+// row-reduced weight gradients are formed from (include/ver_ops.h).
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16; lane l: c = l & 15, g = l >> 4):
+//   A[m][k]: lane holds A[c][8g..8g+7]     B[k][n]: lane holds B[8g..8g+7][c]
+//   D[m][n]: lane holds D[4g..4g+3][c]
+// Every layer is evaluated TRANSPOSED, T^T[o][r] = sum_k W[o][k] X[r][k], i.e. A = weights,
+// B = activations with the row r on the lane's column index c.  Then
+//   * a lane owns ONE row r (c) and 32 of its 128 features o = 16*ot + 4g + i: LayerNorm statistics
+//     are an in-lane sum + two cross-lane adds (xor 16, 32);
+//   * the D registers of tiles (2t, 2t+1) are, as they stand, the B fragment of k-step t of the next
+//     layer if that layer's weights are stored with the matching k order
+//     kperm(t, g, j) = 32t + (j < 4 ? 4g + j : 16 + 4g + j - 4):
+//     the chain never leaves the registers (no LDS transposes, no barriers).
+// Weight fragments live in LDS in fragment order (one conflict-free ds_read_b128 per fragment),
+// built once per step by `ver_occ_mlp_pack` from the fp32 parameters.
+#include "ver_common.h"
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kW = 128;       // hidden width
+constexpr int kC = 16;        // classes
+constexpr int kFrag = 64 * 8; // bf16 elements of one fragment image (64 lanes x 8)
+
+// image sections (in fragments of 1 KiB)
+constexpr int kF1 = 0;            // layer-1 forward  [ot 8][kt 4], natural k
+constexpr int kF2 = 32;           // layer-2 forward  [ot 8][kt 4], kperm
+constexpr int kF3 = 64;           // layer-3 forward  [kt 4], kperm
+constexpr int kFwdFrags = 68;
+constexpr int kB3 = 68;           // layer-3 dgrad    [mt 8]        (K = 16 classes, upper half zero)
+constexpr int kB2 = 76;           // layer-2 dgrad    [mt 8][ks 4]  (m = input feature, k = o via kperm)
+constexpr int kB1 = 108;          // layer-1 dgrad    [mp 4][t 2][ks 4], rows ordered for 16-byte stores
+constexpr int kAllFrags = 140;
+// fp32 vectors: b1 g1 be1 b2 g2 be2 (128 each) b3 (16)
+constexpr int kVecFloats = 6 * kW + kC;
+
+__device__ __forceinline__ int kperm(int t, int g, int j) { return 32 * t + (j < 4 ? 4 * g + j : 16 + 4 * g + j - 4); }
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
+    bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+}  // namespace
+
+// -------------------------------------------------------------------------------------------- pack
+__global__ __launch_bounds__(256) void k_occ_mlp_pack(const float* __restrict__ W1, const float* __restrict__ W2,
+                                                      const float* __restrict__ W3, __bf16* __restrict__ img) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= kAllFrags * kFrag) return;
+    const int f = e / kFrag, lane = (e / 8) & 63, j = e & 7;
+    const int c = lane & 15, g = lane >> 4;
+    float v = 0.0f;
+    if (f < kF2) {                                   // W1[o][k], natural k
+        const int ot = f / 4, kt = f % 4;
+        v = W1[(16 * ot + c) * kW + 32 * kt + 8 * g + j];
+    } else if (f < kF3) {
+        const int ot = (f - kF2) / 4, kt = (f - kF2) % 4;
+        v = W2[(16 * ot + c) * kW + kperm(kt, g, j)];
+    } else if (f < kB3) {
+        const int kt = f - kF3;
+        v = W3[c * kW + kperm(kt, g, j)];
+    } else if (f < kB2) {                            // A[m = feature][k = class 8g+j], classes >= 16 are padding
+        const int mt = f - kB3;
+        v = g < 2 ? W3[(8 * g + j) * kW + 16 * mt + c] : 0.0f;
+    } else if (f < kB1) {                            // A[m = input feature][k = o (kperm)] = W2[o][m]
+        const int mt = (f - kB2) / 4, ks = (f - kB2) % 4;
+        v = W2[kperm(ks, g, j) * kW + 16 * mt + c];
+    } else {                                         // rows of tile (mp, t): m = 4q+i -> feature 32mp + 8q + 4t + i
+        const int mp = (f - kB1) / 8, t = ((f - kB1) / 4) % 2, ks = (f - kB1) % 4;
+        const int feat = 32 * mp + 8 * (c >> 2) + 4 * t + (c & 3);
+        v = W1[kperm(ks, g, j) * kW + feat];
+    }
+    img[e] = (__bf16)v;
+}
+
+// ----------------------------------------------------------------------------------------- forward
+namespace {
+// LayerNorm + ReLU of one row tile held transposed: acc[ot][i] = feature 16ot + 4g + i of row c.
+// Returns the B fragments of the next layer (k-step t <- tiles 2t, 2t+1); optionally the normalised
+// values (for the backward pass).
+template <bool KEEP>
+__device__ __forceinline__ void ln_relu_tile(f32x4 (&acc)[8], const float* gam, const float* bet, float eps,
+                                             bf16x8 (&out)[4], float& rstd_out) {   // gam/bet already offset by 4g
+    float s = 0.0f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) s += (acc[ot].x + acc[ot].y) + (acc[ot].z + acc[ot].w);
+    s += xor16(s);
+    s += xor32(s);
+    const float mu = s * (1.0f / kW);
+    float q = 0.0f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        acc[ot] -= mu;
+        q += (acc[ot].x * acc[ot].x + acc[ot].y * acc[ot].y) + (acc[ot].z * acc[ot].z + acc[ot].w * acc[ot].w);
+    }
+    q += xor16(q);
+    q += xor32(q);
+    const float rs = rsqrtf(q * (1.0f / kW) + eps);
+    rstd_out = rs;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 y[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ot = 2 * t + h;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * ot);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * ot);
+            if (KEEP) acc[ot] *= rs;                       // normalised value stays in acc
+            const f32x4 v = KEEP ? acc[ot] * gm + bt : acc[ot] * (gm * rs) + bt;
+            y[h] = __builtin_elementwise_max(v, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+        }
+        out[t] = pack8(y[0], y[1]);
+    }
+}
+}  // namespace
+
+template <int RT>
+__global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict__ x, const __bf16* __restrict__ img,
+                                                        const float* __restrict__ vec, __bf16* __restrict__ logits,
+                                                        long N, float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                       // [kFwdFrags][64]
+    float* sv = reinterpret_cast<float*>(smem + kFwdFrags * 1024);        // vectors
+    for (int i = threadIdx.x; i < kFwdFrags * 64; i += 256) frag[i] = reinterpret_cast<const bf16x8*>(img)[i];
+    for (int i = threadIdx.x; i < kVecFloats; i += 256) sv[i] = vec[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const long nblk = (N + 16 * RT - 1) / (16 * RT);
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        const long r0 = blk * (16 * RT);
+        // the weight fragments are loop invariant: hide that from LICM, which would otherwise hoist
+        // all 68 of them (272 VGPRs) out of the row loop
+        int lane_off = lane;
+        asm volatile("" : "+v"(lane_off));
+        const bf16x8* fr = frag + lane_off;
+        const float* sv_g = sv + 4 * (lane_off >> 4);
+        bf16x8 bf[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long r = r0 + rt * 16 + c;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                bf[rt][kt] = r < N ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * kt + 8 * g) : z;
+            }
+        }
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            const float* bias = sv_g + layer * 3 * kW;
+            f32x4 acc[RT][8];
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * ot);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][ot] = b;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8 a = fr[((layer ? kF2 : kF1) + ot * 4 + kt) * 64];
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][ot] = mfma(a, bf[rt][kt], acc[rt][ot]);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                float rs;
+                ln_relu_tile<false>(acc[rt], bias + kW, bias + 2 * kW, eps, bf[rt], rs);
+            }
+        }
+        // layer 3: classes 4g..4g+3 of row c
+        const f32x4 b3 = *reinterpret_cast<const f32x4*>(sv_g + 6 * kW);
+        f32x4 lo[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) lo[rt] = b3;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x8 a = fr[(kF3 + kt) * 64];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) lo[rt] = mfma(a, bf[rt][kt], lo[rt]);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long r = r0 + rt * 16 + c;
+            if (r < N) *reinterpret_cast<bf16x4*>(logits + r * kC + 4 * g) = __builtin_convertvector(lo[rt], bf16x4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward
+namespace {
+// acc[mt] (+)= sum_ks A[base + 4 mt + ks] * b[ks] for 8 output tiles, A fragments double-buffered
+// from LDS one tile ahead.  The scheduling barriers keep the compiler from hoisting all 32 fragment
+// reads (128 VGPRs) to the top of the phase.
+template <bool BIAS>
+__device__ __forceinline__ void gemm8(f32x4 (&acc)[8], const bf16x8* fr, int base, const bf16x8 (&b)[4],
+                                      const float* bias) {
+    bf16x8 a[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a[0][ks] = fr[(base + ks) * 64];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        if (mt + 1 < 8) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a[(mt + 1) & 1][ks] = fr[(base + (mt + 1) * 4 + ks) * 64];
+        }
+        acc[mt] = BIAS ? *reinterpret_cast<const f32x4*>(bias + 16 * mt) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[mt] = mfma(a[mt & 1][ks], b[ks], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ f32x4 unpack_half(bf16x8 p, int hi) {
+    const bf16x4 h = hi ? __builtin_shufflevector(p, p, 4, 5, 6, 7) : __builtin_shufflevector(p, p, 0, 1, 2, 3);
+    return __builtin_convertvector(h, f32x4);
+}
+
+// Forward LayerNorm+ReLU that also keeps what the backward needs: the normalised values (bf16, same
+// pairing as the fragments) and 1/sigma.
+__device__ __forceinline__ void ln_relu_keep(f32x4 (&acc)[8], const float* gam, const float* bet, float eps,
+                                             bf16x8 (&out)[4], bf16x8 (&xh)[4], float& rstd_out) {
+    float s = 0.0f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) s += (acc[ot].x + acc[ot].y) + (acc[ot].z + acc[ot].w);
+    s += xor16(s);
+    s += xor32(s);
+    const float mu = s * (1.0f / kW);
+    float q = 0.0f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        acc[ot] -= mu;
+        q += (acc[ot].x * acc[ot].x + acc[ot].y * acc[ot].y) + (acc[ot].z * acc[ot].z + acc[ot].w * acc[ot].w);
+    }
+    q += xor16(q);
+    q += xor32(q);
+    const float rs = rsqrtf(q * (1.0f / kW) + eps);
+    rstd_out = rs;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        xh[t] = pack8(acc[2 * t] * rs, acc[2 * t + 1] * rs);
+        f32x4 y[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ot = 2 * t + h;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * ot);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * ot);
+            // from the ROUNDED normalised value: the backward pass re-derives exactly this ReLU gate
+            y[h] = __builtin_elementwise_max(unpack_half(xh[t], h) * gm + bt, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+        }
+        out[t] = pack8(y[0], y[1]);
+    }
+}
+
+// d(pre-LayerNorm) from d(post-ReLU) for one row tile (transposed layout); accumulates d(gamma), d(beta).
+// The parameter gradients are sums over ROWS, which sit on the lane index here.  Rather than 128
+// per-lane accumulators, dz and dz*xhat (bf16) are fed back as A operands against a constant 0/1
+// selector B: D[r][n] = dz[r][feature 16ot+n], i.e. the tile comes back transposed (feature on the
+// lane, 4 rows in the registers) and 4 adds fold it into ONE accumulator per (tile, quantity).
+__device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
+                                            const float* bet, const bf16x8 (&sel)[2], float (&dgam)[8],
+                                            float (&dbet)[8], bf16x8 (&out)[4]) {
+    float s1 = 0.0f, s2 = 0.0f;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 dz[2], dzn[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ot = 2 * t + h;
+            const f32x4 n = unpack_half(xh[t], h);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * ot);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * ot);
+            const f32x4 y = n * gm + bt;
+            dz[h].x = y.x > 0.0f ? d[ot].x : 0.0f;
+            dz[h].y = y.y > 0.0f ? d[ot].y : 0.0f;
+            dz[h].z = y.z > 0.0f ? d[ot].z : 0.0f;
+            dz[h].w = y.w > 0.0f ? d[ot].w : 0.0f;
+            dzn[h] = dz[h] * n;
+            const f32x4 dg = dz[h] * gm;
+            d[ot] = dg;
+            s1 += (dg.x + dg.y) + (dg.z + dg.w);
+            const f32x4 dn = dg * n;
+            s2 += (dn.x + dn.y) + (dn.z + dn.w);
+        }
+        const bf16x8 pz = pack8(dz[0], dz[1]), pn = pack8(dzn[0], dzn[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 tb = mfma(pz, sel[h], zero4);
+            const f32x4 tg = mfma(pn, sel[h], zero4);
+            dbet[2 * t + h] += (tb.x + tb.y) + (tb.z + tb.w);
+            dgam[2 * t + h] += (tg.x + tg.y) + (tg.z + tg.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 += xor16(s1);
+    s1 += xor32(s1);
+    s2 += xor16(s2);
+    s2 += xor32(s2);
+    const float m1 = s1 * (1.0f / kW), m2 = s2 * (1.0f / kW);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 a = (d[2 * t] - m1 - unpack_half(xh[t], 0) * m2) * rs;
+        const f32x4 b = (d[2 * t + 1] - m1 - unpack_half(xh[t], 1) * m2) * rs;
+        out[t] = pack8(a, b);
+    }
+}
+}  // namespace
+
+// One wave = 16 rows per iteration; one wave per SIMD (the chain needs ~380 registers incl. AGPRs).
+// Outputs h1, h2, da1, da2 are stored in FRAGMENT feature order: position 32t + 8g + j of a row
+// holds feature kperm(t, g, j) (16-byte stores); the caller un-permutes the small weight gradients.
+__global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
+                                                        const __bf16* __restrict__ img, const float* __restrict__ vec,
+                                                        __bf16* __restrict__ dx, __bf16* __restrict__ da1,
+                                                        __bf16* __restrict__ da2, __bf16* __restrict__ h1,
+                                                        __bf16* __restrict__ h2, float* __restrict__ pgrad, long N,
+                                                        float eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                       // [kAllFrags][64]
+    float* sv = reinterpret_cast<float*>(smem + kAllFrags * 1024);
+    for (int i = threadIdx.x; i < kAllFrags * 64; i += 256) frag[i] = reinterpret_cast<const bf16x8*>(img)[i];
+    for (int i = threadIdx.x; i < kVecFloats; i += 256) sv[i] = vec[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float dgam[2][8], dbet[2][8];       // feature 16ot + c, partial over the rows 4g..4g+3 of every block
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) dgam[l][ot] = dbet[l][ot] = 0.0f;
+    // selector B fragments: k = 8g+j of a packed pair holds feature 4g+j of tile 2t (j<4) or tile 2t+1
+    bf16x8 sel[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sel[0][j] = (__bf16)((j < 4 && 4 * g + j == c) ? 1.0f : 0.0f);
+        sel[1][j] = (__bf16)((j >= 4 && 4 * g + j - 4 == c) ? 1.0f : 0.0f);
+    }
+    const long nblk = (N + 15) / 16;
+    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+        int lane_off = lane;
+        asm volatile("" : "+v"(lane_off));
+        const bf16x8* fr = frag + lane_off;
+        const float* sv_g = sv + 4 * (lane_off >> 4);
+        const long r = blk * 16 + c;
+        const bool ok = r < N;
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 bf[4], xh1[4], xh2[4];
+        float rs1, rs2;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) bf[kt] = ok ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * kt + 8 * g) : z8;
+        f32x4 acc[8];
+        // ---- forward, layer 1
+        gemm8<true>(acc, fr, kF1, bf, sv_g);
+        __builtin_amdgcn_sched_barrier(0);
+        ln_relu_keep(acc, sv_g + kW, sv_g + 2 * kW, eps, bf, xh1, rs1);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(h1 + r * kW + 32 * t + 8 * g) = bf[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- forward, layer 2
+        gemm8<true>(acc, fr, kF2, bf, sv_g + 3 * kW);
+        __builtin_amdgcn_sched_barrier(0);
+        ln_relu_keep(acc, sv_g + 4 * kW, sv_g + 5 * kW, eps, bf, xh2, rs2);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(h2 + r * kW + 32 * t + 8 * g) = bf[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- d(h2)^T = W3^T d(logits)^T   (K = 16 classes in the lower half of the k-step)
+        const bf16x8 dl = (ok && g < 2) ? *reinterpret_cast<const bf16x8*>(dlog + r * kC + 8 * g) : z8;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) acc[mt] = mfma(fr[(kB3 + mt) * 64], dl, zero4);
+        __builtin_amdgcn_sched_barrier(0);
+        ln_relu_bwd(acc, xh2, rs2, sv_g + 4 * kW, sv_g + 5 * kW, sel, dgam[1], dbet[1], bf);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(da2 + r * kW + 32 * t + 8 * g) = bf[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- d(h1)^T = W2^T d(a2)^T
+        gemm8<false>(acc, fr, kB2, bf, nullptr);
+        __builtin_amdgcn_sched_barrier(0);
+        ln_relu_bwd(acc, xh1, rs1, sv_g + kW, sv_g + 2 * kW, sel, dgam[0], dbet[0], bf);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(da1 + r * kW + 32 * t + 8 * g) = bf[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- d(x)^T = W1^T d(a1)^T, tile rows ordered so that a lane ends up with 8 consecutive features
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+            f32x4 o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                o[t] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) o[t] = mfma(fr[(kB1 + (mp * 2 + t) * 4 + ks) * 64], bf[ks], o[t]);
+            }
+            if (ok) *reinterpret_cast<bf16x8*>(dx + r * kW + 32 * mp + 8 * g) = pack8(o[0], o[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- d(gamma), d(beta): add the four row groups, then one atomic per feature and wave
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) {
+            float a = dgam[l][ot], b = dbet[l][ot];
+            a += xor16(a);
+            a += xor32(a);
+            b += xor16(b);
+            b += xor32(b);
+            if (g == 0) {
+                atomicAdd(pgrad + (2 * l) * kW + 16 * ot + c, a);
+                atomicAdd(pgrad + (2 * l + 1) * kW + 16 * ot + c, b);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ host
+namespace {
+int check_common(const char* who, const void* x, const void* img, const float* vec, long N, int width, int classes) {
+    VER_REQUIRE(N >= 0, VER_EINVAL, "%s: negative row count", who);
+    VER_REQUIRE(width == kW && classes == kC, VER_EUNSUPPORTED, "%s: built for width %d / %d classes (got %d / %d)", who,
+                kW, kC, width, classes);
+    VER_REQUIRE(img && vec, VER_EINVAL, "%s: null weight image / vector pointer", who);
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(x, VER_EINVAL, "%s: null pointer argument", who);
+    VER_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)img & 15) == 0, VER_EINVAL, "%s: buffers must be 16-byte aligned",
+                who);
+    return VER_OK;
+}
+}  // namespace
+
+extern "C" long ver_occ_mlp_image_bytes(void) { return (long)kAllFrags * kFrag * 2; }
+extern "C" int ver_occ_mlp_vector_floats(void) { return kVecFloats; }
+
+extern "C" int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W3, void* image, void* stream) {
+    VER_REQUIRE(W1 && W2 && W3 && image, VER_EINVAL, "ver_occ_mlp_pack: null pointer argument");
+    const int n = kAllFrags * kFrag;
+    hipLaunchKernelGGL(k_occ_mlp_pack, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, W1, W2, W3,
+                       (__bf16*)image);
+    return ver_check_launch("ver_occ_mlp_pack");
+}
+
+extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits, long N,
+                                   int width, int classes, float eps, void* stream) {
+    int rc = check_common("ver_occ_mlp_forward", x, image, vectors, N, width, classes);
+    if (rc) return rc;
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(logits, VER_EINVAL, "ver_occ_mlp_forward: null logits pointer");
+    constexpr int RT = 4;
+    const size_t lds = (size_t)kFwdFrags * 1024 + kVecFloats * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_occ_mlp_fwd<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const long nblk = (N + 16 * RT - 1) / (16 * RT);
+    long grid = (nblk + 3) / 4;
+    if (grid > 512) grid = 512;                            // 2 workgroups per CU, persistent
+    hipLaunchKernelGGL(k_occ_mlp_fwd<RT>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const __bf16*)x,
+                       (const __bf16*)image, vectors, (__bf16*)logits, N, eps);
+    return ver_check_launch("ver_occ_mlp_forward");
+}
+
+extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
+                                    void* grad_x, void* grad_a1, void* grad_a2, void* h1, void* h2, float* param_grads,
+                                    long N, int width, int classes, float eps, void* stream) {
+    int rc = check_common("ver_occ_mlp_backward", x, image, vectors, N, width, classes);
+    if (rc) return rc;
+    VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(param_grads, 0, 4 * kW * sizeof(float), st);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1 && h2, VER_EINVAL,
+                "ver_occ_mlp_backward: null pointer argument");
+    const size_t lds = (size_t)kAllFrags * 1024 + kVecFloats * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: LDS attribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const long nblk = (N + 15) / 16;
+    long grid = (nblk + 3) / 4;
+    if (grid > 256) grid = 256;                            // one 4-wave workgroup per CU (LDS bound), persistent
+    hipLaunchKernelGGL(k_occ_mlp_bwd, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
+                       (const __bf16*)grad_logits, (const __bf16*)image, vectors, (__bf16*)grad_x, (__bf16*)grad_a1,
+                       (__bf16*)grad_a2, (__bf16*)h1, (__bf16*)h2, param_grads, N, eps);
+    return ver_check_launch("ver_occ_mlp_backward");
+}

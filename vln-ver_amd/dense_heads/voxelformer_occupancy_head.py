@@ -227,11 +227,35 @@ class VoxelFormerOccupancyHead(BaseModule):
         occ = occ.reshape(bs, -1, self.occ_dims)
         return self._occ_mlp(occ)
 
+    @staticmethod
+    def _occ_mlp_is_fusable(mods):
+        """[Linear(128,128), LayerNorm, ReLU] x2 + Linear(128,16) -- the vocc.py occupancy MLP."""
+        if len(mods) != 7:
+            return False
+        kinds = (nn.Linear, nn.LayerNorm, nn.ReLU, nn.Linear, nn.LayerNorm, nn.ReLU, nn.Linear)
+        if not all(isinstance(m, k) for m, k in zip(mods, kinds)):
+            return False
+        l1, n1, _, l2, n2, _, l3 = mods
+        return (tuple(l1.weight.shape) == (128, 128) and tuple(l2.weight.shape) == (128, 128)
+                and tuple(l3.weight.shape) == (16, 128) and all(m.bias is not None for m in (l1, l2, l3))
+                and all(tuple(m.normalized_shape) == (128,) and m.elementwise_affine and m.bias is not None
+                        for m in (n1, n2)) and n1.eps == n2.eps)
+
     def _occ_mlp(self, x):
         """``occ_branches`` (head:241-248).  On the GPU each LayerNorm(128)+ReLU pair is one fused
         HIP pass (``ver_ln_relu_*``); Linear layers are hipBLASLt GEMMs with a split-K weight
-        gradient (``row_linear``)."""
+        gradient (``row_linear``).  Under bf16 autocast the vocc.py shape of the Sequential runs as
+        the fused MFMA kernels ``ver_occ_mlp_forward/backward`` instead."""
         mods = list(self.occ_branches)
+        if x.is_cuda and self._occ_mlp_is_fusable(mods) and (
+                x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
+                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+            # bf16 arithmetic (autocast): the whole Sequential is one MFMA kernel each way
+            from ..hipops import occ_mlp
+            l1, n1, _, l2, n2, _, l3 = mods
+            with torch.autocast('cuda', enabled=False):
+                return occ_mlp(x.to(torch.bfloat16), l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias,
+                               n2.weight, n2.bias, l3.weight, l3.bias, n1.eps)
         i = 0
         while i < len(mods):
             m = mods[i]

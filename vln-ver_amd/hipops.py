@@ -13,12 +13,13 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 8
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
-           'ver_focal_loss_backward')
+           'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
+           'ver_occ_mlp_forward', 'ver_occ_mlp_backward')
 
 _lib = None
 
@@ -40,6 +41,7 @@ def lib():
             if not hasattr(handle, name):
                 raise HipLibraryError('%s does not export %s' % (LIB_PATH, name))
         handle.ver_last_error.restype = ctypes.c_char_p
+        handle.ver_occ_mlp_image_bytes.restype = ctypes.c_long
         if handle.ver_abi_version() != ABI_VERSION:
             raise HipLibraryError('libver_hip.so ABI %d != expected %d: rebuild'
                                   % (handle.ver_abi_version(), ABI_VERSION))
@@ -373,6 +375,114 @@ class SigmoidFocalLossSumFunction(Function):
 
 def sigmoid_focal_loss_sum(logits, target, gamma=2.0, alpha=0.25):
     return SigmoidFocalLossSumFunction.apply(logits, target, float(gamma), float(alpha))
+
+
+# ------------------------------------------------------------------------------------------
+def occ_mlp_pack(w1, w2, w3):
+    """fp32 nn.Linear weights of ``occ_branches`` -> MFMA fragment image (ver_occ_mlp_pack)."""
+    w1, w2, w3 = (_gpu(w, 'weight').detach().float().contiguous() for w in (w1, w2, w3))
+    if w1.shape != (128, 128) or w2.shape != (128, 128) or w3.shape != (16, 128):
+        raise ValueError('occ_mlp is built for Linear(128,128) x2 + Linear(128,16)')
+    image = torch.empty(lib().ver_occ_mlp_image_bytes() // 2, dtype=torch.bfloat16, device=w1.device)
+    _launch('ver_occ_mlp_pack', lambda: lib().ver_occ_mlp_pack(_p(w1), _p(w2), _p(w3), _p(image), _stream()))
+    return image
+
+
+def occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3):
+    vec = torch.cat([_gpu(v, 'vector').detach().float().reshape(-1) for v in (b1, g1, be1, b2, g2, be2, b3)])
+    if vec.numel() != lib().ver_occ_mlp_vector_floats():
+        raise ValueError('occ_mlp vectors: expected 6x128 + 16 floats')
+    return vec.contiguous()
+
+
+def occ_mlp_forward(x, image, vectors, eps=1e-5):
+    """x bf16 [..., 128] -> logits bf16 [..., 16] (ver_occ_mlp_forward)."""
+    x = _gpu(x, 'x')
+    if x.dtype != torch.bfloat16 or x.shape[-1] != 128:
+        raise TypeError('x must be bf16 [..., 128]')
+    x = x.contiguous()
+    n = x.numel() // 128
+    logits = torch.empty(x.shape[:-1] + (16,), dtype=torch.bfloat16, device=x.device)
+    _launch('ver_occ_mlp_forward', lambda: lib().ver_occ_mlp_forward(
+        _p(x), _p(image), _p(vectors), _p(logits), ctypes.c_long(n), 128, 16, ctypes.c_float(eps), _stream()))
+    return logits
+
+
+def _rows_tn(a, b, chunk=8000):
+    """a^T b in fp32 for tall a [N,P], b [N,Q] (N ~ 1e7, P,Q <= 128) plus the column sums of a:
+    the row dimension is split into chunks run as ONE batched GEMM (a plain GEMM would own a
+    single output tile and run on one CU)."""
+    n = a.shape[0]
+    s = n // chunk
+    main = s * chunk
+    prod = a.new_zeros((a.shape[1], b.shape[1]), dtype=torch.float32)
+    colsum = a.new_zeros((a.shape[1],), dtype=torch.float32)
+    if s:
+        a3 = a[:main].view(s, chunk, -1)
+        prod += torch.bmm(a3.transpose(1, 2), b[:main].view(s, chunk, -1)).sum(0, dtype=torch.float32)
+        ones = a.new_ones((1, 1, chunk)).expand(s, 1, chunk)
+        colsum += torch.bmm(ones, a3).sum((0, 1), dtype=torch.float32)
+    if main < n:
+        prod += (a[main:].t() @ b[main:]).float()
+        colsum += a[main:].sum(0, dtype=torch.float32)
+    return prod, colsum
+
+
+_FRAG_ORDER = {}
+
+
+def _frag_order(device):
+    """inverse of the kernels' fragment feature order: inv[feature] = column."""
+    key = str(device)
+    if key not in _FRAG_ORDER:
+        pos = torch.arange(128)
+        t, g, j = pos // 32, (pos % 32) // 8, pos % 8
+        feat = 32 * t + torch.where(j < 4, 4 * g + j, 16 + 4 * g + j - 4)
+        inv = torch.empty(128, dtype=torch.long)
+        inv[feat] = pos
+        _FRAG_ORDER[key] = inv.to(device)
+    return _FRAG_ORDER[key]
+
+
+class OccMLPFunction(Function):
+    """``occ_branches`` (head:241-248) as one fused kernel each way (ver_occ_mlp_*): x bf16 [N,128]
+    -> logits bf16 [N,16].  Nothing but x is kept for the backward pass (the chain is re-computed)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps):
+        x = _gpu(x, 'x').contiguous()
+        image = occ_mlp_pack(w1, w2, w3)
+        vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
+        ctx.save_for_backward(x, image, vec)
+        ctx.eps = eps
+        return occ_mlp_forward(x, image, vec, eps)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_logits):
+        x, image, vec = ctx.saved_tensors
+        shape = x.shape
+        x2 = x.view(-1, 128)
+        n = x2.shape[0]
+        gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
+        gx, ga1, ga2, h1, h2 = (torch.empty_like(x2) for _ in range(5))
+        pg = torch.empty(4, 128, dtype=torch.float32, device=x.device)
+        _launch('ver_occ_mlp_backward', lambda: lib().ver_occ_mlp_backward(
+            _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1), _p(ga2), _p(h1), _p(h2), _p(pg),
+            ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _stream()))
+        inv = _frag_order(x.device)
+        dw3, db3 = _rows_tn(gl, h2)
+        dw2, db2 = _rows_tn(ga2, h1)
+        dw1, db1 = _rows_tn(ga1, x2)
+        dw3 = dw3.index_select(1, inv)
+        dw2 = dw2.index_select(0, inv).index_select(1, inv)
+        dw1 = dw1.index_select(0, inv)
+        return (gx.view(shape), dw1, db1.index_select(0, inv), pg[0], pg[1], dw2, db2.index_select(0, inv),
+                pg[2], pg[3], dw3, db3, None)
+
+
+def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5):
+    return OccMLPFunction.apply(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps)
 
 
 # ------------------------------------------------------------------------------------------

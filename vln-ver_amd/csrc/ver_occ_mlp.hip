@@ -279,7 +279,7 @@ __device__ __forceinline__ void ln_relu_keep(f32x4 (&acc)[8], const float* gam, 
 // lane, 4 rows in the registers) and 4 adds fold it into ONE accumulator per (tile, quantity).
 __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
                                             const float* bet, const bf16x8 (&sel)[2], float (&dgam)[8],
-                                            float (&dbet)[8], bf16x8 (&out)[4]) {
+                                            float (&dbet)[8], float (&dbias)[8], bf16x8 (&out)[4]) {
     float s1 = 0.0f, s2 = 0.0f;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -323,6 +323,13 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4]
         const f32x4 a = (d[2 * t] - m1 - unpack_half(xh[t], 0) * m2) * rs;
         const f32x4 b = (d[2 * t + 1] - m1 - unpack_half(xh[t], 1) * m2) * rs;
         out[t] = pack8(a, b);
+        // d(bias of the Linear in front) = column sums of d(a): same selector trick
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 ta = mfma(out[t], sel[h], zero4);
+            dbias[2 * t + h] += (ta.x + ta.y) + (ta.z + ta.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 }  // namespace
@@ -345,11 +352,11 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float dgam[2][8], dbet[2][8];       // feature 16ot + c, partial over the rows 4g..4g+3 of every block
+    float dgam[2][8], dbet[2][8], dbias[2][8];   // feature 16ot + c, partial over the rows 4g..4g+3 of every block
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot) dgam[l][ot] = dbet[l][ot] = 0.0f;
+        for (int ot = 0; ot < 8; ++ot) dgam[l][ot] = dbet[l][ot] = dbias[l][ot] = 0.0f;
     // selector B fragments: k = 8g+j of a packed pair holds feature 4g+j of tile 2t (j<4) or tile 2t+1
     bf16x8 sel[2];
 #pragma unroll
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc[mt] = mfma(fr[(kB3 + mt) * 64], dl, zero4);
         __builtin_amdgcn_sched_barrier(0);
-        ln_relu_bwd(acc, xh2, rs2, sv_g + 4 * kW, sv_g + 5 * kW, sel, dgam[1], dbet[1], bf);
+        ln_relu_bwd(acc, xh2, rs2, sv_g + 4 * kW, sv_g + 5 * kW, sel, dgam[1], dbet[1], dbias[1], bf);
         if (ok) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(da2 + r * kW + 32 * t + 8 * g) = bf[t];
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
         // ---- d(h1)^T = W2^T d(a2)^T
         gemm8<false>(acc, fr, kB2, bf, nullptr);
         __builtin_amdgcn_sched_barrier(0);
-        ln_relu_bwd(acc, xh1, rs1, sv_g + kW, sv_g + 2 * kW, sel, dgam[0], dbet[0], bf);
+        ln_relu_bwd(acc, xh1, rs1, sv_g + kW, sv_g + 2 * kW, sel, dgam[0], dbet[0], dbias[0], bf);
         if (ok) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(da1 + r * kW + 32 * t + 8 * g) = bf[t];
@@ -428,14 +435,17 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
     for (int l = 0; l < 2; ++l)
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) {
-            float a = dgam[l][ot], b = dbet[l][ot];
+            float a = dgam[l][ot], b = dbet[l][ot], d = dbias[l][ot];
             a += xor16(a);
             a += xor32(a);
             b += xor16(b);
             b += xor32(b);
+            d += xor16(d);
+            d += xor32(d);
             if (g == 0) {
-                atomicAdd(pgrad + (2 * l) * kW + 16 * ot + c, a);
-                atomicAdd(pgrad + (2 * l + 1) * kW + 16 * ot + c, b);
+                atomicAdd(pgrad + (3 * l) * kW + 16 * ot + c, a);
+                atomicAdd(pgrad + (3 * l + 1) * kW + 16 * ot + c, b);
+                atomicAdd(pgrad + (3 * l + 2) * kW + 16 * ot + c, d);
             }
         }
 }
@@ -496,7 +506,7 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     if (rc) return rc;
     VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(param_grads, 0, 4 * kW * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(param_grads, 0, 6 * kW * sizeof(float), st);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1 && h2, VER_EINVAL,

@@ -57,6 +57,32 @@ def test_upsample_lattice_equals_conv_transpose():
         assert maxdiff(a, b) < 1e-10
 
 
+@pytest.mark.parametrize('C,Z,Hl,Wl', [(8, 4, 3, 5), (16, 2, 4, 3), (24, 4, 5, 6)])
+def test_occ_proj_on_lattice_equals_dense_view(C, Z, Hl, Wl):
+    """occ_proj evaluated on the even lattice (gathered GEMMs, hand-written backward) vs the
+    reference's raw .view + permute + Linear on the dense volume (head:564-571), values and all
+    four gradients in fp64, bs = 3."""
+    opl, ups = pkg('dense_heads.occ_proj_lattice'), pkg('dense_heads.upsample')
+    gen = torch.Generator().manual_seed(C + Hl)
+    bs, out = 3, 20
+    e = torch.randn(bs, Z, Hl, Wl, C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    ub = torch.randn(C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(out, Z * C, generator=gen, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(out, generator=gen, dtype=torch.float64).requires_grad_(True)
+    res = opl.occ_proj_from_lattice(e, ub, w, b)
+    assert res is not None
+    rows, plan = res
+    ours = opl.rows_to_voxels(rows, plan, bs)                                  # [bs, Hf*Wf, out]
+    y = ups.full_volume(e, ub)                                                 # [bs, C, Z, 2Hl, 2Wl]
+    dense = torch.nn.functional.linear(
+        y.contiguous().view(bs, Z, 2 * Hl, 2 * Wl, C).permute(0, 2, 3, 1, 4).flatten(3), w, b)
+    dense = dense.view(bs, -1, out)
+    assert maxdiff(ours, dense) < 1e-11
+    g = torch.randn(dense.shape, generator=gen, dtype=torch.float64)
+    for a, r in zip(torch.autograd.grad(ours, [e, ub, w, b], g), torch.autograd.grad(dense, [e, ub, w, b], g)):
+        assert maxdiff(a, r) < 1e-10
+
+
 def test_occupancy_branch_equals_oracle(head):
     """a10 at full size on CPU: ours (lattice upsample) vs the oracle (ConvTranspose3d from its
     definition, raw views kept)."""

@@ -11,11 +11,19 @@ input row is ~3/4 constants whose positions depend only on the row's position:
                     + sum_k  b_up[chan(row, k)] * (sum_{non-data cols of token k} W[:, j])
 
 Rows are grouped by their data-column pattern (5 patterns at the vocc.py sizes: the pattern
-depends on ``b % 5`` only); per group one GEMM ``[rows, ~768] x [~768, 4480]`` replaces the
-``[rows, 3072] x [3072, 4480]`` slice of the dense product: 99 instead of 396 GFLOP per viewpoint,
-and the 4x larger dense volume is never materialised.  Pure index bookkeeping + torch GEMMs
-(autograd-differentiable); the index tables are built once per geometry by brute force from the
-definition of the two raw views, so they are correct by construction for any (C, Z, H, W).
+depends on ``b % 5`` only); per group ONE GEMM ``[bs*rows, K_g] x [K_g, 4480]`` with
+``K_g = data cols + Z + 1`` replaces the ``[.., 3072] x [3072, 4480]`` slice of the dense
+product: the Z+1 extra columns of the gathered operand carry ``b_up[chan(row,k)]`` and a 1, the
+matching weight rows the summed constant columns and the bias, so the constant part costs no
+separate pass.  99 instead of 396 GFLOP per viewpoint and the 4x larger dense volume is never
+materialised.
+
+One autograd Function (``_OccProjLattice``) with a hand-written backward: every GEMM writes
+straight into its slice of a preallocated GROUP-MAJOR buffer (row of (group g, sample b, member i)
+= bs*offset_g + b*n_g + i), so there is no concatenation, no broadcast add and no gradient
+accumulation over slices.  ``occ_branches`` is row-wise and runs in that order; ``rows_to_voxels``
+brings the 16-wide logits into the reference's voxel order.  The index tables are built once per
+geometry by brute force from the definition of the two raw views, so they hold for any (C,Z,H,W).
 """
 import numpy as np
 import torch
@@ -55,8 +63,8 @@ def _build_plan(C, Z, Hf, Wf):
     inverse = inverse.reshape(-1)
     plan = _Plan()
     plan.groups = []
-    plan.rows, plan.feat, plan.lattice_size = rows, feat, C * Z * Hl * Wl
-    order = []
+    plan.rows, plan.feat, plan.lattice_size, plan.C, plan.Z = rows, feat, C * Z * Hl * Wl, C, Z
+    used = np.zeros(plan.lattice_size, dtype=np.int64)
     for gi, r0 in enumerate(first):
         members = np.nonzero(inverse == gi)[0]
         cols = np.nonzero(data2[r0])[0]
@@ -65,49 +73,46 @@ def _build_plan(C, Z, Hf, Wf):
         g.rows = members
         g.cols = cols
         g.gather = lat2[np.ix_(members, cols)]        # [n_rows, n_cols] lattice indices
+        np.add.at(used, g.gather.reshape(-1), 1)
         # per token k: which non-data columns belong to it (for the constant term)
         g.ncols_by_token = [ncols[(ncols // C) == kk] for kk in range(Z)]
         g.chan = chan[members]                        # [n_rows, Z]
         plan.groups.append(g)
-        order.append(members)
-    plan.order = np.concatenate(order)                # row permutation: grouped -> original
-    inv = np.empty_like(plan.order)
-    inv[plan.order] = np.arange(rows)
-    plan.inverse_order = inv
+    # every lattice element feeds exactly one (row, column): the data part of the operand is a permutation
+    plan.is_permutation = bool((used == 1).all())
     return plan
 
 
-class _PermuteGather(torch.autograd.Function):
-    """y = x[:, perm] for a PERMUTATION ``perm`` of x's columns: the backward is the gather with the
-    inverse permutation (deterministic, no atomic index_add)."""
+def _device_plan(plan, device):
+    L, C, Z = plan.lattice_size, plan.C, plan.Z
+    dev = _Plan()
+    dev.rows, dev.feat, dev.lattice_size, dev.C, dev.Z = plan.rows, plan.feat, L, C, Z
+    dev.groups = []
+    off = 0
 
-    @staticmethod
-    def forward(ctx, x, perm, inv_perm):
-        ctx.save_for_backward(inv_perm)
-        return x.index_select(1, perm)
-
-    @staticmethod
-    def backward(ctx, g):
-        inv_perm, = ctx.saved_tensors
-        return g.index_select(1, inv_perm), None, None
-
-
-class _PermuteRows(torch.autograd.Function):
-    """y = x.index_select(2, perm) for a permutation; backward = index_select with its inverse."""
-
-    @staticmethod
-    def forward(ctx, x, perm, inv_perm):
-        ctx.save_for_backward(inv_perm)
-        return x.index_select(2, perm)
-
-    @staticmethod
-    def backward(ctx, g):
-        inv_perm, = ctx.saved_tensors
-        return g.index_select(2, inv_perm), None, None
-
-
-def permute_rows(x, perm, inv_perm):
-    return _PermuteRows.apply(x, perm, inv_perm)
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(device)
+    for g in plan.groups:
+        d = _Plan()
+        d.n_rows, d.n_cols = g.gather.shape
+        d.k_aug = (d.n_cols + Z + 1 + 7) // 8 * 8
+        # operand columns: data | b_up[chan(row,k)] k<Z | 1 | zero padding, as indices into
+        # lat_aug = [lattice (L), up_bias (C), 1, 0]
+        idx = np.full((d.n_rows, d.k_aug), L + C + 1, dtype=np.int64)
+        idx[:, :d.n_cols] = g.gather
+        idx[:, d.n_cols:d.n_cols + Z] = L + g.chan
+        idx[:, d.n_cols + Z] = L + C
+        d.gather_aug = t(idx.reshape(-1))
+        d.scatter = t(g.gather.reshape(-1))           # lattice position of every data element
+        d.cols = t(g.cols)
+        d.ncols_by_token = [t(n) for n in g.ncols_by_token]
+        d.chan = t(g.chan.reshape(-1))
+        d.members = g.rows
+        d.offset = off
+        off += d.n_rows
+        dev.groups.append(d)
+    dev._row_index = {}
+    return dev
 
 
 def get_plan(C, Z, Hf, Wf, device):
@@ -117,61 +122,113 @@ def get_plan(C, Z, Hf, Wf, device):
         if host_key not in _PLAN_CACHE:
             _PLAN_CACHE[host_key] = _build_plan(C, Z, Hf, Wf)
         plan = _PLAN_CACHE[host_key]
-        if plan is None:
-            _PLAN_CACHE[key] = None
-        else:
-            dev = _Plan()
-            dev.rows, dev.feat, dev.lattice_size = plan.rows, plan.feat, plan.lattice_size
-            dev.groups = []
-            for g in plan.groups:
-                d = _Plan()
-                d.n_rows, d.n_cols = g.gather.shape
-                d.gather = torch.from_numpy(g.gather.reshape(-1).astype(np.int64)).to(device)
-                d.cols = torch.from_numpy(g.cols.astype(np.int64)).to(device)
-                d.ncols_by_token = [torch.from_numpy(n.astype(np.int64)).to(device) for n in g.ncols_by_token]
-                d.chan = torch.from_numpy(g.chan.astype(np.int64)).to(device)
-                dev.groups.append(d)
-            dev.inverse_order = torch.from_numpy(plan.inverse_order.astype(np.int64)).to(device)
-            dev.order = torch.from_numpy(plan.order.astype(np.int64)).to(device)
-            perm = np.concatenate([g.gather.reshape(-1) for g in plan.groups]).astype(np.int64)
-            dev.is_permutation = perm.size == plan.lattice_size and np.array_equal(np.sort(perm), np.arange(perm.size))
-            if dev.is_permutation:
-                inv = np.empty_like(perm)
-                inv[perm] = np.arange(perm.size)
-                dev.perm = torch.from_numpy(perm).to(device)
-                dev.inv_perm = torch.from_numpy(inv).to(device)
-            _PLAN_CACHE[key] = dev
+        _PLAN_CACHE[key] = None if (plan is None or not plan.is_permutation) else _device_plan(plan, device)
     return _PLAN_CACHE[key]
+
+
+def _row_index(plan, bs, device):
+    """[bs * rows]: buffer row of (sample b, position q = a*Wf + b') and its inverse."""
+    if bs not in plan._row_index:
+        fwd = np.empty((bs, plan.rows), dtype=np.int64)
+        for g in plan.groups:
+            fwd[:, g.members] = bs * g.offset + np.arange(bs)[:, None] * g.n_rows + np.arange(g.n_rows)[None, :]
+        fwd = fwd.reshape(-1)
+        inv = np.empty_like(fwd)
+        inv[fwd] = np.arange(fwd.size)
+        plan._row_index[bs] = (torch.from_numpy(fwd).to(device), torch.from_numpy(inv).to(device))
+    return plan._row_index[bs]
+
+
+class _OccProjLattice(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, e, up_bias, weight, bias, plan):
+        bs, Z, Hl, Wl, C = e.shape
+        dt = e.dtype
+        out_dim = weight.shape[0]
+        L = plan.lattice_size
+        lat = torch.empty(bs, L + C + 2, dtype=dt, device=e.device)
+        lat[:, :L].view(bs, C, Z, Hl, Wl).copy_(e.permute(0, 4, 1, 2, 3))     # channel-first lattice
+        lat[:, L:L + C] = up_bias.to(dt)
+        lat[:, L + C] = 1
+        lat[:, L + C + 1] = 0
+        w = weight.to(dt)
+        out = torch.empty(bs * plan.rows, out_dim, dtype=dt, device=e.device)
+        operands, weights = [], []
+        for g in plan.groups:
+            a = lat.index_select(1, g.gather_aug).view(bs * g.n_rows, g.k_aug)
+            # W_aug^T [out, k_aug] = data columns | summed constant columns per token | bias | 0
+            s = torch.stack([weight.index_select(1, n).sum(1) for n in g.ncols_by_token], 1)      # [out, Z] fp32
+            pad = g.k_aug - g.n_cols - Z - 1
+            wa = torch.cat([w.index_select(1, g.cols), s.to(dt), bias.to(dt)[:, None],
+                            w.new_zeros(out_dim, pad)], 1)
+            torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
+            operands.append(a)
+            weights.append(wa)
+        ctx.plan, ctx.shape = plan, (bs, Z, Hl, Wl, C)
+        ctx.save_for_backward(weight, *operands, *weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        bs, Z, Hl, Wl, C = ctx.shape
+        weight = ctx.saved_tensors[0]
+        ng = len(plan.groups)
+        operands, weights = ctx.saved_tensors[1:1 + ng], ctx.saved_tensors[1 + ng:]
+        grad_out = grad_out.contiguous()
+        dt = grad_out.dtype
+        acc = torch.float64 if dt == torch.float64 else torch.float32       # parameter gradients
+        d_lat = torch.empty(bs, plan.lattice_size, dtype=dt, device=grad_out.device)
+        d_weight = torch.zeros(weight.shape, dtype=acc, device=weight.device)
+        d_bias = torch.zeros(weight.shape[0], dtype=acc, device=weight.device)
+        d_up = torch.zeros(C, dtype=acc, device=weight.device)
+        for g, a, wa in zip(plan.groups, operands, weights):
+            go = grad_out[bs * g.offset: bs * (g.offset + g.n_rows)]
+            # d(operand): data columns go back to their lattice positions (each written exactly once)
+            d_data = torch.mm(go, wa[:, :g.n_cols])                                  # [bs*n_rows, n_cols]
+            d_lat.index_copy_(1, g.scatter, d_data.view(bs, g.n_rows * g.n_cols))
+            d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())         # [bs*n_rows, Z]
+            d_up.index_add_(0, g.chan, d_const.view(bs, -1).sum(0, dtype=acc))
+            # d(W_aug^T) = go^T a
+            d_wa = torch.mm(go.t(), a).to(acc)                                       # [out, k_aug]
+            d_weight.index_add_(1, g.cols, d_wa[:, :g.n_cols])
+            for k, n in enumerate(g.ncols_by_token):
+                d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]
+            d_bias += d_wa[:, g.n_cols + Z]
+        d_e = d_lat.view(bs, C, Z, Hl, Wl).permute(0, 2, 3, 4, 1)
+        return d_e, d_up, d_weight, d_bias, None
+
+
+class _SelectRows(torch.autograd.Function):
+    """y = x.index_select(0, perm) for a permutation; backward = index_select with its inverse."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return x.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv_perm, = ctx.saved_tensors
+        return g.index_select(0, inv_perm), None, None
 
 
 def occ_proj_from_lattice(e, up_bias, weight, bias):
     """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C]; up_bias: bias of
     the last ConvTranspose3d [C]; weight [out, Z*C], bias [out] of ``occ_proj``.
-    Returns ``(out_grouped [bs, Hf*Wf, out], inverse_order, order)`` with
-    ``out_grouped.index_select(1, inverse_order).view(bs, Hf, Wf, out)`` equal to what
-    ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` returns -- or None when the
-    geometry has no whole-token structure (the caller then takes the dense path)."""
+    Returns ``(rows [bs*Hf*Wf, out] in group-major order, plan)`` -- ``rows_to_voxels`` maps
+    anything computed row-wise from it to the (a, b) order of
+    ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` -- or None when the geometry has
+    no whole-token structure (the caller then takes the dense path)."""
     bs, Z, Hl, Wl, C = e.shape
     plan = get_plan(C, Z, 2 * Hl, 2 * Wl, e.device)
     if plan is None:
         return None
-    dt = e.dtype
-    lat = e.permute(0, 4, 1, 2, 3).reshape(bs, -1)                    # channel-first lattice, flat
-    w = weight.to(dt)
-    outs = []
-    a_all = _PermuteGather.apply(lat, plan.perm, plan.inv_perm) if plan.is_permutation else None
-    off = 0
-    for g in plan.groups:
-        if a_all is not None:
-            a = a_all[:, off:off + g.n_rows * g.n_cols].reshape(bs * g.n_rows, g.n_cols)
-            off += g.n_rows * g.n_cols
-        else:
-            a = lat.index_select(1, g.gather).view(bs * g.n_rows, g.n_cols)
-        wsel = w.index_select(1, g.cols)                              # [out, n_cols]
-        # constant part: sum_k b_up[chan[row,k]] * sum_{non-data cols of token k} W[:, col]
-        s = torch.stack([weight.index_select(1, n).sum(1) for n in g.ncols_by_token])     # [Z, out] fp32
-        const = torch.addmm(bias, up_bias[g.chan], s).to(dt)          # [n_rows, out]
-        o = (a @ wsel.t()).view(bs, g.n_rows, -1) + const[None]
-        outs.append(o)
-    # rows are in group order; ``inverse_order`` maps them back to (a, b) = a*Wf + b
-    return torch.cat(outs, dim=1), plan.inverse_order, plan.order
+    return _OccProjLattice.apply(e, up_bias, weight, bias, plan), plan
+
+
+def rows_to_voxels(x, plan, bs):
+    """x [bs*Hf*Wf, ...] in the group-major row order -> [bs, Hf*Wf, ...] in (a, b) order."""
+    fwd, inv = _row_index(plan, bs, x.device)
+    return _SelectRows.apply(x, fwd, inv).view(bs, plan.rows, *x.shape[1:])

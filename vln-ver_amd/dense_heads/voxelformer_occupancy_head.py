@@ -26,7 +26,7 @@ from . import coders, losses  # noqa: F401  (registers NMSFreeCoder / FocalLoss 
 from .assigner import SamplingResult, build_assigner
 from .coders import normalize_bbox
 from ..ddp import reduce_mean
-from .occ_proj_lattice import occ_proj_from_lattice, permute_rows
+from .occ_proj_lattice import occ_proj_from_lattice, rows_to_voxels
 from .row_linear import row_linear
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
@@ -206,12 +206,12 @@ class VoxelFormerOccupancyHead(BaseModule):
                 res = occ_proj_from_lattice(e, convs[-1].bias, self.occ_proj.weight, self.occ_proj.bias)
                 if res is not None:
                     # ``occ_branches`` is row-wise: run it on the rows as the GEMMs left them
-                    # ([bs, (a,b) grouped, Z, dims]) and bring only the 8x narrower logits into the
-                    # reference's (Z, X, Y) voxel order (:572-579)
-                    grouped, inv, order = res
-                    logits = self._occ_mlp(grouped.view(bs, grouped.shape[1], self.occ_zdim, self.occ_dims))
-                    logits = permute_rows(logits.permute(0, 2, 1, 3), inv, order)
-                    return logits.reshape(bs, -1, logits.shape[-1])
+                    # (group-major) and bring only the 8x narrower logits into the reference's
+                    # (Z, X, Y) voxel order (:572-579)
+                    rows, plan = res
+                    logits = self._occ_mlp(rows.view(rows.shape[0], self.occ_zdim, self.occ_dims))
+                    logits = rows_to_voxels(logits, plan, bs)                       # [bs, X*Y, Z, classes]
+                    return logits.permute(0, 2, 1, 3).reshape(bs, -1, logits.shape[-1])
             x = self._upsample(x).contiguous()
             x = x.view(bs, self.bev_z, self.occ_xdim, self.occ_ydim, c)              # raw view :564
             ox, oy = self.occ_xdim, self.occ_ydim

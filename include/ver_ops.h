@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 9
+#define VER_ABI_VERSION 10
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -182,6 +182,18 @@ int ver_lattice_im2col(const void* src, void* col, const int* taps, int ntaps,
                        int B, int Z, int H, int W, int C, int dtype, void* stream);
 int ver_lattice_col2im(const void* grad_col, void* grad_src, const int* taps, int ntaps,
                        int B, int Z, int H, int W, int C, int dtype, void* stream);
+
+/* Generalised lattice gather / scatter used by the parity-class upsample layers: tap t of row r goes
+ * to col[r * col_stride + col_offset[t] .. + C) (elements; offsets and stride multiples of 16
+ * bytes; columns between tap blocks are left untouched -- the caller keeps constant-pattern columns
+ * there); ntaps <= 32.  planar != 0: src / grad_src are four planes [B,Z,H/2,W/2,C] (plane 2*pm+pn
+ * holds the positions (2y'+pm, 2x'+pn)) of the combined (H, W) lattice the rows enumerate.
+ */
+int ver_lattice_gather(const void* src, void* col, const int* taps, const long* col_offset, long col_stride,
+                       int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype, void* stream);
+int ver_lattice_scatter(const void* grad_col, void* grad_src, const int* taps, const long* col_offset,
+                        long col_stride, int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused LayerNorm(128) + ReLU of the occupancy MLP (`occ_branches`, layers 1-2 and 4-5:

@@ -348,6 +348,31 @@ def test_lattice_im2col_and_adjoint(dtype):
     assert ed.grad.dtype == dtype
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('planar', [False, True])
+def test_lattice_gather_scatter_with_offsets(dtype, planar):
+    """ver_lattice_gather / _scatter (27 taps at per-tap column offsets, plain or planar source) vs
+    the slice-based torch form used on CPU; columns between the tap blocks stay untouched."""
+    ups = pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(21)
+    b, z, hc, wc, c = 2, 4, 6, 4, 16
+    kt = 27 * c + 4 * ups._PW
+    src = torch.randn(b, z, hc, wc, c, generator=gen).to(dtype)
+    e_cpu = ups.plain_to_planar(src).contiguous() if planar else src
+    a_cpu = torch.full((b * z * hc * wc, kt), 7.0, dtype=dtype)
+    ups._gather27(e_cpu, planar, a_cpu, c, hc, wc)
+    a_gpu = torch.full((b * z * hc * wc, kt), 7.0, dtype=dtype, device=DEV)
+    ups._gather27(e_cpu.to(DEV), planar, a_gpu, c, hc, wc)
+    assert torch.equal(a_gpu.cpu(), a_cpu)                                  # pure data movement: bit-exact
+    assert float((a_cpu == 7.0).sum()) >= b * z * hc * wc * 4 * ups._PW     # constant blocks untouched
+    d_a = torch.randn(b * z * hc * wc, kt, generator=gen).to(dtype)
+    want = ups._scatter27(d_a.double(), planar, tuple(e_cpu.shape), c, hc, wc)
+    got = ups._scatter27(d_a.to(DEV), planar, tuple(e_cpu.shape), c, hc, wc)
+    assert got.shape == e_cpu.shape and got.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    assert close(got.float().cpu(), want, atol=tol, rtol=tol)
+
+
 def test_upsample_on_gpu_matches_conv_transpose():
     up = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(6)

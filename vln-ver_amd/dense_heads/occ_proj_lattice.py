@@ -143,12 +143,22 @@ class _OccProjLattice(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, up_bias, weight, bias, plan):
-        bs, Z, Hl, Wl, C = e.shape
+        planar = e.dim() == 6                            # [4,bs,Z,Hl/2,Wl/2,C], plane 2pm+pn = (2y+pm, 2x+pn)
+        if planar:
+            _, bs, Z, hh, wh, C = e.shape
+            Hl, Wl = 2 * hh, 2 * wh
+        else:
+            bs, Z, Hl, Wl, C = e.shape
         dt = e.dtype
         out_dim = weight.shape[0]
         L = plan.lattice_size
         lat = torch.empty(bs, L + C + 2, dtype=dt, device=e.device)
-        lat[:, :L].view(bs, C, Z, Hl, Wl).copy_(e.permute(0, 4, 1, 2, 3))     # channel-first lattice
+        lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                                # channel-first lattice
+        if planar:
+            for p in range(4):
+                lat5[:, :, :, p >> 1::2, p & 1::2].copy_(e[p].permute(0, 4, 1, 2, 3))
+        else:
+            lat5.copy_(e.permute(0, 4, 1, 2, 3))
         lat[:, L:L + C] = up_bias.to(dt)
         lat[:, L + C] = 1
         lat[:, L + C + 1] = 0
@@ -165,7 +175,7 @@ class _OccProjLattice(torch.autograd.Function):
             torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
             operands.append(a)
             weights.append(wa)
-        ctx.plan, ctx.shape = plan, (bs, Z, Hl, Wl, C)
+        ctx.plan, ctx.shape, ctx.planar = plan, (bs, Z, Hl, Wl, C), planar
         ctx.save_for_backward(weight, *operands, *weights)
         return out
 
@@ -196,7 +206,13 @@ class _OccProjLattice(torch.autograd.Function):
             for k, n in enumerate(g.ncols_by_token):
                 d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]
             d_bias += d_wa[:, g.n_cols + Z]
-        d_e = d_lat.view(bs, C, Z, Hl, Wl).permute(0, 2, 3, 4, 1)
+        d5 = d_lat.view(bs, C, Z, Hl, Wl)
+        if ctx.planar:
+            d_e = d_lat.new_empty(4, bs, Z, Hl // 2, Wl // 2, C)
+            for p in range(4):
+                d_e[p].copy_(d5[:, :, :, p >> 1::2, p & 1::2].permute(0, 2, 3, 4, 1))
+        else:
+            d_e = d5.permute(0, 2, 3, 4, 1)
         return d_e, d_up, d_weight, d_bias, None
 
 
@@ -215,13 +231,18 @@ class _SelectRows(torch.autograd.Function):
 
 
 def occ_proj_from_lattice(e, up_bias, weight, bias):
-    """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C]; up_bias: bias of
+    """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C] or planar
+    [4, bs, Z, Hl/2, Wl/2, C]; up_bias: bias of
     the last ConvTranspose3d [C]; weight [out, Z*C], bias [out] of ``occ_proj``.
     Returns ``(rows [bs*Hf*Wf, out] in group-major order, plan)`` -- ``rows_to_voxels`` maps
     anything computed row-wise from it to the (a, b) order of
     ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` -- or None when the geometry has
     no whole-token structure (the caller then takes the dense path)."""
-    bs, Z, Hl, Wl, C = e.shape
+    if e.dim() == 6:                                     # planar lattice from the upsample
+        _, bs, Z, hh, wh, C = e.shape
+        Hl, Wl = 2 * hh, 2 * wh
+    else:
+        bs, Z, Hl, Wl, C = e.shape
     plan = get_plan(C, Z, 2 * Hl, 2 * Wl, e.device)
     if plan is None:
         return None

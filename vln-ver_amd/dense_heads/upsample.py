@@ -104,31 +104,236 @@ def _layer0(e, k, bias):
     return out.view(b, z, h, w, -1)
 
 
-def _layer_lattice(e, k, bias, prev_bias):
-    """e = data lattice [B,Z,H,W,C] of a full input of size (Z,2H,2W) that equals ``prev_bias``
-    off the lattice -> output lattice [B,Z,2H,2W,Co]."""
-    b, z, h, w, c = e.shape
-    co = k.shape[-1]
-    # constant taps: pattern [Z*2H*2W, 75] @ (K[tap]^T prev_bias) [75, Co], bias folded in
-    # (a [75]-batch of 1-row GEMMs; a single fp32 gemv over the raw weight measured slower end to end
-    # because its backward materialises a dense fp32 outer product per layer)
-    v = torch.matmul(prev_bias, k)                                       # [75, Co]
-    const = torch.addmm(bias, _constant_pattern(z, 2 * h, 2 * w, e.device, e.dtype), v)   # [.., Co]
-    const = const.view(z, 2 * h, 2 * w, co)
-    out = e.new_empty(b, z, 2 * h, 2 * w, co)
-    for pm in (0, 1):
-        bs_ = [bb for bb in range(5) if (pm + bb) % 2 == 0]
-        for pn in (0, 1):
-            cs_ = [cc for cc in range(5) if (pn + cc) % 2 == 0]
-            # lattice row of tap b for output row m = 2m'+pm:  m' - 1 + (pm+b)/2
-            taps = [(2 * a - 2, (pm + bb) // 2 - 1, (pn + cc) // 2 - 1)
-                    for a in range(3) for bb in bs_ for cc in cs_]
-            ids = [(a * 5 + bb) * 5 + cc for a in range(3) for bb in bs_ for cc in cs_]
-            ksub = k.index_select(0, _tap_index(ids, k.device))
-            a_mat = _im2col(e, taps)
-            res = (a_mat @ ksub.reshape(-1, co)).view(b, z, h, w, co)
-            out[:, :, pm::2, pn::2, :] = res + const[None, :, pm::2, pn::2, :]
+# ------------------------------------------------------------------------------------------------
+# Parity-class layer (layers 1 and 2 of the stack) as ONE autograd Function.
+#
+# All four output classes (pm, pn) read taps of the same 3x3x3 neighbourhood (dz in {-2,0,2}, dy, dx
+# in {-1,0,1}) of the input lattice: class pn=1 only dx in {0,1}, pm=1 only dy in {0,1}.  So ONE
+# 27-tap matrix A [B*Z*H*W, Kt] serves the four classes, each as a few column ranges (27 instead of
+# 75 tap blocks are written / read back).  Block order is (dx, dy, dz); between the dx groups sit
+# four 80-wide constant blocks P_class = [75 0/1 pattern columns | 1 | 0 0 0 0] whose weight rows are
+# (K[tap]^T prev_bias | bias): the bias-valued odd positions of the input and the layer bias ride in
+# the same GEMM.  Layout of a row (C = channels):
+#     [P00 | b0..b8 | P10 | b9..b17 | P11 | b18..b26 | P01]
+#   class (0,0): everything but P01 in one range (P10, P11 meet zero weight rows)
+#   class (0,1): b9.. to the end in one range         class (1,0): [b3..b8 P10], b12..b17, b21..b26
+#   class (1,1): [b12..b17 P11], b21..b26
+# Every class GEMM writes its own contiguous output plane: the result is PLANAR [4,B,Z,H,W,Co]
+# (plane 2pm+pn = positions (2y+pm, 2x+pn) of the (2H, 2W) lattice) and is consumed as such by the
+# next layer's gather kernel and by occ_proj -- the lattice is never interleaved.
+_PW = 80                                             # width of a constant block
+_CLASSES = ((0, 0), (0, 1), (1, 0), (1, 1))
+
+
+def _block_offset(t, c):
+    return _PW * (1 + t // 9) + t * c
+
+
+def _const_offset(pm, pn, c):
+    return {(0, 0): 0, (1, 0): _PW + 9 * c, (1, 1): 2 * _PW + 18 * c, (0, 1): 3 * _PW + 27 * c}[(pm, pn)]
+
+
+def _tap27():
+    """(dz, dy, dx) of block t = (dxi*3 + dyi)*3 + dzi."""
+    return [(2 * dzi - 2, dyi - 1, dxi - 1) for dxi in range(3) for dyi in range(3) for dzi in range(3)]
+
+
+def _class_tap_id(pm, pn, t):
+    """id in the 75-tap correlation kernel of block t for class (pm, pn), or None."""
+    dxi, dyi, dzi = t // 9, (t // 3) % 3, t % 3
+    bb, cc = 2 * dyi - pm, 2 * dxi - pn
+    if 0 <= bb < 5 and 0 <= cc < 5:
+        return (dzi * 5 + bb) * 5 + cc
+    return None
+
+
+_LAYER_PLAN = {}
+
+
+def _layer_plan(ci, device):
+    """Per class: list of (col_start, col_end, row index into the stacked weight rows
+    [75*ci data | 4*80 own-constant | 3*80 dummy zero])."""
+    key = (ci, str(device))
+    if key in _LAYER_PLAN:
+        return _LAYER_PLAN[key]
+    kt = 27 * ci + 4 * _PW
+    n_data = 75 * ci
+    dummy = [n_data + 4 * _PW]                      # next free dummy row (mutable)
+
+    def seg_rows(pm, pn, seg):
+        kind, val = seg
+        if kind == 'b':
+            tid = _class_tap_id(pm, pn, val)
+            assert tid is not None
+            return np.arange(tid * ci, (tid + 1) * ci)
+        if val == (pm, pn):                          # own constant block
+            p = _CLASSES.index(val)
+            return np.arange(n_data + p * _PW, n_data + (p + 1) * _PW)
+        r = np.arange(dummy[0], dummy[0] + _PW)      # foreign constant block: zero rows
+        dummy[0] += _PW
+        return r
+    b = lambda lo, hi: [('b', t) for t in range(lo, hi)]
+    layout = {
+        (0, 0): [[('c', (0, 0))] + b(0, 9) + [('c', (1, 0))] + b(9, 18) + [('c', (1, 1))] + b(18, 27)],
+        (0, 1): [b(9, 18) + [('c', (1, 1))] + b(18, 27) + [('c', (0, 1))]],
+        (1, 0): [b(3, 9) + [('c', (1, 0))], b(12, 18), b(21, 27)],
+        (1, 1): [b(12, 18) + [('c', (1, 1))], b(21, 27)],
+    }
+    plan = {}
+    for (pm, pn), ranges in layout.items():
+        out = []
+        for segs in ranges:
+            first = segs[0]
+            c0 = _block_offset(first[1], ci) if first[0] == 'b' else _const_offset(*first[1], ci)
+            rows = np.concatenate([seg_rows(pm, pn, sg) for sg in segs])
+            out.append((c0, c0 + len(rows), torch.from_numpy(rows.astype(np.int64)).to(device)))
+        plan[(pm, pn)] = out
+    total_rows = dummy[0]
+    assert total_rows == n_data + 7 * _PW
+    _LAYER_PLAN[key] = (plan, kt, total_rows)
+    return _LAYER_PLAN[key]
+
+
+_CLASS_PATTERN = {}
+
+
+def _class_patterns(z, h, w, device, dtype):
+    """[4][Z*H*W, 80]: constant-block columns of class p for an input lattice (Z,H,W)."""
+    key = (z, h, w, str(device), dtype)
+    if key not in _CLASS_PATTERN:
+        full = _constant_pattern(z, 2 * h, 2 * w, device, dtype).view(z, 2 * h, 2 * w, 75)
+        pats = []
+        for pm, pn in _CLASSES:
+            p = full.new_zeros(z, h, w, _PW)
+            p[..., :75] = full[:, pm::2, pn::2]
+            p[..., 75] = 1
+            pats.append(p.view(z * h * w, _PW))
+        _CLASS_PATTERN[key] = pats
+    return _CLASS_PATTERN[key]
+
+
+def planar_to_plain(e):
+    """[4,B,Z,H,W,C] (plane 2pm+pn = positions (2y+pm, 2x+pn)) -> [B,Z,2H,2W,C]."""
+    _, b, z, h, w, c = e.shape
+    out = e.new_empty(b, z, 2 * h, 2 * w, c)
+    for p, (pm, pn) in enumerate(_CLASSES):
+        out[:, :, pm::2, pn::2] = e[p]
     return out
+
+
+def plain_to_planar(e):
+    return torch.stack([e[:, :, pm::2, pn::2] for pm, pn in _CLASSES])
+
+
+def _gather27(e, planar, a_mat, ci, hc, wc):
+    taps = _tap27()
+    offs = [_block_offset(t, ci) for t in range(27)]
+    if e.is_cuda:
+        from ..hipops import lattice_gather
+        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), planar)
+        return
+    src = planar_to_plain(e) if planar else e
+    b, z = src.shape[:2]
+    pad = F.pad(src, (0, 0, 1, 1, 1, 1, 2, 2))
+    view = a_mat.view(b, z, hc, wc, -1)
+    for (dz, dy, dx), o in zip(taps, offs):
+        view[..., o:o + ci] = pad[:, 2 + dz:2 + dz + z, 1 + dy:1 + dy + hc, 1 + dx:1 + dx + wc]
+
+
+def _scatter27(d_a, planar, shape, ci, hc, wc):
+    """adjoint of _gather27: gradient of the source lattice (plain or planar like the source)."""
+    taps = _tap27()
+    offs = [_block_offset(t, ci) for t in range(27)]
+    if d_a.is_cuda:
+        from ..hipops import lattice_scatter
+        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), planar)
+    b, z = (shape[1], shape[2]) if planar else (shape[0], shape[1])
+    pad = d_a.new_zeros(b, z + 4, hc + 2, wc + 2, ci)
+    view = d_a.view(b, z, hc, wc, -1)
+    for (dz, dy, dx), o in zip(taps, offs):
+        pad[:, 2 + dz:2 + dz + z, 1 + dy:1 + dy + hc, 1 + dx:1 + dx + wc] += view[..., o:o + ci]
+    plain = pad[:, 2:2 + z, 1:1 + hc, 1:1 + wc]
+    return plain_to_planar(plain).contiguous() if planar else plain.contiguous()
+
+
+class _LatticeLayer(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, e, k, bias, prev_bias, planar):
+        """e: input lattice, plain [B,Z,H,W,C] or planar [4,B,Z,H/2,W/2,C]; k [75,Ci,Co] correlation
+        taps; -> planar output [4,B,Z,H,W,Co]."""
+        if planar:
+            _, b, z, hh, wh, ci = e.shape
+            hc, wc = 2 * hh, 2 * wh
+        else:
+            b, z, hc, wc, ci = e.shape
+        co = k.shape[-1]
+        dt = e.dtype
+        plan, kt, total_rows = _layer_plan(ci, e.device)
+        m = b * z * hc * wc
+        a_mat = e.new_empty(m, kt)
+        _gather27(e, planar, a_mat, ci, hc, wc)
+        pats = _class_patterns(z, hc, wc, e.device, dt)
+        a3 = a_mat.view(b, z * hc * wc, kt)
+        for (pm, pn), pat in zip(_CLASSES, pats):
+            o = _const_offset(pm, pn, ci)
+            a3[:, :, o:o + _PW] = pat
+        # stacked weight rows: 75 tap blocks | per class (K^T prev_bias | bias | 0) | zero rows
+        v = torch.matmul(prev_bias.to(dt), k)                                     # [75, Co]
+        vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
+        rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug, v.new_zeros(3 * _PW, co)])
+        assert rows.shape[0] == total_rows
+        out = e.new_empty(4, m, co)
+        for p, cls in enumerate(_CLASSES):
+            for i, (c0, c1, ridx) in enumerate(plan[cls]):
+                w = rows.index_select(0, ridx)
+                if i == 0:
+                    torch.mm(a_mat[:, c0:c1], w, out=out[p])
+                else:
+                    torch.addmm(out[p], a_mat[:, c0:c1], w, out=out[p])
+        ctx.save_for_backward(a_mat, rows, k, prev_bias)
+        ctx.geom = (planar, tuple(e.shape), b, z, hc, wc, ci, co)
+        return out.view(4, b, z, hc, wc, co)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a_mat, rows, k, prev_bias = ctx.saved_tensors
+        planar, e_shape, b, z, hc, wc, ci, co = ctx.geom
+        plan, kt, total_rows = _layer_plan(ci, a_mat.device)
+        dt = a_mat.dtype
+        m = a_mat.shape[0]
+        g = grad_out.contiguous().view(4, m, co)
+        d_a = a_mat.new_empty(m, kt)
+        d_a[:, kt - _PW:] = 0                                   # P01 is outside class (0,0)'s range
+        d_rows = rows.new_empty(total_rows, co)
+        first = True
+        for p, cls in enumerate(_CLASSES):
+            for c0, c1, ridx in plan[cls]:
+                w = rows.index_select(0, ridx)
+                if first:                                       # class (0,0): initialises every tap block
+                    torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
+                    first = False
+                else:
+                    torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
+                d_rows.index_copy_(0, ridx, torch.mm(a_mat[:, c0:c1].t(), g[p]))
+        d_e = _scatter27(d_a, planar, e_shape, ci, hc, wc)
+        n_data = 75 * ci
+        d_k = d_rows[:n_data].view(75, ci, co)
+        d_vaug = d_rows[n_data:n_data + 4 * _PW].view(4, _PW, co).sum(0, dtype=torch.float32 if dt != torch.float64
+                                                                      else torch.float64)
+        d_v = d_vaug[:75].to(dt)
+        d_bias = d_vaug[75]
+        # v = prev_bias @ k
+        pb = prev_bias.to(dt)
+        d_k = torch.addcmul(d_k, pb[None, :, None], d_v[:, None, :])
+        d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
+        return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None
+
+
+def _layer_lattice(e, k, bias, prev_bias, planar):
+    """e = data lattice (plain [B,Z,H,W,C] or planar) of a full input that equals ``prev_bias`` off
+    the lattice -> planar output lattice [4,B,Z,H,W,Co] (H, W = combined size of the input)."""
+    return _LatticeLayer.apply(e, k, bias, prev_bias, planar)
 
 
 def _compute_dtype(x):
@@ -140,20 +345,24 @@ def _compute_dtype(x):
 
 
 def upsample_lattice(x0, weights, biases):
-    """x0 [B,C,Z,H,W] -> (E_3 channels-last [B,Z,4H,4W,C], last bias).  E_3 holds the even
-    positions of the reference's dense output ``up_sample(x0)`` [B,C,Z,8H,8W]."""
+    """x0 [B,C,Z,H,W] -> (E_3 PLANAR [4,B,Z,2H,2W,C], last bias).  E_3 holds the even positions of
+    the reference's dense output ``up_sample(x0)`` [B,C,Z,8H,8W] (``planar_to_plain`` gives the
+    channels-last [B,Z,4H,4W,C] lattice)."""
     dt = _compute_dtype(x0)
     e = x0.permute(0, 2, 3, 4, 1).to(dt)
     ks = [_corr_weight(w, dt) for w in weights]
     bs = [b.to(dt) for b in biases]
     e = _layer0(e, ks[0], bs[0])
-    e = _layer_lattice(e, ks[1], bs[1], bs[0])
-    e = _layer_lattice(e, ks[2], bs[2], bs[1])
+    e = _layer_lattice(e, ks[1], bs[1], bs[0], planar=False)
+    e = _layer_lattice(e, ks[2], bs[2], bs[1], planar=True)
     return e, bs[2]
 
 
 def full_volume(e, bias):
-    """Even lattice [B,Z,H,W,C] + bias -> dense [B,C,Z,2H,2W] (odd rows/cols = bias)."""
+    """Even lattice (plain [B,Z,H,W,C] or planar [4,B,Z,H/2,W/2,C]) + bias -> dense [B,C,Z,2H,2W]
+    (odd rows/cols = bias)."""
+    if e.dim() == 6:
+        e = planar_to_plain(e)
     b, z, h, w, c = e.shape
     y = bias.view(1, c, 1, 1, 1).expand(b, c, z, 2 * h, 2 * w).contiguous()
     y[:, :, :, ::2, ::2] = e.permute(0, 4, 1, 2, 3)

@@ -13,13 +13,13 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
-           'ver_occ_mlp_forward', 'ver_occ_mlp_backward')
+           'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter')
 
 _lib = None
 
@@ -287,6 +287,43 @@ class LatticeIm2colFunction(Function):
 
 def lattice_im2col(lattice, taps):
     return LatticeIm2colFunction.apply(lattice, taps)
+
+
+def _tap_args(taps, col_offset):
+    flat = [int(v) for t in taps for v in t]
+    return (ctypes.c_int * len(flat))(*flat), (ctypes.c_long * len(col_offset))(*[int(o) for o in col_offset])
+
+
+def lattice_gather(src, col, taps, col_offset, combined_hw, planar):
+    """ver_lattice_gather (no autograd): src plain [B,Z,H,W,C] or planar [4,B,Z,H/2,W/2,C] ->
+    tap blocks of col [B*Z*H*W, stride] at the given column offsets."""
+    src, col = _gpu(src, 'src'), _gpu(col, 'col')
+    if not (src.is_contiguous() and col.is_contiguous() and src.dtype == col.dtype):
+        raise ValueError('lattice_gather: contiguous src / col of one dtype required')
+    H, W = combined_hw
+    B, Z, C = (src.shape[1], src.shape[2], src.shape[5]) if planar else (src.shape[0], src.shape[1], src.shape[4])
+    arr, offs = _tap_args(taps, col_offset)
+    dt = 1 if src.dtype == torch.bfloat16 else 0
+    _launch('ver_lattice_gather', lambda: lib().ver_lattice_gather(
+        _p(src), _p(col), arr, offs, ctypes.c_long(col.shape[1]), len(taps), B, Z, H, W, C, int(planar), dt,
+        _stream()))
+    return col
+
+
+def lattice_scatter(grad_col, grad_src, taps, col_offset, combined_hw, planar):
+    """ver_lattice_scatter (no autograd): the adjoint of ``lattice_gather`` into grad_src (overwritten)."""
+    grad_col, grad_src = _gpu(grad_col, 'grad_col'), _gpu(grad_src, 'grad_src')
+    if not (grad_src.is_contiguous() and grad_col.is_contiguous() and grad_src.dtype == grad_col.dtype):
+        raise ValueError('lattice_scatter: contiguous buffers of one dtype required')
+    H, W = combined_hw
+    s = grad_src.shape
+    B, Z, C = (s[1], s[2], s[5]) if planar else (s[0], s[1], s[4])
+    arr, offs = _tap_args(taps, col_offset)
+    dt = 1 if grad_src.dtype == torch.bfloat16 else 0
+    _launch('ver_lattice_scatter', lambda: lib().ver_lattice_scatter(
+        _p(grad_col), _p(grad_src), arr, offs, ctypes.c_long(grad_col.shape[1]), len(taps), B, Z, H, W, C,
+        int(planar), dt, _stream()))
+    return grad_src
 
 
 # ------------------------------------------------------------------------------------------

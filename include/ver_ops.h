@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 10
+#define VER_ABI_VERSION 11
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -194,6 +194,19 @@ int ver_lattice_gather(const void* src, void* col, const int* taps, const long* 
 int ver_lattice_scatter(const void* grad_col, void* grad_src, const int* taps, const long* col_offset,
                         long col_stride, int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype,
                         void* stream);
+
+/* Layout changes of the coarse-to-fine head (LDS-tiled transposes):
+ *   ver_convt_weight_forward : ConvTranspose3d weight f32 [pairs = Ci*Co][3*5*5] (the reference's
+ *       parameter layout, head:251-258) -> correlation taps [75][pairs] in `dtype`, tap (a,b,c) =
+ *       weight[.., 2-a, 4-b, 4-c];  _backward: gradient of the taps -> f32 gradient of the weight.
+ *   ver_lattice_transpose    : even lattice channels-last (plain [B,Z,H,W,C] or planar
+ *       4 x [B,Z,H/2,W/2,C]) <-> channel-first rows cf[b*cf_stride + ((c*Z + z)*H + y)*W + x]
+ *       (to_channel_first != 0: channels_last is read; else it is written).
+ */
+int ver_convt_weight_forward(const float* weight, void* taps, long pairs, int dtype, void* stream);
+int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pairs, int dtype, void* stream);
+int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
+                          int C, int planar, int to_channel_first, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused LayerNorm(128) + ReLU of the occupancy MLP (`occ_branches`, layers 1-2 and 4-5:

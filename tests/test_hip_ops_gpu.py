@@ -373,6 +373,35 @@ def test_lattice_gather_scatter_with_offsets(dtype, planar):
     assert close(got.float().cpu(), want, atol=tol, rtol=tol)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_convt_weight_taps_and_lattice_transpose(dtype):
+    """Layout kernels: ConvTranspose3d weight -> flipped correlation taps (and its adjoint), lattice
+    channels-last (plain / planar) <-> channel-first rows.  Pure data movement: bit-exact."""
+    hip, ups = pkg('hipops'), pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(22)
+    w = torch.randn(24, 40, 3, 5, 5, generator=gen)
+    want = w.to(dtype).flip(2, 3, 4).permute(2, 3, 4, 0, 1).reshape(75, 24, 40)
+    wd = w.to(DEV).requires_grad_(True)
+    got = hip.convt_weight_taps(wd, dtype)
+    assert torch.equal(got.detach().cpu(), want)
+    g = torch.randn(75, 24, 40, generator=gen).to(dtype)
+    got.backward(g.to(DEV))
+    want_g = g.float().view(3, 5, 5, 24, 40).permute(3, 4, 0, 1, 2).flip(2, 3, 4)
+    assert torch.equal(wd.grad.cpu(), want_g)
+    b, z, h, wl, c = 2, 3, 6, 10, 200                      # C not a multiple of the 128-channel tile
+    plain = torch.randn(b, z, h, wl, c, generator=gen).to(dtype)
+    L = c * z * h * wl
+    for planar in (False, True):
+        src = ups.plain_to_planar(plain).contiguous() if planar else plain
+        cf = torch.full((b, L + 5), 3.0, dtype=dtype, device=DEV)
+        hip.lattice_transpose(src.to(DEV), cf, (h, wl), planar, True)
+        assert torch.equal(cf[:, :L].cpu().view(b, c, z, h, wl), plain.permute(0, 4, 1, 2, 3))
+        assert bool((cf[:, L:] == 3.0).all())
+        back = torch.empty_like(src, device=DEV)
+        hip.lattice_transpose(back, cf, (h, wl), planar, False)
+        assert torch.equal(back.cpu(), src)
+
+
 def test_upsample_on_gpu_matches_conv_transpose():
     up = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(6)

@@ -1,0 +1,167 @@
+// Layout changes around the coarse-to-fine head (include/ver_ops.h: ver_convt_weight_*, ver_lattice_transpose):
+// LDS-tiled transposes, fully coalesced on the wide side.
+//
+//  * ConvTranspose3d weight [Ci,Co,3,5,5] fp32 (reference: dense_heads/voxelformer_occupancy_head.py
+//    :251-258) <-> correlation taps [75,Ci,Co] in the compute dtype, tap (a,b,c) = W[.., 2-a, 4-b, 4-c]
+//    (a transposed convolution is a correlation with the flipped kernel).  As torch ops this is a
+//    cast + flip + permuted copy per layer and step (0.6 ms each way for 44 M elements).
+//  * even lattice, channels-last (plain [B,Z,H,W,C] or planar 4x[B,Z,H/2,W/2,C]) <-> channel-first
+//    rows dst[b, ((c*Z + z)*H + y)*W + x] (row stride given): the order in which the reference's raw
+//    .view (head:564) reads the volume, consumed by the gathered occ_proj GEMMs.
+#include "ver_common.h"
+
+namespace {
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+constexpr int kTaps = 75;
+constexpr int kPairs = 64;       // (ci, co) pairs per workgroup
+}  // namespace
+
+// w [P][75] fp32 -> k [75][P] (bf16 or fp32), P = Ci*Co, tap order flipped
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_convt_weight_fwd(const float* __restrict__ w, void* __restrict__ k, long P) {
+    __shared__ float tile[kPairs * kTaps + 1];
+    const long p0 = (long)blockIdx.x * kPairs;
+    const int np = (int)((P - p0) < kPairs ? (P - p0) : kPairs);
+    for (int i = threadIdx.x; i < np * kTaps; i += 256) tile[i] = w[p0 * kTaps + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTaps * kPairs; i += 256) {
+        const int t = i / kPairs, p = i % kPairs;
+        if (p >= np) continue;
+        const int a = t / 25, b = (t / 5) % 5, c = t % 5;
+        const float v = tile[p * kTaps + ((2 - a) * 5 + (4 - b)) * 5 + (4 - c)];
+        if (BF16)
+            reinterpret_cast<uint16_t*>(k)[(long)t * P + p0 + p] = f32_to_bf16(v);
+        else
+            reinterpret_cast<float*>(k)[(long)t * P + p0 + p] = v;
+    }
+}
+
+// adjoint: dk [75][P] -> dw [P][75] fp32
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_convt_weight_bwd(const void* __restrict__ dk, float* __restrict__ dw, long P) {
+    __shared__ float tile[kPairs * kTaps + 1];
+    const long p0 = (long)blockIdx.x * kPairs;
+    const int np = (int)((P - p0) < kPairs ? (P - p0) : kPairs);
+    for (int i = threadIdx.x; i < kTaps * kPairs; i += 256) {
+        const int t = i / kPairs, p = i % kPairs;
+        if (p >= np) continue;
+        const int a = t / 25, b = (t / 5) % 5, c = t % 5;
+        float v;
+        if (BF16)
+            v = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(dk)[(long)t * P + p0 + p] << 16);
+        else
+            v = reinterpret_cast<const float*>(dk)[(long)t * P + p0 + p];
+        tile[p * kTaps + ((2 - a) * 5 + (4 - b)) * 5 + (4 - c)] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
+}
+
+// ---- lattice <-> channel-first rows.  One workgroup = one (b, z, y) row of W positions x 128 channels.
+namespace {
+constexpr int kCh = 128;
+template <bool PLANAR>
+__device__ __forceinline__ long cl_index(int b, int z, int y, int x, int B, int Z, int H, int W) {
+    if (PLANAR) {
+        const int plane = ((y & 1) << 1) | (x & 1);
+        return ((((long)plane * B + b) * Z + z) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+    }
+    return (((long)b * Z + z) * H + y) * W + x;
+}
+}  // namespace
+
+// T = 2-byte or 4-byte element.  TO_CF: channels-last -> channel-first rows; else the reverse.
+template <typename T, bool PLANAR, bool TO_CF>
+__global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T* __restrict__ cf, long cf_stride,
+                                                           int B, int Z, int H, int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* tile = reinterpret_cast<T*>(smem);                  // [kCh][W + 1]
+    const int wp = W + 1;
+    int r = blockIdx.x;
+    const int y = r % H;
+    r /= H;
+    const int z = r % Z;
+    const int b = r / Z;
+    const int c0 = blockIdx.y * kCh;
+    const int nc = (C - c0) < kCh ? (C - c0) : kCh;
+    if (TO_CF) {
+        for (int i = threadIdx.x; i < W * kCh; i += 256) {
+            const int x = i / kCh, c = i % kCh;
+            if (c < nc) tile[c * wp + x] = cl[cl_index<PLANAR>(b, z, y, x, B, Z, H, W) * C + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kCh * W; i += 256) {
+            const int c = i / W, x = i % W;
+            if (c < nc) cf[(long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y) * W + x] = tile[c * wp + x];
+        }
+    } else {
+        for (int i = threadIdx.x; i < kCh * W; i += 256) {
+            const int c = i / W, x = i % W;
+            if (c < nc) tile[c * wp + x] = cf[(long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y) * W + x];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < W * kCh; i += 256) {
+            const int x = i / kCh, c = i % kCh;
+            if (c < nc) cl[cl_index<PLANAR>(b, z, y, x, B, Z, H, W) * C + c0 + c] = tile[c * wp + x];
+        }
+    }
+}
+
+extern "C" int ver_convt_weight_forward(const float* weight, void* taps, long pairs, int dtype, void* stream) {
+    VER_REQUIRE(pairs >= 0, VER_EINVAL, "ver_convt_weight_forward: negative size");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_convt_weight_forward: dtype %d", dtype);
+    if (pairs == 0) return VER_OK;
+    VER_REQUIRE(weight && taps, VER_EINVAL, "ver_convt_weight_forward: null pointer argument");
+    const unsigned blocks = (unsigned)((pairs + kPairs - 1) / kPairs);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_convt_weight_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, taps, pairs);
+    else
+        hipLaunchKernelGGL(k_convt_weight_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, weight, taps, pairs);
+    return ver_check_launch("ver_convt_weight_forward");
+}
+
+extern "C" int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pairs, int dtype, void* stream) {
+    VER_REQUIRE(pairs >= 0, VER_EINVAL, "ver_convt_weight_backward: negative size");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_convt_weight_backward: dtype %d", dtype);
+    if (pairs == 0) return VER_OK;
+    VER_REQUIRE(grad_taps && grad_weight, VER_EINVAL, "ver_convt_weight_backward: null pointer argument");
+    const unsigned blocks = (unsigned)((pairs + kPairs - 1) / kPairs);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_convt_weight_bwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_taps,
+                           grad_weight, pairs);
+    else
+        hipLaunchKernelGGL(k_convt_weight_bwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_taps,
+                           grad_weight, pairs);
+    return ver_check_launch("ver_convt_weight_backward");
+}
+
+extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
+                                     int C, int planar, int to_channel_first, int dtype, void* stream) {
+    VER_REQUIRE(B >= 0 && Z > 0 && H > 0 && W > 0 && C > 0, VER_EINVAL, "ver_lattice_transpose: bad sizes");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_lattice_transpose: dtype %d", dtype);
+    VER_REQUIRE(!planar || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_transpose: planar needs even H, W");
+    VER_REQUIRE(cf_stride >= (long)C * Z * H * W, VER_EINVAL, "ver_lattice_transpose: row stride too small");
+    if (B == 0) return VER_OK;
+    VER_REQUIRE(channels_last && channel_first, VER_EINVAL, "ver_lattice_transpose: null pointer argument");
+    const size_t esize = dtype == VER_BF16 ? 2 : 4;
+    const size_t lds = (size_t)kCh * (W + 1) * esize;
+    VER_REQUIRE(lds <= 64 * 1024, VER_EUNSUPPORTED, "ver_lattice_transpose: W = %d too wide", W);
+    const dim3 grid((unsigned)((long)B * Z * H), (unsigned)((C + kCh - 1) / kCh));
+    hipStream_t st = (hipStream_t)stream;
+#define VER_TR(T, PL, CF)                                                                                             \
+    hipLaunchKernelGGL((k_lattice_transpose<T, PL, CF>), grid, dim3(256), lds, st, (T*)channels_last, (T*)channel_first, \
+                       cf_stride, B, Z, H, W, C)
+    if (dtype == VER_BF16) {
+        if (planar) { if (to_channel_first) VER_TR(uint16_t, true, true); else VER_TR(uint16_t, true, false); }
+        else        { if (to_channel_first) VER_TR(uint16_t, false, true); else VER_TR(uint16_t, false, false); }
+    } else {
+        if (planar) { if (to_channel_first) VER_TR(float, true, true); else VER_TR(float, true, false); }
+        else        { if (to_channel_first) VER_TR(float, false, true); else VER_TR(float, false, false); }
+    }
+#undef VER_TR
+    return ver_check_launch("ver_lattice_transpose");
+}

@@ -154,7 +154,10 @@ class _OccProjLattice(torch.autograd.Function):
         L = plan.lattice_size
         lat = torch.empty(bs, L + C + 2, dtype=dt, device=e.device)
         lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                                # channel-first lattice
-        if planar:
+        if e.is_cuda and dt in (torch.float32, torch.bfloat16):
+            from ..hipops import lattice_transpose
+            lattice_transpose(e.contiguous(), lat, (Hl, Wl), planar, True)
+        elif planar:
             for p in range(4):
                 lat5[:, :, :, p >> 1::2, p & 1::2].copy_(e[p].permute(0, 4, 1, 2, 3))
         else:
@@ -207,7 +210,11 @@ class _OccProjLattice(torch.autograd.Function):
                 d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]
             d_bias += d_wa[:, g.n_cols + Z]
         d5 = d_lat.view(bs, C, Z, Hl, Wl)
-        if ctx.planar:
+        if d_lat.is_cuda and dt in (torch.float32, torch.bfloat16):
+            from ..hipops import lattice_transpose
+            d_e = d_lat.new_empty((4, bs, Z, Hl // 2, Wl // 2, C) if ctx.planar else (bs, Z, Hl, Wl, C))
+            lattice_transpose(d_e, d_lat, (Hl, Wl), ctx.planar, False)
+        elif ctx.planar:
             d_e = d_lat.new_empty(4, bs, Z, Hl // 2, Wl // 2, C)
             for p in range(4):
                 d_e[p].copy_(d5[:, :, :, p >> 1::2, p & 1::2].permute(0, 2, 3, 4, 1))

@@ -40,6 +40,9 @@ def _corr_weight(weight, dtype):
     tensor in the compute dtype, tap index = (a*5+b)*5+c, K[a,b,c] = Wt[:, :, 2-a, 4-b, 4-c]
     (one cast + one gather kernel; the per-class tap subsets below are index_select's of it)."""
     ci, co = weight.shape[:2]
+    if weight.is_cuda and weight.dtype == torch.float32 and dtype in (torch.float32, torch.bfloat16):
+        from ..hipops import convt_weight_taps
+        return convt_weight_taps(weight, dtype)                       # one LDS-tiled transpose each way
     return weight.to(dtype).flip(2, 3, 4).permute(2, 3, 4, 0, 1).reshape(75, ci, co)
 
 
@@ -109,15 +112,16 @@ def _layer0(e, k, bias):
 #
 # All four output classes (pm, pn) read taps of the same 3x3x3 neighbourhood (dz in {-2,0,2}, dy, dx
 # in {-1,0,1}) of the input lattice: class pn=1 only dx in {0,1}, pm=1 only dy in {0,1}.  So ONE
-# 27-tap matrix A [B*Z*H*W, Kt] serves the four classes, each as a few column ranges (27 instead of
-# 75 tap blocks are written / read back).  Block order is (dx, dy, dz); between the dx groups sit
-# four 80-wide constant blocks P_class = [75 0/1 pattern columns | 1 | 0 0 0 0] whose weight rows are
-# (K[tap]^T prev_bias | bias): the bias-valued odd positions of the input and the layer bias ride in
-# the same GEMM.  Layout of a row (C = channels):
-#     [P00 | b0..b8 | P10 | b9..b17 | P11 | b18..b26 | P01]
-#   class (0,0): everything but P01 in one range (P10, P11 meet zero weight rows)
-#   class (0,1): b9.. to the end in one range         class (1,0): [b3..b8 P10], b12..b17, b21..b26
-#   class (1,1): [b12..b17 P11], b21..b26
+# 27-tap matrix A [B*Z*H*W, Kt] serves the four classes (27 instead of 75 tap blocks are written /
+# read back).  The (dy, dx) pairs are ordered in four groups
+#     G1 = (dy-, dx-) | G2 = (dy+, dx-) | G3 = (dy+, dx+) | G4 = (dy-, dx+)      (- : -1, + : {0, 1})
+# so that EVERY class is one contiguous column range: (0,0) = G1..G4, (1,0) = G2 G3, (1,1) = G3,
+# (0,1) = G3 G4.  Four 80-wide constant blocks P_class = [75 0/1 pattern columns | 1 | 0 0 0 0] sit
+# between the groups, with weight rows (K[tap]^T prev_bias | bias): the bias-valued odd positions of
+# the input and the layer bias ride in the same GEMM.  Layout of a row (C = channels):
+#     [P00 | G1 | P10 | G2 | P11 | G3 | G4 | P01]
+#   (0,0): P00..G4 (P10, P11 meet zero weight rows)      (1,0): P10 G2 P11 G3 (P11 -> zero rows)
+#   (1,1): P11 G3                                          (0,1): G3 G4 P01
 # Every class GEMM writes its own contiguous output plane: the result is PLANAR [4,B,Z,H,W,Co]
 # (plane 2pm+pn = positions (2y+pm, 2x+pn) of the (2H, 2W) lattice) and is consumed as such by the
 # next layer's gather kernel and by occ_proj -- the lattice is never interleaved.
@@ -125,22 +129,41 @@ _PW = 80                                             # width of a constant block
 _CLASSES = ((0, 0), (0, 1), (1, 0), (1, 1))
 
 
+def _group_of(dyi, dxi):
+    yp, xp = dyi > 0, dxi > 0
+    return 0 if (not yp and not xp) else 1 if (yp and not xp) else 2 if (yp and xp) else 3
+
+
+def _block_order():
+    """27 blocks (dxi, dyi, dzi) in column order: groups G1..G4, inside a group (dx, dy, dz)."""
+    blocks = [(dxi, dyi, dzi) for dxi in range(3) for dyi in range(3) for dzi in range(3)]
+    return sorted(blocks, key=lambda b: (_group_of(b[1], b[0]), b))
+
+
+_ORDER = _block_order()
+_GROUP_START = [next(i for i, b in enumerate(_ORDER) if _group_of(b[1], b[0]) == g) for g in range(4)] + [27]
+# number of constant blocks in front of block position i: P00 before G1, P10 before G2, P11 before G3
+_CONST_BEFORE = [1 + (i >= _GROUP_START[1]) + (i >= _GROUP_START[2]) for i in range(27)]
+
+
 def _block_offset(t, c):
-    return _PW * (1 + t // 9) + t * c
+    """column offset of the t-th block (position in _ORDER)."""
+    return _PW * _CONST_BEFORE[t] + t * c
 
 
 def _const_offset(pm, pn, c):
-    return {(0, 0): 0, (1, 0): _PW + 9 * c, (1, 1): 2 * _PW + 18 * c, (0, 1): 3 * _PW + 27 * c}[(pm, pn)]
+    g = _GROUP_START
+    return {(0, 0): 0, (1, 0): _PW + g[1] * c, (1, 1): 2 * _PW + g[2] * c, (0, 1): 3 * _PW + 27 * c}[(pm, pn)]
 
 
 def _tap27():
-    """(dz, dy, dx) of block t = (dxi*3 + dyi)*3 + dzi."""
-    return [(2 * dzi - 2, dyi - 1, dxi - 1) for dxi in range(3) for dyi in range(3) for dzi in range(3)]
+    """(dz, dy, dx) of the t-th block."""
+    return [(2 * dzi - 2, dyi - 1, dxi - 1) for dxi, dyi, dzi in _ORDER]
 
 
 def _class_tap_id(pm, pn, t):
-    """id in the 75-tap correlation kernel of block t for class (pm, pn), or None."""
-    dxi, dyi, dzi = t // 9, (t // 3) % 3, t % 3
+    """id in the 75-tap correlation kernel of the t-th block for class (pm, pn), or None."""
+    dxi, dyi, dzi = _ORDER[t]
     bb, cc = 2 * dyi - pm, 2 * dxi - pn
     if 0 <= bb < 5 and 0 <= cc < 5:
         return (dzi * 5 + bb) * 5 + cc
@@ -173,11 +196,12 @@ def _layer_plan(ci, device):
         dummy[0] += _PW
         return r
     b = lambda lo, hi: [('b', t) for t in range(lo, hi)]
+    g = _GROUP_START
     layout = {
-        (0, 0): [[('c', (0, 0))] + b(0, 9) + [('c', (1, 0))] + b(9, 18) + [('c', (1, 1))] + b(18, 27)],
-        (0, 1): [b(9, 18) + [('c', (1, 1))] + b(18, 27) + [('c', (0, 1))]],
-        (1, 0): [b(3, 9) + [('c', (1, 0))], b(12, 18), b(21, 27)],
-        (1, 1): [b(12, 18) + [('c', (1, 1))], b(21, 27)],
+        (0, 0): [[('c', (0, 0))] + b(g[0], g[1]) + [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[4])],
+        (1, 0): [[('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[3])],
+        (1, 1): [[('c', (1, 1))] + b(g[2], g[3])],
+        (0, 1): [b(g[2], g[4]) + [('c', (0, 1))]],
     }
     plan = {}
     for (pm, pn), ranges in layout.items():

@@ -13,13 +13,14 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
-           'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter')
+           'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter',
+           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose')
 
 _lib = None
 
@@ -287,6 +288,58 @@ class LatticeIm2colFunction(Function):
 
 def lattice_im2col(lattice, taps):
     return LatticeIm2colFunction.apply(lattice, taps)
+
+
+class ConvTWeightFunction(Function):
+    """ConvTranspose3d weight fp32 [Ci,Co,3,5,5] -> correlation taps [75,Ci,Co] (fp32 or bf16),
+    ver_convt_weight_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, weight, dtype):
+        weight = _gpu(weight, 'weight')
+        if weight.dtype != torch.float32 or tuple(weight.shape[2:]) != (3, 5, 5):
+            raise TypeError('weight must be fp32 [Ci,Co,3,5,5]')
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('taps dtype must be fp32 or bf16')
+        weight = weight.contiguous()
+        ci, co = weight.shape[:2]
+        taps = torch.empty(75, ci, co, dtype=dtype, device=weight.device)
+        dt = 1 if dtype == torch.bfloat16 else 0
+        _launch('ver_convt_weight_forward', lambda: lib().ver_convt_weight_forward(
+            _p(weight), _p(taps), ctypes.c_long(ci * co), dt, _stream()))
+        ctx.shape, ctx.dt, ctx.dtype = tuple(weight.shape), dt, dtype
+        return taps
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_taps):
+        g = _gpu(grad_taps, 'grad_taps').to(ctx.dtype).contiguous()
+        ci, co = ctx.shape[:2]
+        gw = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        _launch('ver_convt_weight_backward', lambda: lib().ver_convt_weight_backward(
+            _p(g), _p(gw), ctypes.c_long(ci * co), ctx.dt, _stream()))
+        return gw, None
+
+
+def convt_weight_taps(weight, dtype):
+    return ConvTWeightFunction.apply(weight, dtype)
+
+
+def lattice_transpose(channels_last, channel_first, combined_hw, planar, to_channel_first):
+    """ver_lattice_transpose (no autograd): channels_last plain [B,Z,H,W,C] / planar [4,B,Z,H/2,W/2,C]
+    <-> channel_first [B, stride] rows holding [C,Z,H,W] at their start."""
+    cl, cf = _gpu(channels_last, 'channels_last'), _gpu(channel_first, 'channel_first')
+    if not (cl.is_contiguous() and cf.is_contiguous() and cl.dtype == cf.dtype):
+        raise ValueError('lattice_transpose: contiguous buffers of one dtype required')
+    if cl.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('lattice_transpose: fp32 or bf16')
+    H, W = combined_hw
+    s = cl.shape
+    B, Z, C = (s[1], s[2], s[5]) if planar else (s[0], s[1], s[4])
+    dt = 1 if cl.dtype == torch.bfloat16 else 0
+    _launch('ver_lattice_transpose', lambda: lib().ver_lattice_transpose(
+        _p(cl), _p(cf), ctypes.c_long(cf.shape[1]), B, Z, H, W, C, int(planar), int(to_channel_first), dt,
+        _stream()))
 
 
 def _tap_args(taps, col_offset):

@@ -3,7 +3,9 @@ import sys, importlib, warnings, json
 warnings.filterwarnings('ignore')
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
 import numpy as np, torch
+import os
 hip = importlib.import_module('vln-ver_amd.hipops'); syn = importlib.import_module('vln-ver_amd.synthetic')
+if os.environ.get('VER_LIB'): hip.LIB_PATH = os.environ['VER_LIB']
 import cases
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 grid = (4, 15, 15) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split('x'))

@@ -19,6 +19,7 @@
 // Backward kernel: same tiling with a second LDS tile that accumulates d(value) through
 // ds_add_f32 and is flushed once; d(offsets), d(logits) are reduced over the G lanes with
 // wave shuffles, softmax backward fused.
+#include <cstdlib>
 #include <type_traits>
 #include "ver_common.h"
 
@@ -326,12 +327,14 @@ extern "C" int ver_debug_read(long long* out, int n) {
 
 template <int N>
 __device__ __forceinline__ float row_bcast_f(float v) {   // every lane reads lane N of its own 16-lane row
+    // bound_ctrl = true: every lane of a row_newbcast is written, so no "old" value has to be
+    // materialised in front of the v_mov_b32_dpp (it was one extra v_mov per broadcast)
     return __builtin_bit_cast(float,
-                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, false));
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
 }
 template <int N>
 __device__ __forceinline__ unsigned row_bcast_u(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xf, 0xf, true);
 }
 
 template <int HD, int G>
@@ -343,35 +346,58 @@ __device__ __forceinline__ void emit_row(float* row, int gl, const float (&acc)[
     }
 }
 
-// one point of phase B: weights / row byte offsets of point PT come from lanes PT*LPP .. of the row
+typedef __attribute__((address_space(3))) const unsigned char lds_byte;
+
+// LDS byte address = base + (row offset held by lane N of this 16-lane row).  (Fusing the broadcast
+// into the add as inline-asm v_add_u32_dpp was measured 25 % SLOWER: the asm statements defeat the
+// scheduler's interleaving of address arithmetic, ds_reads and FMAs.)
+template <int N>
+__device__ __forceinline__ unsigned row_bcast_u(unsigned v);
+template <int N>
+__device__ __forceinline__ unsigned bcast_add(unsigned koff, unsigned base) {
+    return base + row_bcast_u<N>(koff);
+}
+
+template <typename VT>
+__device__ __forceinline__ const VT* lds_ptr(unsigned addr) {
+    return reinterpret_cast<const VT*>((const unsigned char*)(lds_byte*)(uintptr_t)addr);
+}
+
+// one point of phase B: weights / row byte offsets of point PT come from lanes PT*LPP .. of the row.
+// base0 / base1 = LDS byte address of this lane's two channel segments (ChMap<HD,16>) in tile row 0.
 template <int HD, int P, int PT, typename VT>
-__device__ __forceinline__ void consume_point(const unsigned char* tile0, const unsigned char* tile1,
-                                              const float (&wsel)[2], const unsigned (&ksel)[2],
-                                              float (&acc)[HD / 16]) {
+__device__ __forceinline__ void consume_point(unsigned base0, unsigned base1, const float (&wsel)[2],
+                                              const unsigned (&ksel)[2], float (&acc)[HD / 16]) {
     constexpr int LPP = 16 / P;          // lanes per point (2 for P=8, 4 for P=4)
     constexpr int CPN = 4 / LPP;         // corners per lane (2 / 1)
     using M = ChMap<HD, 16>;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int reg = t % CPN;
+        constexpr int L1 = PT * LPP + (LPP > 1 ? 1 : 0), L2 = PT * LPP + (LPP > 2 ? 2 : 0),
+                      L3 = PT * LPP + (LPP > 3 ? 3 : 0);
         float w;
-        unsigned koff;                   // byte offset of the corner's tile row
+        unsigned a0, a1 = 0;             // LDS byte addresses of the corner's tile row, this lane's segments
         if (t / CPN == 0) {
-            w = row_bcast_f<PT * LPP + 0>(wsel[reg]);
-            koff = row_bcast_u<PT * LPP + 0>(ksel[reg]);
+            w = row_bcast_f<PT * LPP>(wsel[reg]);
+            a0 = bcast_add<PT * LPP>(ksel[reg], base0);
+            if (M::W1 > 0) a1 = bcast_add<PT * LPP>(ksel[reg], base1);
         } else if (t / CPN == 1) {
-            w = row_bcast_f<PT * LPP + (LPP > 1 ? 1 : 0)>(wsel[reg]);
-            koff = row_bcast_u<PT * LPP + (LPP > 1 ? 1 : 0)>(ksel[reg]);
+            w = row_bcast_f<L1>(wsel[reg]);
+            a0 = bcast_add<L1>(ksel[reg], base0);
+            if (M::W1 > 0) a1 = bcast_add<L1>(ksel[reg], base1);
         } else if (t / CPN == 2) {
-            w = row_bcast_f<PT * LPP + (LPP > 2 ? 2 : 0)>(wsel[reg]);
-            koff = row_bcast_u<PT * LPP + (LPP > 2 ? 2 : 0)>(ksel[reg]);
+            w = row_bcast_f<L2>(wsel[reg]);
+            a0 = bcast_add<L2>(ksel[reg], base0);
+            if (M::W1 > 0) a1 = bcast_add<L2>(ksel[reg], base1);
         } else {
-            w = row_bcast_f<PT * LPP + (LPP > 3 ? 3 : 0)>(wsel[reg]);
-            koff = row_bcast_u<PT * LPP + (LPP > 3 ? 3 : 0)>(ksel[reg]);
+            w = row_bcast_f<L3>(wsel[reg]);
+            a0 = bcast_add<L3>(ksel[reg], base0);
+            if (M::W1 > 0) a1 = bcast_add<L3>(ksel[reg], base1);
         }
         float v[M::CPL];
-        load_vec<M::W0>(reinterpret_cast<const VT*>(tile0 + koff), v);
-        load_vec<M::W1>(reinterpret_cast<const VT*>(tile1 + koff), v + M::W0);
+        load_vec<M::W0>(lds_ptr<VT>(a0), v);
+        load_vec<M::W1>(lds_ptr<VT>(a1), v + M::W0);
 #pragma unroll
         for (int j = 0; j < M::CPL; ++j) acc[j] += w * v[j];
     }
@@ -379,17 +405,16 @@ __device__ __forceinline__ void consume_point(const unsigned char* tile0, const 
 
 template <int HD, int P, int PT, typename VT>
 struct PointLoop {
-    __device__ __forceinline__ static void run(const unsigned char* tile0, const unsigned char* tile1,
-                                               const float (&wsel)[2], const unsigned (&ksel)[2],
-                                               float (&acc)[HD / 16]) {
-        consume_point<HD, P, PT, VT>(tile0, tile1, wsel, ksel, acc);
-        PointLoop<HD, P, PT + 1, VT>::run(tile0, tile1, wsel, ksel, acc);
+    __device__ __forceinline__ static void run(unsigned base0, unsigned base1, const float (&wsel)[2],
+                                               const unsigned (&ksel)[2], float (&acc)[HD / 16]) {
+        consume_point<HD, P, PT, VT>(base0, base1, wsel, ksel, acc);
+        PointLoop<HD, P, PT + 1, VT>::run(base0, base1, wsel, ksel, acc);
     }
 };
 template <int HD, int P, typename VT>
 struct PointLoop<HD, P, P, VT> {
-    __device__ __forceinline__ static void run(const unsigned char*, const unsigned char*, const float (&)[2],
-                                               const unsigned (&)[2], float (&)[HD / 16]) {}
+    __device__ __forceinline__ static void run(unsigned, unsigned, const float (&)[2], const unsigned (&)[2],
+                                               float (&)[HD / 16]) {}
 };
 
 template <int HD, int G, int P, typename VT>
@@ -400,7 +425,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
     int nchunks, int chunk, int hsplit, int nbuf) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CPL = HD / G;
-    constexpr int NCONS = kFwdWaves - kFwdLoaders;                     // consumer waves
+    const int nwaves = (int)(blockDim.x >> 6);                         // 16 (or 8 with two workgroups per CU)
+    const int NCONS = nwaves - kFwdLoaders;                            // consumer waves
     const int Nk = mh * mw;
     const size_t tile_elems = (size_t)Nk * HD;
     VT* tiles = reinterpret_cast<VT*>(smem);
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool loader = kFwdLoaders > 0 && wave >= NCONS;
     const int dma_wave = kFwdLoaders > 0 ? wave - NCONS : wave;
-    constexpr int kDmaWaves = kFwdLoaders > 0 ? kFwdLoaders : kFwdWaves;
+    const int kDmaWaves = kFwdLoaders > 0 ? kFwdLoaders : nwaves;
     const bool issues_dma = kFwdLoaders == 0 || loader;
     const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
     const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
         // ------------------------------------------------------------ consumers
         if constexpr (G == 16) {
             constexpr int LPP = 16 / P, CPN = 4 / LPP;
-            constexpr int STEP = NCONS * 4;
+            const int STEP = NCONS * 4;
             const int row = lane >> 4, lr = lane & 15;
             const int ap = lr / LPP, asub = lr % LPP;      // phase A: point, corner subset
             const int ad = (D == 1) ? 0 : (ap % D);
@@ -475,9 +501,11 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                 sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
                 return sm;
             };
+            // LDS byte addresses of this lane's two channel segments in row 0 of the current tile
             using M16 = ChMap<HD, 16>;
-            const unsigned char* tile0 = reinterpret_cast<const unsigned char*>(tile + M16::off0(lr));
-            const unsigned char* tile1 = reinterpret_cast<const unsigned char*>(tile + M16::off1(lr));
+            const unsigned tile_lds = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(tile);
+            const unsigned base_seg0 = tile_lds + M16::off0(lr) * (unsigned)sizeof(VT);
+            const unsigned base_seg1 = tile_lds + M16::off1(lr) * (unsigned)sizeof(VT);
             const int base0 = start + wave * 4;
             int n_cur = load_id(base0);
             int n_nxt = load_id(base0 + STEP);
@@ -496,7 +524,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                     const float mx = group_max<16>(s_cur.lg);
                     const float e = __expf(s_cur.lg - mx);
                     const float ssum = group_sum<16>(asub == 0 ? e : 0.0f);
-                    const float a = m ? e / (ssum * (float)__popc(m)) : 0.0f;
+                    const float a = m ? e * __builtin_amdgcn_rcpf(ssum * (float)__popc(m)) : 0.0f;   // 1 ulp
                     Bilinear s;
                     bilinear_setup<false>(s_cur.u.x + s_cur.of.x * inv_w, s_cur.u.y + s_cur.of.y * inv_h, mh, mw, s);
                     if constexpr (CPN == 2) {
@@ -517,7 +545,9 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                 float acc[CPL];
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-                PointLoop<HD, P, 0, VT>::run(tile0, tile1, wsel, ksel, acc);
+                // the fused DPP adds are inline asm: the hazard recogniser does not see that they read
+                // ksel through DPP, so keep two wait states behind the VALU ops that produced it
+                PointLoop<HD, P, 0, VT>::run(base_seg0, base_seg1, wsel, ksel, acc);
                 if (n_cur >= 0)
                     emit_row<HD, G>(slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD, lr, acc,
                                     __popc(m) == 1);
@@ -1092,13 +1122,25 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                 "ver_sca_forward: %dx%dx%d value tile (%zu B) exceeds the 160 KiB LDS", map_h, map_w, head_dim,
                 tile_bytes);
     VER_REQUIRE(map_h * map_w <= 65536, VER_EUNSUPPORTED, "ver_sca_forward: map larger than 65536 tokens");
-    const int nbuf = 2 * tile_bytes <= kMaxLds ? 2 : 1;          // double-buffer the tile when it fits
+    // two ways to overlap the tile stream with the gather: one 16-wave workgroup per CU with a
+    // double-buffered tile, or two 8-wave workgroups per CU with one tile each (finer work split:
+    // 32 instead of 64 voxel slots per pass over a camera's ~140 visible voxels)
+    static const int fwd_threads = [] {
+        const char* e = getenv("VER_SCA_FWD_THREADS");
+        const int t = e ? atoi(e) : 512;               // measured: 512 beats 1024 by 5-15 % (B = 32..256)
+        return (t == 512 || t == 1024) ? t : 512;
+    }();
+    const int nbuf = (fwd_threads == kFwdThreads && 2 * tile_bytes <= kMaxLds) ? 2 : 1;
     const size_t lds = tile_bytes * nbuf;
     const int nchunks = (Nq + kFwdChunk - 1) / kFwdChunk;
     // heads are walked inside a workgroup (the tile stream is double buffered); split them over
     // several workgroups only while the grid would not yet fill the 256 CUs a few times over
+    static const long min_wgs = [] {
+        const char* e = getenv("VER_SCA_FWD_MIN_WGS");
+        return e ? atol(e) : 1536L;                    // >= 3 workgroups per residency slot (2 per CU)
+    }();
     int hsplit = 1;
-    while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < 768) hsplit *= 2;
+    while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < min_wgs) hsplit *= 2;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, st, zero_list, zero_cnt, slots, Nq,
                        heads * head_dim);
@@ -1112,7 +1154,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             if (e != hipSuccess)
                 return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
             const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(kFwdThreads), lds, st, vptr, offsets, logits, uv, vis, vis_list,
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(fwd_threads), lds, st, vptr, offsets, logits, uv, vis, vis_list,
                                vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsplit, nbuf);
             return ver_check_launch("ver_sca_forward");
         };

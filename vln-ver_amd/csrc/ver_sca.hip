@@ -744,7 +744,8 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CPL = HD / 16;
     constexpr int LPP = 16 / P, CPN = 4 / LPP;
-    constexpr int STEP = kFwdWaves * 4;
+    const int nwaves_rt = (int)(blockDim.x >> 6);
+    const int STEP = nwaves_rt * 4;
     using M16 = ChMap<HD, 16>;
     const int Nk = mh * mw;
     const size_t tile_elems = (size_t)Nk * HD;
@@ -771,20 +772,20 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
     const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
     constexpr unsigned kRowBytes = HD * sizeof(VT);
 
-    if (nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave, kFwdWaves);
+    if (nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave, nwaves_rt);
     for (int hh = 0; hh < heads_per; ++hh) {
         const int h = h0 + hh;
         const int cur = nbuf == 2 ? (hh & 1) : 0;
         VT* tile = tiles + cur * tile_elems;
         if (nbuf == 1) {
             __syncthreads();
-            stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave, kFwdWaves);
+            stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave, nwaves_rt);
         }
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (nbuf == 2 && hh + 1 < heads_per)
             stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, wave,
-                               kFwdWaves);
+                               nwaves_rt);
         const unsigned char* tile0 = reinterpret_cast<const unsigned char*>(tile + M16::off0(lr));
         const unsigned char* tile1 = reinterpret_cast<const unsigned char*>(tile + M16::off1(lr));
 
@@ -1192,17 +1193,27 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
             if (map_h * map_w <= kValMaxRows) {
                 // ---- d(offsets), d(logits): forward-shaped kernel
                 const size_t tile_bytes = (size_t)map_h * map_w * head_dim * esz;
-                const int nbuf = 2 * tile_bytes <= kMaxLds ? 2 : 1;
+                static const int off_threads = [] {
+                    const char* ev = getenv("VER_SCA_BWD_THREADS");
+                    const int t = ev ? atoi(ev) : 1024;
+                    return (t == 512 || t == 1024) ? t : 1024;
+                }();
+                static const long off_min_wgs = [] {
+                    const char* ev = getenv("VER_SCA_BWD_MIN_WGS");
+                    return ev ? atol(ev) : 768L;
+                }();
+                const int nbuf = (off_threads == kFwdThreads && 2 * tile_bytes <= kMaxLds) ? 2 : 1;
                 const size_t lds_off = tile_bytes * nbuf;
                 const int nch = (Nq + kFwdChunk - 1) / kFwdChunk;
                 int hsplit = 1;
-                while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nch < 768) hsplit *= 2;
+                while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nch < off_min_wgs)
+                    hsplit *= 2;
                 auto launch_off = [&](auto kern, auto vptr) {
                     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_off);
                     if (e2 != hipSuccess)
                         return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
-                    hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * hsplit * nch), dim3(kFwdThreads), lds_off, st, vptr,
+                    hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * hsplit * nch), dim3(off_threads), lds_off, st, vptr,
                                        offsets, logits, uv, vis, vis_list, vis_cnt, grad_slots, grad_offsets,
                                        grad_logits, Ncam, Nq, D, heads, map_h, map_w, nch, kFwdChunk, hsplit, nbuf);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_off");

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=32, help='viewpoints per GPU per step')
     ap.add_argument('--micro', type=int, default=32, help='viewpoints per head micro-batch')
+    ap.add_argument('--no-tuned-gemms', action='store_true',
+                    help='do not load the recorded hipBLASLt solution table (vln-ver_amd/tuning)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd', 'vocc_full_train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -190,6 +192,9 @@ def main():
             dist.init_process_group(args.backend)
     hip = importlib.import_module('vln-ver_amd.hipops')
     hip.lib()
+    tuned = False
+    if not args.no_tuned_gemms:
+        tuned = importlib.import_module('vln-ver_amd.tuning').enable_tuned_gemms()
     pkg, syn, head, n_train = build_model(args, dev)
     B = args.batch
     train = args.workload in ('vocc_c2f_train', 'vocc_full_train')
@@ -287,7 +292,7 @@ def main():
                                    'single-scale 50x50x16 volume, forward only',
                        'viewpoints_per_gpu_per_step': B, 'global_viewpoints_per_step': B * world,
                        'head_micro_batch': args.micro, 'parallelism': 'dp%d' % world,
-                       'trainable_params': n_train,
+                       'trainable_params': n_train, 'tuned_gemm_table': tuned,
                        'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
                                      else 'fp32'},
             'roofline': roof, 'roofline_other_kernels': others,

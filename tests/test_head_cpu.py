@@ -128,6 +128,24 @@ def test_detection_and_occupancy_losses_match_reference():
     assert sorted(d) == sorted(['loss_cls', 'loss_bbox', 'loss_occupancy', 'loss_flow'] +
                                ['d%d.loss_%s' % (i, k) for i in range(5) for k in ('cls', 'bbox')])
     assert float(d['loss_cls']) == pytest.approx(float(g['loss_cls']), rel=1e-5)
+    # loss() forms the Hungarian targets of all layers / samples in one batch: same numbers and
+    # gradients as the reference-shaped per-layer loss_single, here on 2 samples with 3 and 0 boxes
+    cls2 = T(np.concatenate([gh['c3_b0_cls'], gh['c3_b0_cls'][:, :, ::-1].copy()], 1)).requires_grad_(True)
+    box2 = T(np.concatenate([gh['c3_b0_bbox'], gh['c3_b0_bbox'][:, :, ::-1].copy()], 1)).requires_grad_(True)
+    gtb = [T(boxes)[:, :7], T(boxes)[:0, :7]]
+    gtl = [T(labels), T(labels)[:0]]
+    batched = h.loss(gtb, gtl, None, dict(all_cls_scores=cls2, all_bbox_preds=box2, occupancy_preds=None))
+    gb = torch.autograd.grad(sum(v for k, v in batched.items() if 'cls' in k or 'bbox' in k), [cls2, box2])
+    pad = [torch.cat([b, b.new_zeros(b.shape[0], 2)], 1) for b in gtb]
+    tot = 0
+    for lvl in range(cls2.shape[0]):
+        lc_, lb_, _ = h.loss_single(cls2[lvl], box2[lvl], None, pad, gtl)
+        key = '' if lvl == cls2.shape[0] - 1 else 'd%d.' % lvl
+        assert float(batched[key + 'loss_cls']) == pytest.approx(float(lc_), rel=1e-6)
+        assert float(batched[key + 'loss_bbox']) == pytest.approx(float(lb_), rel=1e-6)
+        tot = tot + lc_ + lb_
+    gs = torch.autograd.grad(tot, [cls2, box2])
+    assert close(gb[0], gs[0], atol=1e-7, rtol=1e-5) and close(gb[1], gs[1], atol=1e-7, rtol=1e-5)
     # empty ground truth: everything is background, box loss is zero
     lc0, lb0, _ = h.loss_single(cls.detach(), box.detach(), None, [T(boxes)[:0]], [T(labels)[:0]])
     assert float(lb0) == 0.0 and float(lc0) > 0.0

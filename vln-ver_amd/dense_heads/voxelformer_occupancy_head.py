@@ -415,16 +415,101 @@ class VoxelFormerOccupancyHead(BaseModule):
         labels = [torch.as_tensor(x, device=all_box.device).long() for x in gt_labels_list]
         nl = len(all_cls)
         losses = {}
+        targets = self._batched_targets(all_cls, all_box, padded, labels)
         for lvl in range(nl):
             last = lvl == nl - 1
-            lc, lb, lo = self.loss_single(all_cls[lvl], all_box[lvl], occ if last else None, padded, labels,
-                                          gt_occupancy if last else None)
+            if targets is None:
+                lc, lb, lo = self.loss_single(all_cls[lvl], all_box[lvl], occ if last else None, padded, labels,
+                                              gt_occupancy if last else None)
+            else:
+                lc, lb = self._loss_from_targets(all_cls[lvl], all_box[lvl], *[t[lvl] for t in targets[:3]],
+                                                 targets[3][lvl])
+                lo = self.occupancy_loss(occ, gt_occupancy) if (last and occ is not None) else torch.zeros_like(lc)
             if last:
                 losses.update(loss_cls=lc, loss_bbox=lb, loss_occupancy=lo, loss_flow=torch.zeros_like(lc))
             else:
                 losses['d%d.loss_cls' % lvl] = lc
                 losses['d%d.loss_bbox' % lvl] = lb
         return losses
+
+    # ---- Hungarian targets of all decoder layers and samples with ONE device->host round trip
+    def _batched_targets(self, all_cls, all_box, gt_boxes, gt_labels):
+        """``_get_target_single`` (head:642-705) for every (layer, sample) at once: the cost matrices
+        [L,bs,Nq,Gmax] are formed on the device (same formulas as ``HungarianAssigner3D.assign``),
+        copied to the host in one piece, solved there (scipy, as in the reference) and the matched
+        indices come back in one piece.  Returns (labels [L,bs,Nq], bbox_targets [L,bs,Nq,9],
+        positive mask [L,bs,Nq], positives per layer) or None when there is nothing to batch."""
+        from .assigner import BBox3DL1Cost, FocalLossCost, linear_sum_assignment
+        a = self.assigner
+        if (a is None or linear_sum_assignment is None or not isinstance(a.cls_cost, FocalLossCost)
+                or not isinstance(a.reg_cost, BBox3DL1Cost)):
+            return None
+        nl, bs, nq, _ = all_cls.shape
+        counts = [int(g.shape[0]) for g in gt_boxes]
+        gmax = max(counts) if counts else 0
+        if gmax == 0:
+            return None
+        dev = all_box.device
+        gt_pad = all_box.new_zeros(bs, gmax, 9)
+        lab_pad = torch.zeros(bs, gmax, dtype=torch.long, device=dev)
+        for i, (g, lab) in enumerate(zip(gt_boxes, gt_labels)):
+            if counts[i]:
+                gt_pad[i, :counts[i]] = g.to(all_box.dtype)
+                lab_pad[i, :counts[i]] = lab.reshape(-1)
+        with torch.no_grad():
+            c = a.cls_cost
+            p = all_cls.float().sigmoid()
+            neg = -(1 - p + c.eps).log() * (1 - c.alpha) * p.pow(c.gamma)
+            pos = -(p + c.eps).log() * c.alpha * (1 - p).pow(c.gamma)
+            cls_cost = ((pos - neg) * c.weight).gather(3, lab_pad[None, :, None, :].expand(nl, bs, nq, gmax))
+            gt_norm = normalize_bbox(gt_pad.view(-1, 9), a.pc_range).view(bs, gmax, -1)[..., :8]
+            # padded gts hold log(0): keep them finite, their columns are never handed to the solver
+            gt_norm = torch.nan_to_num(gt_norm, nan=0.0, posinf=0.0, neginf=0.0)
+            reg_cost = (all_box.float()[..., None, :8] - gt_norm[None, :, None]).abs().sum(-1) * a.reg_cost.weight
+            cost = (cls_cost + reg_cost).cpu().numpy()
+        import numpy as np
+        idx = np.full((nl, bs, nq), -1, dtype=np.int64)
+        for lvl in range(nl):
+            for i in range(bs):
+                if counts[i]:
+                    rows, cols = linear_sum_assignment(cost[lvl, i, :, :counts[i]])
+                    idx[lvl, i, rows] = cols
+        num_pos = (idx >= 0).reshape(nl, -1).sum(1).tolist()
+        idx_t = torch.from_numpy(idx).to(dev)
+        pos_mask = idx_t >= 0
+        safe = idx_t.clamp(min=0)
+        labels = torch.where(pos_mask, lab_pad[None].expand(nl, bs, gmax).gather(2, safe),
+                             torch.full_like(safe, self.num_classes))
+        bbox_targets = gt_pad[None].expand(nl, bs, gmax, 9).gather(2, safe[..., None].expand(nl, bs, nq, 9))
+        return labels, bbox_targets, pos_mask, num_pos
+
+    def _loss_from_targets(self, cls_scores, bbox_preds, labels, bbox_targets, pos_mask, num_total_pos):
+        """The detection terms of ``loss_single`` (head:903-976) from precomputed targets; rows the
+        reference drops by boolean indexing (non-finite normalised targets) get weight 0 instead, so
+        nothing here synchronises with the host."""
+        import torch.distributed as dist
+        cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
+        num_total_neg = pos_mask.numel() - num_total_pos
+        cls_avg_factor = num_total_pos * 1.0 + num_total_neg * self.bg_cls_weight
+        if self.sync_cls_avg_factor:
+            cls_avg_factor = float(reduce_mean(cls_scores.new_tensor([cls_avg_factor])))
+        cls_avg_factor = max(cls_avg_factor, 1)
+        labels = labels.reshape(-1)
+        loss_cls = self.loss_cls(cls_scores, labels, labels.new_ones(labels.shape, dtype=cls_scores.dtype),
+                                 avg_factor=cls_avg_factor)
+        if dist.is_available() and dist.is_initialized():
+            num_total_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([float(num_total_pos)])), min=1).item()
+        else:
+            num_total_pos = max(float(num_total_pos), 1.0)
+        bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
+        pos = pos_mask.reshape(-1)
+        normalized = normalize_bbox(bbox_targets.reshape(-1, bbox_targets.size(-1)), self.pc_range)
+        keep = (torch.isfinite(normalized).all(dim=-1) & pos).to(bbox_preds.dtype)
+        weights = keep[:, None] * self.code_weights
+        target = torch.nan_to_num(normalized[:, :10], nan=0.0, posinf=0.0, neginf=0.0) * keep[:, None]
+        loss_bbox = self.loss_bbox(bbox_preds[:, :10] * keep[:, None], target, weights[:, :10],
+                                   avg_factor=num_total_pos)
+        return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)
 
     def get_occupancy_prediction(self, occ_results, occ_threshold=0.25):
         """head:1505-1540 (focal-loss branch): sigmoid, threshold as an extra "empty" column,

@@ -40,8 +40,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=32, help='viewpoints per GPU per step')
-    ap.add_argument('--micro', type=int, default=32, help='viewpoints per head micro-batch')
+    ap.add_argument('--batch', type=int, default=64, help='viewpoints per GPU per step')
+    ap.add_argument('--micro', type=int, default=64, help='viewpoints per head micro-batch')
     ap.add_argument('--no-tuned-gemms', action='store_true',
                     help='do not load the recorded hipBLASLt solution table (vln-ver_amd/tuning)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
@@ -293,6 +293,7 @@ def main():
                        'viewpoints_per_gpu_per_step': B, 'global_viewpoints_per_step': B * world,
                        'head_micro_batch': args.micro, 'parallelism': 'dp%d' % world,
                        'trainable_params': n_train, 'tuned_gemm_table': tuned,
+                       'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
                                      else 'fp32'},
             'roofline': roof, 'roofline_other_kernels': others,

@@ -341,8 +341,7 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
                                                         const __bf16* __restrict__ img, const float* __restrict__ vec,
                                                         __bf16* __restrict__ dx, __bf16* __restrict__ da1,
                                                         __bf16* __restrict__ da2, __bf16* __restrict__ h1,
-                                                        __bf16* __restrict__ h2, float* __restrict__ pgrad, long N,
-                                                        float eps) {
+                                                        float* __restrict__ pgrad, long N, float eps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                       // [kAllFrags][64]
     float* sv = reinterpret_cast<float*>(smem + kAllFrags * 1024);
@@ -364,6 +363,15 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
         sel[0][j] = (__bf16)((j < 4 && 4 * g + j == c) ? 1.0f : 0.0f);
         sel[1][j] = (__bf16)((j >= 4 && 4 * g + j - 4 == c) ? 1.0f : 0.0f);
     }
+    // d(W3)[class][feature] = sum_r d(logits)[r][class] * h2[r][feature] is accumulated in-kernel (h2 never
+    // goes to HBM): both tiles are turned feature/class-on-the-lane by selector MFMAs, then multiplied
+    // with the rows as the (half-filled) K dimension.  dw3[ot][i] = class 4g+i, feature 16ot + c.
+    f32x4 dw3[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) dw3[ot] = zero4;
+    bf16x8 sel_cls;                                  // k-slot 8g'+j of the d(logits) fragment holds class 8g'+j (g' < 2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sel_cls[j] = (__bf16)((g < 2 && 8 * g + j == c) ? 1.0f : 0.0f);
     const long nblk = (N + 15) / 16;
     for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
         int lane_off = lane;
@@ -391,13 +399,21 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
         gemm8<true>(acc, fr, kF2, bf, sv_g + 3 * kW);
         __builtin_amdgcn_sched_barrier(0);
         ln_relu_keep(acc, sv_g + 4 * kW, sv_g + 5 * kW, eps, bf, xh2, rs2);
-        if (ok) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(h2 + r * kW + 32 * t + 8 * g) = bf[t];
-        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- d(h2)^T = W3^T d(logits)^T   (K = 16 classes in the lower half of the k-step)
         const bf16x8 dl = (ok && g < 2) ? *reinterpret_cast<const bf16x8*>(dlog + r * kC + 8 * g) : z8;
+        {   // d(W3) += d(logits)^T h2 for this row tile
+            const f32x4 tdl = mfma(dl, sel_cls, zero4);                       // [row 4g+i][class c]
+            const bf16x8 a3 = pack8(tdl, zero4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 th = mfma(bf[t], sel[h], zero4);               // [row 4g+i][feature 16(2t+h)+c]
+                    dw3[2 * t + h] = mfma(a3, pack8(th, zero4), dw3[2 * t + h]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) acc[mt] = mfma(fr[(kB3 + mt) * 64], dl, zero4);
         __builtin_amdgcn_sched_barrier(0);
@@ -448,6 +464,11 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
                 atomicAdd(pgrad + (3 * l + 2) * kW + 16 * ot + c, d);
             }
         }
+    // ---- d(W3) [16][128] behind the six vectors
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(pgrad + 6 * kW + (4 * g + i) * kW + 16 * ot + c, dw3[ot][i]);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -500,16 +521,16 @@ extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float
 }
 
 extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
-                                    void* grad_x, void* grad_a1, void* grad_a2, void* h1, void* h2, float* param_grads,
-                                    long N, int width, int classes, float eps, void* stream) {
+                                    void* grad_x, void* grad_a1, void* grad_a2, void* h1, float* param_grads, long N,
+                                    int width, int classes, float eps, void* stream) {
     int rc = check_common("ver_occ_mlp_backward", x, image, vectors, N, width, classes);
     if (rc) return rc;
     VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(param_grads, 0, 6 * kW * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW) * sizeof(float), st);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
-    VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1 && h2, VER_EINVAL,
+    VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1, VER_EINVAL,
                 "ver_occ_mlp_backward: null pointer argument");
     const size_t lds = (size_t)kAllFrags * 1024 + kVecFloats * sizeof(float);
     static bool attr_done = false;
@@ -523,6 +544,6 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     if (grid > 256) grid = 256;                            // one 4-wave workgroup per CU (LDS bound), persistent
     hipLaunchKernelGGL(k_occ_mlp_bwd, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
                        (const __bf16*)grad_logits, (const __bf16*)image, vectors, (__bf16*)grad_x, (__bf16*)grad_a1,
-                       (__bf16*)grad_a2, (__bf16*)h1, (__bf16*)h2, param_grads, N, eps);
+                       (__bf16*)grad_a2, (__bf16*)h1, param_grads, N, eps);
     return ver_check_launch("ver_occ_mlp_backward");
 }

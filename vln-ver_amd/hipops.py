@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -557,19 +557,20 @@ class OccMLPFunction(Function):
         x2 = x.view(-1, 128)
         n = x2.shape[0]
         gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
-        gx, ga1, ga2, h1, h2 = (torch.empty_like(x2) for _ in range(5))
-        pg = torch.empty(6, 128, dtype=torch.float32, device=x.device)
+        gx, ga1, ga2, h1 = (torch.empty_like(x2) for _ in range(4))
+        pg = torch.empty(6 * 128 + 16 * 128, dtype=torch.float32, device=x.device)
         _launch('ver_occ_mlp_backward', lambda: lib().ver_occ_mlp_backward(
-            _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1), _p(ga2), _p(h1), _p(h2), _p(pg),
+            _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1), _p(ga2), _p(h1), _p(pg),
             ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _stream()))
         inv = _frag_order(x.device)
-        dw3, db3 = _rows_tn(gl, h2)
+        vecs = pg[:768].view(6, 128)
+        dw3 = pg[768:].view(16, 128)
+        db3 = gl.sum(0, dtype=torch.float32)
         dw2, _ = _rows_tn(ga2, h1, with_colsum=False)
         dw1, _ = _rows_tn(ga1, x2, with_colsum=False)
-        dw3 = dw3.index_select(1, inv)
         dw2 = dw2.index_select(0, inv).index_select(1, inv)
         dw1 = dw1.index_select(0, inv)
-        return (gx.view(shape), dw1, pg[2], pg[0], pg[1], dw2, pg[5], pg[3], pg[4], dw3, db3, None)
+        return (gx.view(shape), dw1, vecs[2], vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
 
 
 def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5):

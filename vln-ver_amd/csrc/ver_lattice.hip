@@ -37,28 +37,39 @@ __device__ __forceinline__ long lattice_index(int b, int z, int y, int x, int B,
     return (((long)b * Z + z) * H + y) * W + x;
 }
 
+// One workgroup walks rows; inside a row the (tap, vector) index advances without divisions
+// (the first version decoded every 16-byte vector from a flat index: five runtime divisions each).
 template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict__ src, uint4* __restrict__ col,
                                                         TapListEx taps, long stride_v, int B, int Z, int H, int W,
                                                         int CV) {
-    const long total = (long)B * Z * H * W * taps.n * CV;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int v = (int)(i % CV);
-        long r = i / CV;
-        const int t = (int)(r % taps.n);
-        r /= taps.n;
-        const long row = r;
+    const long rows = (long)B * Z * H * W;
+    const int per_row = taps.n * CV;
+    const int t0 = (int)threadIdx.x / CV, v0 = (int)threadIdx.x % CV;
+    const int dt = 256 / CV, dv = 256 % CV;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        long r = row;
         const int x = (int)(r % W);
-        long q = r / W;
-        const int y = (int)(q % H);
-        q /= H;
-        const int z = (int)(q % Z);
-        const int b = (int)(q / Z);
-        const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
-        uint4 val = make_uint4(0u, 0u, 0u, 0u);
-        if (sz >= 0 && sz < Z && sy >= 0 && sy < H && sx >= 0 && sx < W)
-            val = src[lattice_index<PLANAR>(b, sz, sy, sx, B, Z, H, W) * CV + v];
-        col[row * stride_v + taps.off[t] + v] = val;
+        r /= W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int z = (int)(r % Z);
+        const int b = (int)(r / Z);
+        uint4* dst = col + row * stride_v;
+        int t = t0, v = v0;
+        for (int i = threadIdx.x; i < per_row; i += 256) {
+            const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (sz >= 0 && sz < Z && sy >= 0 && sy < H && sx >= 0 && sx < W)
+                val = src[lattice_index<PLANAR>(b, sz, sy, sx, B, Z, H, W) * CV + v];
+            dst[taps.off[t] + v] = val;
+            t += dt;
+            v += dv;
+            if (v >= CV) {
+                v -= CV;
+                ++t;
+            }
+        }
     }
 }
 
@@ -302,13 +313,14 @@ extern "C" int ver_lattice_gather(const void* src, void* col, const int* taps, c
     if (rc) return rc;
     if (B == 0) return VER_OK;
     const int CV = C * esize / 16;
-    const long total = (long)B * Z * H * W * ntaps * CV;
+    const long rows = (long)B * Z * H * W;
     const long stride_v = col_stride * esize / 16;
+    const unsigned blocks = (unsigned)(rows < 256L * 32 ? rows : 256L * 32);
     if (planar)
-        hipLaunchKernelGGL(k_lattice_gather<true>, dim3(lattice_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_lattice_gather<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)src, (uint4*)col, tl, stride_v, B, Z, H, W, CV);
     else
-        hipLaunchKernelGGL(k_lattice_gather<false>, dim3(lattice_blocks(total)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(k_lattice_gather<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)src, (uint4*)col, tl, stride_v, B, Z, H, W, CV);
     return ver_check_launch("ver_lattice_gather");
 }

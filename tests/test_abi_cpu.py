@@ -47,6 +47,35 @@ def test_argument_validation_without_gpu():
     assert rc == -1
 
 
+def test_argument_validation_of_the_head_entry_points():
+    """Same for the lattice / MLP / loss entry points: unsupported widths and null pointers come
+    back as error codes with a message, nothing is launched."""
+    hip = pkg('hipops')
+    lib = hip.lib()
+    lib.ver_occ_mlp_image_bytes.restype = ctypes.c_long
+    assert lib.ver_occ_mlp_image_bytes() == 140 * 1024 and lib.ver_occ_mlp_vector_floats() == 6 * 128 + 16
+    buf = (ctypes.c_float * 16)()
+    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 64, 16, ctypes.c_float(1e-5), None)
+    assert rc == -2 and b'width' in lib.ver_last_error()                  # built for 128 / 16
+    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 128, 16, ctypes.c_float(1e-5), None)
+    assert rc == -1 and b'null' in lib.ver_last_error()
+    assert lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(0), 128, 16, ctypes.c_float(1e-5), None) == 0
+    rc = lib.ver_focal_loss_forward(None, None, None, ctypes.c_long(8), 10, ctypes.c_float(2), ctypes.c_float(.25), 0, None)
+    assert rc == -2 and b'multiple of 8' in lib.ver_last_error()
+    assert lib.ver_focal_loss_blocks(ctypes.c_long(0), 16) == 1
+    taps = (ctypes.c_int * 3)(0, 0, 0)
+    offs = (ctypes.c_long * 1)(8)
+    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(16), 1, 1, 1, 3, 2, 8, 1, 0, None)
+    assert rc == -1 and b'even' in lib.ver_last_error()                   # planar needs even H, W
+    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(12), 1, 1, 1, 2, 2, 8, 0, 0, None)
+    assert rc == -1 and b'outside the row' in lib.ver_last_error()        # tap block past the row end
+    rc = lib.ver_lattice_transpose(buf, buf, ctypes.c_long(3), 1, 1, 2, 2, 8, 0, 1, 0, None)
+    assert rc == -1 and b'stride' in lib.ver_last_error()
+    assert lib.ver_convt_weight_forward(None, None, ctypes.c_long(0), 1, None) == 0
+    rc = lib.ver_ln_relu_forward(buf, buf, buf, buf, buf, buf, ctypes.c_long(2), 96, ctypes.c_float(1e-5), 0, None)
+    assert rc == -2
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
 def test_ops_refuse_cpu_tensors():
     hip = pkg('hipops')

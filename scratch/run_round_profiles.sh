@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r01
 timeout 900 python bench.py --steps 4 --warmup 2 > gpurun_out/r01/bench_default.json 2> gpurun_out/r01/bench_default.err
 echo "bench done $?"
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01/trace -o trace -- python3 bench.py --steps 2 --warmup 1 --batch 32 --no-cpu-baseline > gpurun_out/r01/trace_bench.json 2> gpurun_out/r01/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/r01/trace -o trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r01/trace_bench.json 2> gpurun_out/r01/trace.err
 echo "trace done $?"
 python scratch/prof_summary.py kernels gpurun_out/r01/trace/trace_results.db gpurun_out/r01/bench_kernel_stats.csv; rm -rf gpurun_out/r01/trace
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 12
+#define VER_ABI_VERSION 13
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -183,30 +183,34 @@ int ver_lattice_im2col(const void* src, void* col, const int* taps, int ntaps,
 int ver_lattice_col2im(const void* grad_col, void* grad_src, const int* taps, int ntaps,
                        int B, int Z, int H, int W, int C, int dtype, void* stream);
 
-/* Generalised lattice gather / scatter used by the parity-class upsample layers: tap t of row r goes
- * to col[r * col_stride + col_offset[t] .. + C) (elements; offsets and stride multiples of 16
- * bytes; columns between tap blocks are left untouched -- the caller keeps constant-pattern columns
- * there); ntaps <= 32.  planar != 0: src / grad_src are four planes [B,Z,H/2,W/2,C] (plane 2*pm+pn
- * holds the positions (2y'+pm, 2x'+pn)) of the combined (H, W) lattice the rows enumerate.
+/* Generalised lattice gather / scatter used by the parity-class upsample layers.  Rows enumerate
+ * (b, zr < Zr, y, x); tap t reads the source position (zr + dz_t, y + dy_t, x + dx_t) of a lattice
+ * with Zs z-layers (zero outside) into col[r * col_stride + col_offset[t] .. + C) (elements; offsets
+ * and stride multiples of 16 bytes; columns between tap blocks are left untouched -- the caller keeps
+ * constant-pattern columns there); ntaps <= 64.  Source layouts (`layout`):
+ *   0 plain [B,Zs,H,W,C]      1 planar: four planes [B,Zs,H/2,W/2,C], plane 2*pm+pn = positions
+ *   (2y'+pm, 2x'+pn) of the combined (H, W) lattice      2 z-split [B,2,H,W,2,C] (Zs = 4): element
+ *   (b,z,y,x) at row (b, z&1, y, x), channel block z>>1      3 planar z-split: four planes of layout 2.
+ * scatter is the adjoint (gather form, no atomics): grad_src is overwritten in the source's layout.
  */
 int ver_lattice_gather(const void* src, void* col, const int* taps, const long* col_offset, long col_stride,
-                       int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype, void* stream);
+                       int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype, void* stream);
 int ver_lattice_scatter(const void* grad_col, void* grad_src, const int* taps, const long* col_offset,
-                        long col_stride, int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype,
+                        long col_stride, int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype,
                         void* stream);
 
 /* Layout changes of the coarse-to-fine head (LDS-tiled transposes):
  *   ver_convt_weight_forward : ConvTranspose3d weight f32 [pairs = Ci*Co][3*5*5] (the reference's
  *       parameter layout, head:251-258) -> correlation taps [75][pairs] in `dtype`, tap (a,b,c) =
  *       weight[.., 2-a, 4-b, 4-c];  _backward: gradient of the taps -> f32 gradient of the weight.
- *   ver_lattice_transpose    : even lattice channels-last (plain [B,Z,H,W,C] or planar
- *       4 x [B,Z,H/2,W/2,C]) <-> channel-first rows cf[b*cf_stride + ((c*Z + z)*H + y)*W + x]
+ *   ver_lattice_transpose    : even lattice channels-last (one of the four layouts of
+ *       ver_lattice_gather) <-> channel-first rows cf[b*cf_stride + ((c*Z + z)*H + y)*W + x]
  *       (to_channel_first != 0: channels_last is read; else it is written).
  */
 int ver_convt_weight_forward(const float* weight, void* taps, long pairs, int dtype, void* stream);
 int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pairs, int dtype, void* stream);
 int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
-                          int C, int planar, int to_channel_first, int dtype, void* stream);
+                          int C, int layout, int to_channel_first, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused LayerNorm(128) + ReLU of the occupancy MLP (`occ_branches`, layers 1-2 and 4-5:

@@ -39,19 +39,20 @@ def test_restated_cfg_builds_variants():
         r.build_head(dict(cases.vocc_head_cfg(), add_layout=True))
 
 
-def test_upsample_lattice_equals_conv_transpose():
+@pytest.mark.parametrize('Z', [4, 3])            # Z = 4: z-split path (two z taps, N = 2C); else the 27-tap path
+def test_upsample_lattice_equals_conv_transpose(Z):
     up = pkg('dense_heads.upsample')
     torch.manual_seed(1)
-    x = torch.randn(2, 6, 4, 5, 7, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(2, 6, Z, 5, 7, dtype=torch.float64, requires_grad=True)
     ws = [(torch.randn(6, 6, 3, 5, 5, dtype=torch.float64) * 0.1).requires_grad_(True) for _ in range(3)]
     bs = [torch.randn(6, dtype=torch.float64, requires_grad=True) for _ in range(3)]
     y = up.upsample_dense(x, ws, bs)
     r = x
     for w, b in zip(ws, bs):
         r = F.conv_transpose3d(r, w, b, **up.GEOM)
-    assert y.shape == r.shape == (2, 6, 4, 40, 56)
+    assert y.shape == r.shape == (2, 6, Z, 40, 56)
     assert maxdiff(y, r) < 1e-12
-    assert maxdiff(y[:, :, :, 1::2], bs[2].view(1, 6, 1, 1, 1).expand(2, 6, 4, 20, 56)) == 0.0
+    assert maxdiff(y[:, :, :, 1::2], bs[2].view(1, 6, 1, 1, 1).expand(2, 6, Z, 20, 56)) == 0.0
     g = torch.randn_like(r)
     for a, b in zip(torch.autograd.grad(y, [x] + ws + bs, g), torch.autograd.grad(r, [x] + ws + bs, g)):
         assert maxdiff(a, b) < 1e-10

@@ -355,7 +355,7 @@ def test_lattice_gather_scatter_with_offsets(dtype, planar):
     the slice-based torch form used on CPU; columns between the tap blocks stay untouched."""
     ups = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(21)
-    b, z, hc, wc, c = 2, 4, 6, 4, 16
+    b, z, hc, wc, c = 2, 3, 6, 4, 16
     kt = 27 * c + 4 * ups._PW
     src = torch.randn(b, z, hc, wc, c, generator=gen).to(dtype)
     e_cpu = ups.plain_to_planar(src).contiguous() if planar else src
@@ -368,6 +368,35 @@ def test_lattice_gather_scatter_with_offsets(dtype, planar):
     d_a = torch.randn(b * z * hc * wc, kt, generator=gen).to(dtype)
     want = ups._scatter27(d_a.double(), planar, tuple(e_cpu.shape), c, hc, wc)
     got = ups._scatter27(d_a.to(DEV), planar, tuple(e_cpu.shape), c, hc, wc)
+    assert got.shape == e_cpu.shape and got.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 4e-2
+    assert close(got.float().cpu(), want, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', [0, 2, 3])
+def test_lattice_gather_scatter_z_split(dtype, layout):
+    """The Z = 4 form: rows (b, z & 1, y, x), two z taps (dz in {0, 2}); source plain (first layer),
+    z-split or planar z-split (what the layers' GEMMs leave behind)."""
+    ups = pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(23 + layout)
+    b, hc, wc, c = 2, 6, 4, 16
+    plain = torch.randn(b, 4, hc, wc, c, generator=gen).to(dtype)
+    e_cpu = ups._from_plain(plain, layout)
+    if layout == 0:
+        taps, offs, _, _ = ups._layer0_z4_plan(c, 'cpu')
+        kt = 50 * c
+    else:
+        _, kt, _, taps, offs = ups._layer_plan_z4(c, 'cpu')
+    m = b * 2 * hc * wc
+    a_cpu = torch.full((m, kt), 7.0, dtype=dtype)
+    ups._gather_z4(e_cpu, layout, a_cpu, taps, offs, c, hc, wc)
+    a_gpu = torch.full((m, kt), 7.0, dtype=dtype, device=DEV)
+    ups._gather_z4(e_cpu.to(DEV), layout, a_gpu, taps, offs, c, hc, wc)
+    assert torch.equal(a_gpu.cpu(), a_cpu)
+    d_a = torch.randn(m, kt, generator=gen).to(dtype)
+    want = ups._scatter_z4(d_a.double(), layout, tuple(e_cpu.shape), taps, offs, c, hc, wc)
+    got = ups._scatter_z4(d_a.to(DEV), layout, tuple(e_cpu.shape), taps, offs, c, hc, wc)
     assert got.shape == e_cpu.shape and got.dtype == dtype
     tol = 1e-5 if dtype == torch.float32 else 4e-2
     assert close(got.float().cpu(), want, atol=tol, rtol=tol)
@@ -388,17 +417,17 @@ def test_convt_weight_taps_and_lattice_transpose(dtype):
     got.backward(g.to(DEV))
     want_g = g.float().view(3, 5, 5, 24, 40).permute(3, 4, 0, 1, 2).flip(2, 3, 4)
     assert torch.equal(wd.grad.cpu(), want_g)
-    b, z, h, wl, c = 2, 3, 6, 10, 200                      # C not a multiple of the 128-channel tile
+    b, z, h, wl, c = 2, 4, 6, 10, 200                      # C not a multiple of the 128-channel tile
     plain = torch.randn(b, z, h, wl, c, generator=gen).to(dtype)
     L = c * z * h * wl
-    for planar in (False, True):
-        src = ups.plain_to_planar(plain).contiguous() if planar else plain
+    for layout in (0, 1, 2, 3):                            # plain, planar, z-split, planar z-split
+        src = ups._from_plain(plain, layout)
         cf = torch.full((b, L + 5), 3.0, dtype=dtype, device=DEV)
-        hip.lattice_transpose(src.to(DEV), cf, (h, wl), planar, True)
+        hip.lattice_transpose(src.to(DEV), cf, (h, wl), layout, True)
         assert torch.equal(cf[:, :L].cpu().view(b, c, z, h, wl), plain.permute(0, 4, 1, 2, 3))
         assert bool((cf[:, L:] == 3.0).all())
         back = torch.empty_like(src, device=DEV)
-        hip.lattice_transpose(back, cf, (h, wl), planar, False)
+        hip.lattice_transpose(back, cf, (h, wl), layout, False)
         assert torch.equal(back.cpu(), src)
 
 

@@ -18,32 +18,79 @@ struct TapList {
 
 // Generalised form (ver_lattice_gather / ver_lattice_scatter): every tap has its own column offset
 // inside a row of `col_stride` elements (the upsample keeps constant-pattern columns between tap
-// blocks so that each output parity class reads ONE column range of a shared 27-tap matrix), and the
-// source may be PLANAR: four planes [B,Z,H/2,W/2,C] holding the positions (2y'+pm, 2x'+pn) of the
-// combined (H, W) lattice, plane index 2*pm + pn -- the layout the previous layer's four class
-// GEMMs leave behind, so the lattice is never interleaved.
+// blocks so that each output parity class reads ONE column range of a shared tap matrix).  The rows
+// enumerate (b, zr < Zr, y, x); tap t reads source position (zr + dz_t, y + dy_t, x + dx_t) of a
+// lattice with Zs z-layers (zero outside).  Source layouts (`layout`):
+//   0 plain      [B, Zs, H, W, C]
+//   1 planar     4 x [B, Zs, H/2, W/2, C]: plane 2*pm+pn holds the positions (2y'+pm, 2x'+pn) of the
+//                combined (H, W) lattice -- what the previous layer's four class GEMMs leave behind
+//   2 z-split    [B, 2, H, W, 2, C] (Zs = 4): element (b,z,y,x) at row (b, z&1, y, x), channel block z>>1
+//                -- the output of the Z = 4 layers, whose GEMM yields both z halves side by side (N = 2C)
+//   3 planar z-split  4 x [B, 2, H/2, W/2, 2, C]
 struct TapListEx {
     int n;
-    signed char dz[32], dy[32], dx[32];
-    int off[32];        // column offset of the tap block, in 16-byte vectors
+    signed char dz[64], dy[64], dx[64];
+    int off[64];        // column offset of the tap block, in 16-byte vectors
 };
 
-template <bool PLANAR>
-__device__ __forceinline__ long lattice_index(int b, int z, int y, int x, int B, int Z, int H, int W) {
-    if (PLANAR) {
+// index of the C-vector of lattice position (b, z, y, x), in units of C elements
+template <int LAYOUT>
+__device__ __forceinline__ long lattice_index(int b, int z, int y, int x, int B, int Zs, int H, int W) {
+    if (LAYOUT == 1) {
         const int plane = ((y & 1) << 1) | (x & 1);
-        return ((((long)plane * B + b) * Z + z) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+        return ((((long)plane * B + b) * Zs + z) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
     }
-    return (((long)b * Z + z) * H + y) * W + x;
+    if (LAYOUT == 2) return (((((long)b * 2 + (z & 1)) * H + y) * W + x) << 1) + (z >> 1);
+    if (LAYOUT == 3) {
+        const int plane = ((y & 1) << 1) | (x & 1);
+        return ((((((long)plane * B + b) * 2 + (z & 1)) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) << 1) + (z >> 1);
+    }
+    return (((long)b * Zs + z) * H + y) * W + x;
+}
+
+// storage index (in C-vectors) -> (b, z, y, x) of the combined lattice
+template <int LAYOUT>
+__device__ __forceinline__ void lattice_decode(long r, int B, int Zs, int H, int W, int& b, int& z, int& y, int& x) {
+    if (LAYOUT == 0) {
+        x = (int)(r % W); r /= W;
+        y = (int)(r % H); r /= H;
+        z = (int)(r % Zs);
+        b = (int)(r / Zs);
+    } else if (LAYOUT == 1) {
+        const int Wh = W >> 1, Hh = H >> 1;
+        const int xh = (int)(r % Wh); r /= Wh;
+        const int yh = (int)(r % Hh); r /= Hh;
+        z = (int)(r % Zs); r /= Zs;
+        b = (int)(r % B);
+        const int plane = (int)(r / B);
+        y = 2 * yh + (plane >> 1);
+        x = 2 * xh + (plane & 1);
+    } else if (LAYOUT == 2) {
+        const int zh = (int)(r & 1); r >>= 1;
+        x = (int)(r % W); r /= W;
+        y = (int)(r % H); r /= H;
+        z = 2 * zh + (int)(r & 1);
+        b = (int)(r >> 1);
+    } else {
+        const int Wh = W >> 1, Hh = H >> 1;
+        const int zh = (int)(r & 1); r >>= 1;
+        const int xh = (int)(r % Wh); r /= Wh;
+        const int yh = (int)(r % Hh); r /= Hh;
+        z = 2 * zh + (int)(r & 1); r >>= 1;
+        b = (int)(r % B);
+        const int plane = (int)(r / B);
+        y = 2 * yh + (plane >> 1);
+        x = 2 * xh + (plane & 1);
+    }
 }
 
 // One workgroup walks rows; inside a row the (tap, vector) index advances without divisions
 // (the first version decoded every 16-byte vector from a flat index: five runtime divisions each).
-template <bool PLANAR>
+template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict__ src, uint4* __restrict__ col,
-                                                        TapListEx taps, long stride_v, int B, int Z, int H, int W,
-                                                        int CV) {
-    const long rows = (long)B * Z * H * W;
+                                                        TapListEx taps, long stride_v, int B, int Zr, int Zs, int H,
+                                                        int W, int CV) {
+    const long rows = (long)B * Zr * H * W;
     const int per_row = taps.n * CV;
     const int t0 = (int)threadIdx.x / CV, v0 = (int)threadIdx.x % CV;
     const int dt = 256 / CV, dv = 256 % CV;
@@ -53,15 +100,15 @@ __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict_
         r /= W;
         const int y = (int)(r % H);
         r /= H;
-        const int z = (int)(r % Z);
-        const int b = (int)(r / Z);
+        const int z = (int)(r % Zr);
+        const int b = (int)(r / Zr);
         uint4* dst = col + row * stride_v;
         int t = t0, v = v0;
         for (int i = threadIdx.x; i < per_row; i += 256) {
             const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
             uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (sz >= 0 && sz < Z && sy >= 0 && sy < H && sx >= 0 && sx < W)
-                val = src[lattice_index<PLANAR>(b, sz, sy, sx, B, Z, H, W) * CV + v];
+            if (sz >= 0 && sz < Zs && sy >= 0 && sy < H && sx >= 0 && sx < W)
+                val = src[lattice_index<LAYOUT>(b, sz, sy, sx, B, Zs, H, W) * CV + v];
             dst[taps.off[t] + v] = val;
             t += dt;
             v += dv;
@@ -73,43 +120,23 @@ __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict_
     }
 }
 
-template <bool BF16, bool PLANAR>
+template <bool BF16, int LAYOUT>
 __global__ __launch_bounds__(256) void k_lattice_scatter(const uint4* __restrict__ gcol, uint4* __restrict__ gsrc,
-                                                         TapListEx taps, long stride_v, int B, int Z, int H, int W,
-                                                         int CV) {
+                                                         TapListEx taps, long stride_v, int B, int Zr, int Zs, int H,
+                                                         int W, int CV) {
     // one thread = one 16-byte vector of the source gradient, enumerated in STORAGE order
-    const long total = (long)B * Z * H * W * CV;
+    const long total = (long)B * Zs * H * W * CV;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int v = (int)(i % CV);
-        long r = i / CV;
         int b, z, y, x;
-        if (PLANAR) {
-            const int Wh = W >> 1, Hh = H >> 1;
-            const int xh = (int)(r % Wh);
-            long q = r / Wh;
-            const int yh = (int)(q % Hh);
-            q /= Hh;
-            z = (int)(q % Z);
-            q /= Z;
-            b = (int)(q % B);
-            const int plane = (int)(q / B);
-            y = 2 * yh + (plane >> 1);
-            x = 2 * xh + (plane & 1);
-        } else {
-            x = (int)(r % W);
-            long q = r / W;
-            y = (int)(q % H);
-            q /= H;
-            z = (int)(q % Z);
-            b = (int)(q / Z);
-        }
+        lattice_decode<LAYOUT>(i / CV, B, Zs, H, W, b, z, y, x);
         float acc[BF16 ? 8 : 4];
 #pragma unroll
         for (int j = 0; j < (BF16 ? 8 : 4); ++j) acc[j] = 0.0f;
         for (int t = 0; t < taps.n; ++t) {
             const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
-            if (oz < 0 || oz >= Z || oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
-            const uint4 g = gcol[((((long)b * Z + oz) * H + oy) * W + ox) * stride_v + taps.off[t] + v];
+            if (oz < 0 || oz >= Zr || oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
+            const uint4 g = gcol[((((long)b * Zr + oz) * H + oy) * W + ox) * stride_v + taps.off[t] + v];
             if (BF16) {
                 const uint32_t w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -282,7 +309,7 @@ extern "C" int ver_lattice_col2im(const void* gcol, void* gsrc, const int* taps,
 
 namespace {
 int fill_taps_ex(TapListEx& tl, const int* taps, const long* col_offset, int ntaps, long col_stride, int C, int esize) {
-    VER_REQUIRE(taps && col_offset && ntaps > 0 && ntaps <= 32, VER_EINVAL, "ver_lattice: 1..32 taps with offsets required");
+    VER_REQUIRE(taps && col_offset && ntaps > 0 && ntaps <= 64, VER_EINVAL, "ver_lattice: 1..64 taps with offsets required");
     VER_REQUIRE(col_stride > 0 && (col_stride * esize) % 16 == 0, VER_EINVAL, "ver_lattice: row stride must be a multiple of 16 bytes");
     tl.n = ntaps;
     for (int t = 0; t < ntaps; ++t) {
@@ -297,56 +324,75 @@ int fill_taps_ex(TapListEx& tl, const int* taps, const long* col_offset, int nta
     }
     return VER_OK;
 }
+int check_layout(const char* who, int layout, int Zr, int Zs, int H, int W) {
+    VER_REQUIRE(layout >= 0 && layout <= 3, VER_EINVAL, "%s: layout %d", who, layout);
+    VER_REQUIRE(Zr > 0 && Zs > 0, VER_EINVAL, "%s: bad z sizes", who);
+    VER_REQUIRE(!(layout & 1) || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "%s: planar source needs even H, W", who);
+    VER_REQUIRE(layout < 2 || Zs == 4, VER_EUNSUPPORTED, "%s: the z-split layouts are built for 4 z-layers", who);
+    return VER_OK;
+}
 unsigned lattice_blocks(long total) {
     return (unsigned)((total + 255) / 256 < 256L * 32 ? (total + 255) / 256 : 256L * 32);
 }
 }  // namespace
 
 extern "C" int ver_lattice_gather(const void* src, void* col, const int* taps, const long* col_offset, long col_stride,
-                                  int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype, void* stream) {
-    int rc = check_lattice(src, col, B, Z, H, W, C, dtype);
+                                  int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype,
+                                  void* stream) {
+    int rc = check_lattice(src, col, B, Zs, H, W, C, dtype);
     if (rc) return rc;
-    VER_REQUIRE(!planar || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_gather: planar source needs even H, W");
+    rc = check_layout("ver_lattice_gather", layout, Zr, Zs, H, W);
+    if (rc) return rc;
     const int esize = dtype == VER_BF16 ? 2 : 4;
     TapListEx tl;
     rc = fill_taps_ex(tl, taps, col_offset, ntaps, col_stride, C, esize);
     if (rc) return rc;
     if (B == 0) return VER_OK;
     const int CV = C * esize / 16;
-    const long rows = (long)B * Z * H * W;
+    const long rows = (long)B * Zr * H * W;
     const long stride_v = col_stride * esize / 16;
     const unsigned blocks = (unsigned)(rows < 256L * 32 ? rows : 256L * 32);
-    if (planar)
-        hipLaunchKernelGGL(k_lattice_gather<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)src, (uint4*)col, tl, stride_v, B, Z, H, W, CV);
-    else
-        hipLaunchKernelGGL(k_lattice_gather<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           (const uint4*)src, (uint4*)col, tl, stride_v, B, Z, H, W, CV);
+    hipStream_t st = (hipStream_t)stream;
+#define VER_GATHER(L)                                                                                                 \
+    hipLaunchKernelGGL(k_lattice_gather<L>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)col, tl, stride_v, \
+                       B, Zr, Zs, H, W, CV)
+    if (layout == 0) VER_GATHER(0);
+    else if (layout == 1) VER_GATHER(1);
+    else if (layout == 2) VER_GATHER(2);
+    else VER_GATHER(3);
+#undef VER_GATHER
     return ver_check_launch("ver_lattice_gather");
 }
 
 extern "C" int ver_lattice_scatter(const void* gcol, void* gsrc, const int* taps, const long* col_offset,
-                                   long col_stride, int ntaps, int B, int Z, int H, int W, int C, int planar, int dtype,
-                                   void* stream) {
-    int rc = check_lattice(gcol, gsrc, B, Z, H, W, C, dtype);
+                                   long col_stride, int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout,
+                                   int dtype, void* stream) {
+    int rc = check_lattice(gcol, gsrc, B, Zs, H, W, C, dtype);
     if (rc) return rc;
-    VER_REQUIRE(!planar || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_scatter: planar source needs even H, W");
+    rc = check_layout("ver_lattice_scatter", layout, Zr, Zs, H, W);
+    if (rc) return rc;
     const int esize = dtype == VER_BF16 ? 2 : 4;
     TapListEx tl;
     rc = fill_taps_ex(tl, taps, col_offset, ntaps, col_stride, C, esize);
     if (rc) return rc;
     if (B == 0) return VER_OK;
     const int CV = C * esize / 16;
-    const long total = (long)B * Z * H * W * CV;
+    const long total = (long)B * Zs * H * W * CV;
     const long stride_v = col_stride * esize / 16;
     hipStream_t st = (hipStream_t)stream;
-#define VER_SCATTER(BF, PL)                                                                                         \
-    hipLaunchKernelGGL((k_lattice_scatter<BF, PL>), dim3(lattice_blocks(total)), dim3(256), 0, st, (const uint4*)gcol, \
-                       (uint4*)gsrc, tl, stride_v, B, Z, H, W, CV)
+#define VER_SCATTER(BF, L)                                                                                         \
+    hipLaunchKernelGGL((k_lattice_scatter<BF, L>), dim3(lattice_blocks(total)), dim3(256), 0, st, (const uint4*)gcol, \
+                       (uint4*)gsrc, tl, stride_v, B, Zr, Zs, H, W, CV)
     if (dtype == VER_BF16) {
-        if (planar) VER_SCATTER(true, true); else VER_SCATTER(true, false);
+        if (layout == 0) VER_SCATTER(true, 0);
+        else if (layout == 1) VER_SCATTER(true, 1);
+        else if (layout == 2) VER_SCATTER(true, 2);
+        else VER_SCATTER(true, 3);
     } else {
-        if (planar) VER_SCATTER(false, true); else VER_SCATTER(false, false);
+        if (layout == 0) VER_SCATTER(false, 0);
+        else if (layout == 1) VER_SCATTER(false, 1);
+        else if (layout == 2) VER_SCATTER(false, 2);
+        else VER_SCATTER(false, 3);
     }
 #undef VER_SCATTER
     return ver_check_launch("ver_lattice_scatter");

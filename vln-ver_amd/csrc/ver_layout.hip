@@ -64,18 +64,24 @@ __global__ __launch_bounds__(256) void k_convt_weight_bwd(const void* __restrict
 // ---- lattice <-> channel-first rows.  One workgroup = one (b, z, y) row of W positions x 128 channels.
 namespace {
 constexpr int kCh = 128;
-template <bool PLANAR>
+// same source layouts as ver_lattice_gather (0 plain, 1 planar, 2 z-split, 3 planar z-split)
+template <int LAYOUT>
 __device__ __forceinline__ long cl_index(int b, int z, int y, int x, int B, int Z, int H, int W) {
-    if (PLANAR) {
+    if (LAYOUT == 1) {
         const int plane = ((y & 1) << 1) | (x & 1);
         return ((((long)plane * B + b) * Z + z) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+    }
+    if (LAYOUT == 2) return (((((long)b * 2 + (z & 1)) * H + y) * W + x) << 1) + (z >> 1);
+    if (LAYOUT == 3) {
+        const int plane = ((y & 1) << 1) | (x & 1);
+        return ((((((long)plane * B + b) * 2 + (z & 1)) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) << 1) + (z >> 1);
     }
     return (((long)b * Z + z) * H + y) * W + x;
 }
 }  // namespace
 
 // T = 2-byte or 4-byte element.  TO_CF: channels-last -> channel-first rows; else the reverse.
-template <typename T, bool PLANAR, bool TO_CF>
+template <typename T, int LAYOUT, bool TO_CF>
 __global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T* __restrict__ cf, long cf_stride,
                                                            int B, int Z, int H, int W, int C) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T
     if (TO_CF) {
         for (int i = threadIdx.x; i < W * kCh; i += 256) {
             const int x = i / kCh, c = i % kCh;
-            if (c < nc) tile[c * wp + x] = cl[cl_index<PLANAR>(b, z, y, x, B, Z, H, W) * C + c0 + c];
+            if (c < nc) tile[c * wp + x] = cl[cl_index<LAYOUT>(b, z, y, x, B, Z, H, W) * C + c0 + c];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < kCh * W; i += 256) {
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T
         __syncthreads();
         for (int i = threadIdx.x; i < W * kCh; i += 256) {
             const int x = i / kCh, c = i % kCh;
-            if (c < nc) cl[cl_index<PLANAR>(b, z, y, x, B, Z, H, W) * C + c0 + c] = tile[c * wp + x];
+            if (c < nc) cl[cl_index<LAYOUT>(b, z, y, x, B, Z, H, W) * C + c0 + c] = tile[c * wp + x];
         }
     }
 }
@@ -140,10 +146,12 @@ extern "C" int ver_convt_weight_backward(const void* grad_taps, float* grad_weig
 }
 
 extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
-                                     int C, int planar, int to_channel_first, int dtype, void* stream) {
+                                     int C, int layout, int to_channel_first, int dtype, void* stream) {
     VER_REQUIRE(B >= 0 && Z > 0 && H > 0 && W > 0 && C > 0, VER_EINVAL, "ver_lattice_transpose: bad sizes");
     VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_lattice_transpose: dtype %d", dtype);
-    VER_REQUIRE(!planar || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_transpose: planar needs even H, W");
+    VER_REQUIRE(layout >= 0 && layout <= 3, VER_EINVAL, "ver_lattice_transpose: layout %d", layout);
+    VER_REQUIRE(!(layout & 1) || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_transpose: planar needs even H, W");
+    VER_REQUIRE(layout < 2 || Z == 4, VER_EUNSUPPORTED, "ver_lattice_transpose: the z-split layouts are built for 4 z-layers");
     VER_REQUIRE(cf_stride >= (long)C * Z * H * W, VER_EINVAL, "ver_lattice_transpose: row stride too small");
     if (B == 0) return VER_OK;
     VER_REQUIRE(channels_last && channel_first, VER_EINVAL, "ver_lattice_transpose: null pointer argument");
@@ -152,16 +160,22 @@ extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, l
     VER_REQUIRE(lds <= 64 * 1024, VER_EUNSUPPORTED, "ver_lattice_transpose: W = %d too wide", W);
     const dim3 grid((unsigned)((long)B * Z * H), (unsigned)((C + kCh - 1) / kCh));
     hipStream_t st = (hipStream_t)stream;
-#define VER_TR(T, PL, CF)                                                                                             \
-    hipLaunchKernelGGL((k_lattice_transpose<T, PL, CF>), grid, dim3(256), lds, st, (T*)channels_last, (T*)channel_first, \
+#define VER_TR(T, L, CF)                                                                                             \
+    hipLaunchKernelGGL((k_lattice_transpose<T, L, CF>), grid, dim3(256), lds, st, (T*)channels_last, (T*)channel_first, \
                        cf_stride, B, Z, H, W, C)
+#define VER_TR_L(T, CF)                  \
+    do {                                 \
+        if (layout == 0) VER_TR(T, 0, CF);      \
+        else if (layout == 1) VER_TR(T, 1, CF); \
+        else if (layout == 2) VER_TR(T, 2, CF); \
+        else VER_TR(T, 3, CF);                  \
+    } while (0)
     if (dtype == VER_BF16) {
-        if (planar) { if (to_channel_first) VER_TR(uint16_t, true, true); else VER_TR(uint16_t, true, false); }
-        else        { if (to_channel_first) VER_TR(uint16_t, false, true); else VER_TR(uint16_t, false, false); }
+        if (to_channel_first) VER_TR_L(uint16_t, true); else VER_TR_L(uint16_t, false);
     } else {
-        if (planar) { if (to_channel_first) VER_TR(float, true, true); else VER_TR(float, true, false); }
-        else        { if (to_channel_first) VER_TR(float, false, true); else VER_TR(float, false, false); }
+        if (to_channel_first) VER_TR_L(float, true); else VER_TR_L(float, false);
     }
+#undef VER_TR_L
 #undef VER_TR
     return ver_check_launch("ver_lattice_transpose");
 }

@@ -143,8 +143,13 @@ class _OccProjLattice(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, up_bias, weight, bias, plan):
-        planar = e.dim() == 6                            # [4,bs,Z,Hl/2,Wl/2,C], plane 2pm+pn = (2y+pm, 2x+pn)
-        if planar:
+        # lattice layouts of the upsample: 0 plain [bs,Z,Hl,Wl,C], 1 planar [4,bs,Z,Hl/2,Wl/2,C]
+        # (plane 2pm+pn = (2y+pm, 2x+pn)), 3 planar z-split [4,bs,2,Hl/2,Wl/2,2,C] (Z = 4)
+        layout = {5: 0, 6: 1, 7: 3}[e.dim()]
+        if layout == 3:
+            _, bs, _, hh, wh, _, C = e.shape
+            Z, Hl, Wl = 4, 2 * hh, 2 * wh
+        elif layout == 1:
             _, bs, Z, hh, wh, C = e.shape
             Hl, Wl = 2 * hh, 2 * wh
         else:
@@ -156,12 +161,10 @@ class _OccProjLattice(torch.autograd.Function):
         lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                                # channel-first lattice
         if e.is_cuda and dt in (torch.float32, torch.bfloat16):
             from ..hipops import lattice_transpose
-            lattice_transpose(e.contiguous(), lat, (Hl, Wl), planar, True)
-        elif planar:
-            for p in range(4):
-                lat5[:, :, :, p >> 1::2, p & 1::2].copy_(e[p].permute(0, 4, 1, 2, 3))
+            lattice_transpose(e.contiguous(), lat, (Hl, Wl), layout, True)
         else:
-            lat5.copy_(e.permute(0, 4, 1, 2, 3))
+            from .upsample import _to_plain
+            lat5.copy_(_to_plain(e, layout).permute(0, 4, 1, 2, 3))
         lat[:, L:L + C] = up_bias.to(dt)
         lat[:, L + C] = 1
         lat[:, L + C + 1] = 0
@@ -178,7 +181,7 @@ class _OccProjLattice(torch.autograd.Function):
             torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
             operands.append(a)
             weights.append(wa)
-        ctx.plan, ctx.shape, ctx.planar = plan, (bs, Z, Hl, Wl, C), planar
+        ctx.plan, ctx.shape, ctx.layout, ctx.e_shape = plan, (bs, Z, Hl, Wl, C), layout, tuple(e.shape)
         ctx.save_for_backward(weight, *operands, *weights)
         return out
 
@@ -212,14 +215,11 @@ class _OccProjLattice(torch.autograd.Function):
         d5 = d_lat.view(bs, C, Z, Hl, Wl)
         if d_lat.is_cuda and dt in (torch.float32, torch.bfloat16):
             from ..hipops import lattice_transpose
-            d_e = d_lat.new_empty((4, bs, Z, Hl // 2, Wl // 2, C) if ctx.planar else (bs, Z, Hl, Wl, C))
-            lattice_transpose(d_e, d_lat, (Hl, Wl), ctx.planar, False)
-        elif ctx.planar:
-            d_e = d_lat.new_empty(4, bs, Z, Hl // 2, Wl // 2, C)
-            for p in range(4):
-                d_e[p].copy_(d5[:, :, :, p >> 1::2, p & 1::2].permute(0, 2, 3, 4, 1))
+            d_e = d_lat.new_empty(ctx.e_shape)
+            lattice_transpose(d_e, d_lat, (Hl, Wl), ctx.layout, False)
         else:
-            d_e = d5.permute(0, 2, 3, 4, 1)
+            from .upsample import _from_plain
+            d_e = _from_plain(d5.permute(0, 2, 3, 4, 1), ctx.layout)
         return d_e, d_up, d_weight, d_bias, None
 
 
@@ -238,14 +238,17 @@ class _SelectRows(torch.autograd.Function):
 
 
 def occ_proj_from_lattice(e, up_bias, weight, bias):
-    """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C] or planar
-    [4, bs, Z, Hl/2, Wl/2, C]; up_bias: bias of
+    """e: even lattice of the upsample output, channels-last [bs, Z, Hl, Wl, C], planar
+    [4, bs, Z, Hl/2, Wl/2, C] or planar z-split [4, bs, 2, Hl/2, Wl/2, 2, C]; up_bias: bias of
     the last ConvTranspose3d [C]; weight [out, Z*C], bias [out] of ``occ_proj``.
     Returns ``(rows [bs*Hf*Wf, out] in group-major order, plan)`` -- ``rows_to_voxels`` maps
     anything computed row-wise from it to the (a, b) order of
     ``occ_proj(Y.view(bs,Z,Hf,Wf,C).permute(0,2,3,1,4).flatten(3))`` -- or None when the geometry has
     no whole-token structure (the caller then takes the dense path)."""
-    if e.dim() == 6:                                     # planar lattice from the upsample
+    if e.dim() == 7:                                     # planar z-split lattice (Z = 4)
+        _, bs, _, hh, wh, _, C = e.shape
+        Z, Hl, Wl = 4, 2 * hh, 2 * wh
+    elif e.dim() == 6:                                   # planar lattice
         _, bs, Z, hh, wh, C = e.shape
         Hl, Wl = 2 * hh, 2 * wh
     else:

@@ -254,7 +254,7 @@ def _gather27(e, planar, a_mat, ci, hc, wc):
     offs = [_block_offset(t, ci) for t in range(27)]
     if e.is_cuda:
         from ..hipops import lattice_gather
-        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), planar)
+        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), 1 if planar else 0)
         return
     src = planar_to_plain(e) if planar else e
     b, z = src.shape[:2]
@@ -270,7 +270,7 @@ def _scatter27(d_a, planar, shape, ci, hc, wc):
     offs = [_block_offset(t, ci) for t in range(27)]
     if d_a.is_cuda:
         from ..hipops import lattice_scatter
-        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), planar)
+        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), 1 if planar else 0)
     b, z = (shape[1], shape[2]) if planar else (shape[0], shape[1])
     pad = d_a.new_zeros(b, z + 4, hc + 2, wc + 2, ci)
     view = d_a.view(b, z, hc, wc, -1)
@@ -360,6 +360,300 @@ def _layer_lattice(e, k, bias, prev_bias, planar):
     return _LatticeLayer.apply(e, k, bias, prev_bias, planar)
 
 
+
+# ------------------------------------------------------------------------------------------------
+# Z = 4 (vocc.py: bev_z = 4).  The z taps of the stack are dz in {-2, 0, +2}: with four z-layers
+# every output layer has exactly TWO in-range taps -- z = 0,1 read the input layers (z, z+2), z = 2,3
+# read (z-2, z) -- and both halves read the SAME pair (zl, zl+2), zl = z & 1.  So the tap matrix needs
+# only the rows (b, zl, y, x) (half of them) and 2 instead of 3 z blocks per (dy, dx); the two output
+# halves come out of ONE GEMM side by side, A [B*2*H*W, K] x [W_lo | W_hi] [K, 2*Co] with
+# W_lo = K[dz = 0], K[dz = +2] and W_hi = K[dz = -2], K[dz = 0].  A third fewer FLOPs in all three
+# layers, a third of the tap-matrix traffic, N = 1536 instead of 768.  Lattices are kept Z-SPLIT,
+# [B, 2 (zl), H, W, 2 (zh), C] (z = 2*zh + zl): exactly the GEMM output [rows, 2*Co].
+ZS_PLAIN, ZS_PLANAR, ZS_SPLIT, ZS_PLANAR_SPLIT = 0, 1, 2, 3          # = hipops lattice layouts
+_PW2 = 2 * _PW                                                         # lo | hi constant blocks
+
+
+def zs_to_plain(e):
+    """[B,2,H,W,2,C] -> [B,4,H,W,C]"""
+    b, _, h, w, _, c = e.shape
+    return e.permute(0, 4, 1, 2, 3, 5).reshape(b, 4, h, w, c)
+
+
+def plain_to_zs(e):
+    b, z, h, w, c = e.shape
+    assert z == 4
+    return e.reshape(b, 2, 2, h, w, c).permute(0, 2, 3, 4, 1, 5).contiguous()
+
+
+def planar_zs_to_plain(e):
+    """[4,B,2,H,W,2,C] -> [B,4,2H,2W,C]"""
+    _, b, _, h, w, _, c = e.shape
+    out = e.new_empty(b, 4, 2 * h, 2 * w, c)
+    for p, (pm, pn) in enumerate(_CLASSES):
+        out[:, :, pm::2, pn::2] = zs_to_plain(e[p])
+    return out
+
+
+def plain_to_planar_zs(e):
+    return torch.stack([plain_to_zs(e[:, :, pm::2, pn::2]) for pm, pn in _CLASSES])
+
+
+def lattice_to_plain(e):
+    """lattice as ``upsample_lattice`` returns it (plain, planar or planar z-split) -> channels-last
+    [B,Z,H,W,C]"""
+    if e.dim() == 7:
+        return planar_zs_to_plain(e)
+    if e.dim() == 6:
+        return planar_to_plain(e)
+    return e
+
+
+def _to_plain(e, layout):
+    return {ZS_PLAIN: lambda t: t, ZS_PLANAR: planar_to_plain, ZS_SPLIT: zs_to_plain,
+            ZS_PLANAR_SPLIT: planar_zs_to_plain}[layout](e)
+
+
+def _from_plain(e, layout):
+    return {ZS_PLAIN: lambda t: t.contiguous(), ZS_PLANAR: lambda t: plain_to_planar(t).contiguous(),
+            ZS_SPLIT: plain_to_zs, ZS_PLANAR_SPLIT: lambda t: plain_to_planar_zs(t).contiguous()}[layout](e)
+
+
+def _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc):
+    """rows (b, zl, y, x); tap (dz in {0,2}, dy, dx) reads input layer zl + dz."""
+    if e.is_cuda:
+        from ..hipops import lattice_gather
+        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2)
+        return
+    src = _to_plain(e, layout)
+    b = src.shape[0]
+    py = max(abs(t[1]) for t in taps)
+    px = max(abs(t[2]) for t in taps)
+    pad = F.pad(src, (0, 0, px, px, py, py))
+    view = a_mat.view(b, 2, hc, wc, -1)
+    for (dz, dy, dx), o in zip(taps, offs):
+        view[..., o:o + ci] = pad[:, dz:dz + 2, py + dy:py + dy + hc, px + dx:px + dx + wc]
+
+
+def _scatter_z4(d_a, layout, shape, taps, offs, ci, hc, wc):
+    if d_a.is_cuda:
+        from ..hipops import lattice_scatter
+        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), layout, row_z=2)
+    b = d_a.shape[0] // (2 * hc * wc)
+    py = max(abs(t[1]) for t in taps)
+    px = max(abs(t[2]) for t in taps)
+    pad = d_a.new_zeros(b, 4, hc + 2 * py, wc + 2 * px, ci)
+    view = d_a.view(b, 2, hc, wc, -1)
+    for (dz, dy, dx), o in zip(taps, offs):
+        pad[:, dz:dz + 2, py + dy:py + dy + hc, px + dx:px + dx + wc] += view[..., o:o + ci]
+    return _from_plain(pad[:, :, py:py + hc, px:px + wc], layout)
+
+
+_L0Z4 = {}
+
+
+def _layer0_z4_plan(ci, device):
+    """blocks (bb, cc, j) of the 5x5x2 neighbourhood; row indices into k.reshape(75*ci, co) of the taps
+    feeding the lower (a = 1 + j) and the upper (a = j) output half."""
+    key = (ci, str(device))
+    if key not in _L0Z4:
+        taps, lo, hi = [], [], []
+        for bb in range(5):
+            for cc in range(5):
+                for j in range(2):
+                    taps.append((2 * j, bb - 2, cc - 2))
+                    lo.append(np.arange(ci) + (((1 + j) * 5 + bb) * 5 + cc) * ci)
+                    hi.append(np.arange(ci) + ((j * 5 + bb) * 5 + cc) * ci)
+        t = lambda a: torch.from_numpy(np.concatenate(a).astype(np.int64)).to(device)
+        _L0Z4[key] = (taps, [i * ci for i in range(50)], t(lo), t(hi))
+    return _L0Z4[key]
+
+
+class _Layer0Z4(torch.autograd.Function):
+    """First layer for Z = 4: every tap hits data.  x plain [B,4,H,W,Ci] -> z-split [B,2,H,W,2,Co]."""
+
+    @staticmethod
+    def forward(ctx, x, k, bias):
+        b, z, h, w, ci = x.shape
+        co = k.shape[-1]
+        taps, offs, lo, hi = _layer0_z4_plan(ci, x.device)
+        a_mat = x.new_empty(b * 2 * h * w, 50 * ci)
+        _gather_z4(x, ZS_PLAIN, a_mat, taps, offs, ci, h, w)
+        rows = k.reshape(75 * ci, co)
+        wmat = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)        # [50 ci, 2 co]
+        out = torch.addmm(torch.cat([bias, bias]).to(x.dtype), a_mat, wmat)
+        ctx.save_for_backward(a_mat, wmat)
+        ctx.geom = (tuple(x.shape), ci, co, h, w)
+        return out.view(b, 2, h, w, 2, co)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a_mat, wmat = ctx.saved_tensors
+        shape, ci, co, h, w = ctx.geom
+        taps, offs, lo, hi = _layer0_z4_plan(ci, a_mat.device)
+        g = grad_out.contiguous().view(-1, 2 * co)
+        d_x = _scatter_z4(torch.mm(g, wmat.t()), ZS_PLAIN, shape, taps, offs, ci, h, w)
+        d_w = torch.mm(a_mat.t(), g)                                                       # [50 ci, 2 co]
+        d_lo = d_w.new_zeros(75 * ci, co)
+        d_hi = d_w.new_zeros(75 * ci, co)
+        d_lo.index_copy_(0, lo, d_w[:, :co])
+        d_hi.index_copy_(0, hi, d_w[:, co:])
+        acc = torch.float64 if g.dtype == torch.float64 else torch.float32
+        d_b = g.sum(0, dtype=acc)
+        return d_x, (d_lo + d_hi).view(75, ci, co), (d_b[:co] + d_b[co:]).to(g.dtype)
+
+
+def _block_order_z4():
+    """18 blocks (dxi, dyi, j) in column order: groups G1..G4 over (dy, dx), then (dx, dy, j)."""
+    blocks = [(dxi, dyi, j) for dxi in range(3) for dyi in range(3) for j in range(2)]
+    return sorted(blocks, key=lambda b: (_group_of(b[1], b[0]), b))
+
+
+_ORDER4 = _block_order_z4()
+_GROUP_START4 = [next(i for i, b in enumerate(_ORDER4) if _group_of(b[1], b[0]) == g) for g in range(4)] + [18]
+_CONST_BEFORE4 = [1 + (i >= _GROUP_START4[1]) + (i >= _GROUP_START4[2]) for i in range(18)]
+
+
+def _block_offset4(t, c):
+    return _PW2 * _CONST_BEFORE4[t] + t * c
+
+
+def _const_offset4(pm, pn, c):
+    g = _GROUP_START4
+    return {(0, 0): 0, (1, 0): _PW2 + g[1] * c, (1, 1): 2 * _PW2 + g[2] * c, (0, 1): 3 * _PW2 + 18 * c}[(pm, pn)]
+
+
+_LAYER_PLAN4 = {}
+
+
+def _layer_plan_z4(ci, device):
+    """Per class (c0, c1, lo, hi): one column range and the rows of the stacked weight matrix
+    [75*ci taps | 4 x 80 (K^T b_prev | bias | 0) | zero rows] feeding the lower / upper output half."""
+    key = (ci, str(device))
+    if key in _LAYER_PLAN4:
+        return _LAYER_PLAN4[key]
+    kt = 18 * ci + 4 * _PW2
+    n_data = 75 * ci
+    zero_base = n_data + 4 * _PW
+    dummy = {'lo': zero_base, 'hi': zero_base}
+
+    def zeros(which, n):
+        r = np.arange(dummy[which], dummy[which] + n)
+        dummy[which] += n
+        return r
+
+    def seg(pm, pn, sg):
+        kind, val = sg
+        if kind == 'b':
+            dxi, dyi, j = _ORDER4[val]
+            bb, cc = 2 * dyi - pm, 2 * dxi - pn
+            assert 0 <= bb < 5 and 0 <= cc < 5
+            lo = np.arange(ci) + (((1 + j) * 5 + bb) * 5 + cc) * ci
+            hi = np.arange(ci) + ((j * 5 + bb) * 5 + cc) * ci
+            return lo, hi
+        if val == (pm, pn):                          # own constant block: [P_lo | P_hi]
+            p = _CLASSES.index(val)
+            own = np.arange(n_data + p * _PW, n_data + (p + 1) * _PW)
+            return (np.concatenate([own, zeros('lo', _PW)]), np.concatenate([zeros('hi', _PW), own]))
+        return zeros('lo', _PW2), zeros('hi', _PW2)    # foreign constant block
+    b = lambda lo, hi: [('b', t) for t in range(lo, hi)]
+    g = _GROUP_START4
+    layout = {
+        (0, 0): [('c', (0, 0))] + b(g[0], g[1]) + [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[4]),
+        (1, 0): [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[3]),
+        (1, 1): [('c', (1, 1))] + b(g[2], g[3]),
+        (0, 1): b(g[2], g[4]) + [('c', (0, 1))],
+    }
+    plan = {}
+    for (pm, pn), segs in layout.items():
+        first = segs[0]
+        c0 = _block_offset4(first[1], ci) if first[0] == 'b' else _const_offset4(*first[1], ci)
+        parts = [seg(pm, pn, sg) for sg in segs]
+        lo = np.concatenate([p_[0] for p_ in parts])
+        hi = np.concatenate([p_[1] for p_ in parts])
+        t = lambda a: torch.from_numpy(a.astype(np.int64)).to(device)
+        plan[(pm, pn)] = (c0, c0 + len(lo), t(lo), t(hi))
+    total_rows = max(dummy.values())
+    taps = [(2 * j, dyi - 1, dxi - 1) for dxi, dyi, j in _ORDER4]
+    offs = [_block_offset4(t, ci) for t in range(18)]
+    _LAYER_PLAN4[key] = (plan, kt, total_rows, taps, offs)
+    return _LAYER_PLAN4[key]
+
+
+class _LatticeLayerZ4(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, e, k, bias, prev_bias, planar):
+        """e: z-split [B,2,H,W,2,C] or planar z-split [4,B,2,H/2,W/2,2,C]; k [75,Ci,Co]
+        -> planar z-split output [4,B,2,H,W,2,Co] (H, W = combined size of the input)."""
+        if planar:
+            _, b, _, hh, wh, _, ci = e.shape
+            hc, wc = 2 * hh, 2 * wh
+        else:
+            b, _, hc, wc, _, ci = e.shape
+        layout = ZS_PLANAR_SPLIT if planar else ZS_SPLIT
+        co = k.shape[-1]
+        dt = e.dtype
+        plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, e.device)
+        m = b * 2 * hc * wc
+        a_mat = e.new_empty(m, kt)
+        _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc)
+        pats = _class_patterns(4, hc, wc, e.device, dt)
+        a3 = a_mat.view(b, 2 * hc * wc, kt)
+        for (pm, pn), pat in zip(_CLASSES, pats):
+            o = _const_offset4(pm, pn, ci)
+            halves = pat.view(2, 2 * hc * wc, _PW)                  # output z = zl (lower), zl + 2 (upper)
+            a3[:, :, o:o + _PW] = halves[0]
+            a3[:, :, o + _PW:o + _PW2] = halves[1]
+        v = torch.matmul(prev_bias.to(dt), k)                                     # [75, Co]
+        vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
+        rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug,
+                          v.new_zeros(total_rows - 75 * ci - 4 * _PW, co)])
+        out = e.new_empty(4, m, 2 * co)
+        for p, cls in enumerate(_CLASSES):
+            c0, c1, lo, hi = plan[cls]
+            w = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)
+            torch.mm(a_mat[:, c0:c1], w, out=out[p])
+        ctx.save_for_backward(a_mat, rows, k, prev_bias)
+        ctx.geom = (layout, tuple(e.shape), b, hc, wc, ci, co)
+        return out.view(4, b, 2, hc, wc, 2, co)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a_mat, rows, k, prev_bias = ctx.saved_tensors
+        layout, e_shape, b, hc, wc, ci, co = ctx.geom
+        plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, a_mat.device)
+        dt = a_mat.dtype
+        m = a_mat.shape[0]
+        g = grad_out.contiguous().view(4, m, 2 * co)
+        d_a = a_mat.new_empty(m, kt)
+        d_a[:, kt - _PW2:] = 0                                  # P01 is outside class (0,0)'s range
+        d_lo = rows.new_zeros(total_rows, co)
+        d_hi = rows.new_zeros(total_rows, co)
+        for p, cls in enumerate(_CLASSES):
+            c0, c1, lo, hi = plan[cls]
+            w = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)
+            if p == 0:                                          # class (0,0): initialises every tap block
+                torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
+            else:
+                torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
+            d_w = torch.mm(a_mat[:, c0:c1].t(), g[p])
+            d_lo.index_copy_(0, lo, d_w[:, :co])
+            d_hi.index_copy_(0, hi, d_w[:, co:])
+        d_e = _scatter_z4(d_a, layout, e_shape, taps, offs, ci, hc, wc)
+        d_rows = d_lo + d_hi
+        n_data = 75 * ci
+        acc = torch.float64 if dt == torch.float64 else torch.float32
+        d_k = d_rows[:n_data].view(75, ci, co)
+        d_vaug = d_rows[n_data:n_data + 4 * _PW].view(4, _PW, co).sum(0, dtype=acc)
+        d_v = d_vaug[:75].to(dt)
+        d_bias = d_vaug[75]
+        pb = prev_bias.to(dt)
+        d_k = torch.addcmul(d_k, pb[None, :, None], d_v[:, None, :])
+        d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
+        return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None
+
+
 def _compute_dtype(x):
     """bf16 under ``torch.autocast`` (im2col, GEMM operands and lattices all in bf16, fp32
     accumulation inside the GEMM), else the input's dtype."""
@@ -369,13 +663,18 @@ def _compute_dtype(x):
 
 
 def upsample_lattice(x0, weights, biases):
-    """x0 [B,C,Z,H,W] -> (E_3 PLANAR [4,B,Z,2H,2W,C], last bias).  E_3 holds the even positions of
-    the reference's dense output ``up_sample(x0)`` [B,C,Z,8H,8W] (``planar_to_plain`` gives the
-    channels-last [B,Z,4H,4W,C] lattice)."""
+    """x0 [B,C,Z,H,W] -> (E_3, last bias).  E_3 holds the even positions of the reference's dense
+    output ``up_sample(x0)`` [B,C,Z,8H,8W], as a PLANAR lattice [4,B,Z,2H,2W,C] or, for Z = 4, planar
+    z-split [4,B,2,2H,2W,2,C] (``lattice_to_plain`` gives the channels-last [B,Z,4H,4W,C] lattice)."""
     dt = _compute_dtype(x0)
     e = x0.permute(0, 2, 3, 4, 1).to(dt)
     ks = [_corr_weight(w, dt) for w in weights]
     bs = [b.to(dt) for b in biases]
+    if e.shape[1] == 4:                                   # bev_z = 4: z-split path (a third fewer FLOPs)
+        e = _Layer0Z4.apply(e.contiguous(), ks[0], bs[0])
+        e = _LatticeLayerZ4.apply(e, ks[1], bs[1], bs[0], False)
+        e = _LatticeLayerZ4.apply(e, ks[2], bs[2], bs[1], True)
+        return e, bs[2]
     e = _layer0(e, ks[0], bs[0])
     e = _layer_lattice(e, ks[1], bs[1], bs[0], planar=False)
     e = _layer_lattice(e, ks[2], bs[2], bs[1], planar=True)
@@ -383,9 +682,11 @@ def upsample_lattice(x0, weights, biases):
 
 
 def full_volume(e, bias):
-    """Even lattice (plain [B,Z,H,W,C] or planar [4,B,Z,H/2,W/2,C]) + bias -> dense [B,C,Z,2H,2W]
-    (odd rows/cols = bias)."""
-    if e.dim() == 6:
+    """Even lattice (plain [B,Z,H,W,C], planar [4,B,Z,H/2,W/2,C] or planar z-split
+    [4,B,2,H/2,W/2,2,C]) + bias -> dense [B,C,Z,2H,2W] (odd rows/cols = bias)."""
+    if e.dim() == 7:
+        e = planar_zs_to_plain(e)
+    elif e.dim() == 6:
         e = planar_to_plain(e)
     b, z, h, w, c = e.shape
     y = bias.view(1, c, 1, 1, 1).expand(b, c, z, 2 * h, 2 * w).contiguous()

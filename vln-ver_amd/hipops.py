@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -325,8 +325,23 @@ def convt_weight_taps(weight, dtype):
     return ConvTWeightFunction.apply(weight, dtype)
 
 
-def lattice_transpose(channels_last, channel_first, combined_hw, planar, to_channel_first):
-    """ver_lattice_transpose (no autograd): channels_last plain [B,Z,H,W,C] / planar [4,B,Z,H/2,W/2,C]
+PLAIN, PLANAR, ZSPLIT, PLANAR_ZSPLIT = 0, 1, 2, 3      # lattice layouts of ver_lattice_gather / _transpose
+
+
+def _lattice_dims(t, layout):
+    """(B, Zs, C) of a lattice tensor in the given layout."""
+    s = t.shape
+    if layout == PLAIN:          # [B,Z,H,W,C]
+        return s[0], s[1], s[4]
+    if layout == PLANAR:         # [4,B,Z,H/2,W/2,C]
+        return s[1], s[2], s[5]
+    if layout == ZSPLIT:         # [B,2,H,W,2,C]
+        return s[0], 4, s[5]
+    return s[1], 4, s[6]         # [4,B,2,H/2,W/2,2,C]
+
+
+def lattice_transpose(channels_last, channel_first, combined_hw, layout, to_channel_first):
+    """ver_lattice_transpose (no autograd): channels_last lattice in one of the four layouts
     <-> channel_first [B, stride] rows holding [C,Z,H,W] at their start."""
     cl, cf = _gpu(channels_last, 'channels_last'), _gpu(channel_first, 'channel_first')
     if not (cl.is_contiguous() and cf.is_contiguous() and cl.dtype == cf.dtype):
@@ -334,11 +349,10 @@ def lattice_transpose(channels_last, channel_first, combined_hw, planar, to_chan
     if cl.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError('lattice_transpose: fp32 or bf16')
     H, W = combined_hw
-    s = cl.shape
-    B, Z, C = (s[1], s[2], s[5]) if planar else (s[0], s[1], s[4])
+    B, Z, C = _lattice_dims(cl, int(layout))
     dt = 1 if cl.dtype == torch.bfloat16 else 0
     _launch('ver_lattice_transpose', lambda: lib().ver_lattice_transpose(
-        _p(cl), _p(cf), ctypes.c_long(cf.shape[1]), B, Z, H, W, C, int(planar), int(to_channel_first), dt,
+        _p(cl), _p(cf), ctypes.c_long(cf.shape[1]), B, Z, H, W, C, int(layout), int(to_channel_first), dt,
         _stream()))
 
 
@@ -347,35 +361,36 @@ def _tap_args(taps, col_offset):
     return (ctypes.c_int * len(flat))(*flat), (ctypes.c_long * len(col_offset))(*[int(o) for o in col_offset])
 
 
-def lattice_gather(src, col, taps, col_offset, combined_hw, planar):
-    """ver_lattice_gather (no autograd): src plain [B,Z,H,W,C] or planar [4,B,Z,H/2,W/2,C] ->
-    tap blocks of col [B*Z*H*W, stride] at the given column offsets."""
+def lattice_gather(src, col, taps, col_offset, combined_hw, layout, row_z=None):
+    """ver_lattice_gather (no autograd): src lattice in `layout` -> tap blocks of
+    col [B*row_z*H*W, stride] at the given column offsets (row_z defaults to the source's z count)."""
     src, col = _gpu(src, 'src'), _gpu(col, 'col')
     if not (src.is_contiguous() and col.is_contiguous() and src.dtype == col.dtype):
         raise ValueError('lattice_gather: contiguous src / col of one dtype required')
     H, W = combined_hw
-    B, Z, C = (src.shape[1], src.shape[2], src.shape[5]) if planar else (src.shape[0], src.shape[1], src.shape[4])
+    B, Zs, C = _lattice_dims(src, int(layout))
+    Zr = Zs if row_z is None else int(row_z)
     arr, offs = _tap_args(taps, col_offset)
     dt = 1 if src.dtype == torch.bfloat16 else 0
     _launch('ver_lattice_gather', lambda: lib().ver_lattice_gather(
-        _p(src), _p(col), arr, offs, ctypes.c_long(col.shape[1]), len(taps), B, Z, H, W, C, int(planar), dt,
+        _p(src), _p(col), arr, offs, ctypes.c_long(col.shape[1]), len(taps), B, Zr, Zs, H, W, C, int(layout), dt,
         _stream()))
     return col
 
 
-def lattice_scatter(grad_col, grad_src, taps, col_offset, combined_hw, planar):
+def lattice_scatter(grad_col, grad_src, taps, col_offset, combined_hw, layout, row_z=None):
     """ver_lattice_scatter (no autograd): the adjoint of ``lattice_gather`` into grad_src (overwritten)."""
     grad_col, grad_src = _gpu(grad_col, 'grad_col'), _gpu(grad_src, 'grad_src')
     if not (grad_src.is_contiguous() and grad_col.is_contiguous() and grad_src.dtype == grad_col.dtype):
         raise ValueError('lattice_scatter: contiguous buffers of one dtype required')
     H, W = combined_hw
-    s = grad_src.shape
-    B, Z, C = (s[1], s[2], s[5]) if planar else (s[0], s[1], s[4])
+    B, Zs, C = _lattice_dims(grad_src, int(layout))
+    Zr = Zs if row_z is None else int(row_z)
     arr, offs = _tap_args(taps, col_offset)
     dt = 1 if grad_src.dtype == torch.bfloat16 else 0
     _launch('ver_lattice_scatter', lambda: lib().ver_lattice_scatter(
-        _p(grad_col), _p(grad_src), arr, offs, ctypes.c_long(grad_col.shape[1]), len(taps), B, Z, H, W, C,
-        int(planar), dt, _stream()))
+        _p(grad_col), _p(grad_src), arr, offs, ctypes.c_long(grad_col.shape[1]), len(taps), B, Zr, Zs, H, W, C,
+        int(layout), dt, _stream()))
     return grad_src
 
 

@@ -28,6 +28,8 @@ geometry by brute force from the definition of the two raw views, so they hold f
 import numpy as np
 import torch
 
+from .upsample import rows_tn
+
 _PLAN_CACHE = {}
 
 
@@ -207,7 +209,7 @@ class _OccProjLattice(torch.autograd.Function):
             d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())         # [bs*n_rows, Z]
             d_up.index_add_(0, g.chan, d_const.view(bs, -1).sum(0, dtype=acc))
             # d(W_aug^T) = go^T a
-            d_wa = torch.mm(go.t(), a).to(acc)                                       # [out, k_aug]
+            d_wa = rows_tn(a, go).t().to(acc)                                        # [out, k_aug]
             d_weight.index_add_(1, g.cols, d_wa[:, :g.n_cols])
             for k, n in enumerate(g.ncols_by_token):
                 d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]

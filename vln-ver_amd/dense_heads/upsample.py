@@ -339,7 +339,7 @@ class _LatticeLayer(torch.autograd.Function):
                     first = False
                 else:
                     torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
-                d_rows.index_copy_(0, ridx, torch.mm(a_mat[:, c0:c1].t(), g[p]))
+                d_rows.index_copy_(0, ridx, rows_tn(a_mat[:, c0:c1], g[p]))
         d_e = _scatter27(d_a, planar, e_shape, ci, hc, wc)
         n_data = 75 * ci
         d_k = d_rows[:n_data].view(75, ci, co)
@@ -493,7 +493,7 @@ class _Layer0Z4(torch.autograd.Function):
         taps, offs, lo, hi = _layer0_z4_plan(ci, a_mat.device)
         g = grad_out.contiguous().view(-1, 2 * co)
         d_x = _scatter_z4(torch.mm(g, wmat.t()), ZS_PLAIN, shape, taps, offs, ci, h, w)
-        d_w = torch.mm(a_mat.t(), g)                                                       # [50 ci, 2 co]
+        d_w = rows_tn(a_mat, g)                                                            # [50 ci, 2 co]
         d_lo = d_w.new_zeros(75 * ci, co)
         d_hi = d_w.new_zeros(75 * ci, co)
         d_lo.index_copy_(0, lo, d_w[:, :co])
@@ -637,7 +637,7 @@ class _LatticeLayerZ4(torch.autograd.Function):
                 torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
             else:
                 torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
-            d_w = torch.mm(a_mat[:, c0:c1].t(), g[p])
+            d_w = rows_tn(a_mat[:, c0:c1], g[p])
             d_lo.index_copy_(0, lo, d_w[:, :co])
             d_hi.index_copy_(0, hi, d_w[:, co:])
         d_e = _scatter_z4(d_a, layout, e_shape, taps, offs, ci, hc, wc)
@@ -652,6 +652,20 @@ class _LatticeLayerZ4(torch.autograd.Function):
         d_k = torch.addcmul(d_k, pb[None, :, None], d_v[:, None, :])
         d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
         return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None
+
+
+def rows_tn(a, g):
+    """a^T g for tall operands (a [M,K] may be a column range of a wider matrix, g [M,N] contiguous).
+    The library runs this K x N output with M = 1e5..2e5 as a stream-K GEMM at ~0.75 PFLOP/s; split
+    into 8 row chunks as ONE batched GEMM (strided views, no copies) and summed in fp32 it reaches
+    ~1.05 PFLOP/s (scratch/exp_wgrad.py)."""
+    m = a.shape[0]
+    if not a.is_cuda or a.dtype == torch.float64 or m % 8 or m < 8 * 2048:
+        return torch.mm(a.t(), g)
+    s = 8
+    a3 = a.unflatten(0, (s, m // s))
+    g3 = g.unflatten(0, (s, m // s))
+    return torch.bmm(a3.transpose(1, 2), g3).sum(0, dtype=torch.float32).to(a.dtype)
 
 
 def _compute_dtype(x):

@@ -9,7 +9,7 @@ def kernel_stats(path, out):
         f.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
         for r in rows:
             f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (r[0].replace('"', "'")[:160], r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
-def pmc_stats(path, out, like=('k_sca', 'k_project', 'k_build', 'k_zero', 'k_msda', 'k_lattice')):
+def pmc_stats(path, out, like=('k_sca', 'k_project', 'k_build', 'k_zero', 'k_msda', 'k_lattice', 'k_occ_mlp', 'k_focal')):
     db = sqlite3.connect(path); cur = db.cursor()
     rows = cur.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name").fetchall()
     with open(out, 'a') as f:

@@ -25,40 +25,33 @@ struct Bilinear {
     bool any;
 };
 
+// Branch-free on purpose: with an early return for samples outside the map the struct's arrays were
+// kept in scratch memory by the compiler (k_sca_bwd_off ran 72 B of private segment per lane).
 template <bool GRAD>
 __device__ __forceinline__ void bilinear_setup(float loc_x, float loc_y, int H, int W, Bilinear& s) {
     const float x = loc_x * (float)W - 0.5f;
     const float y = loc_y * (float)H - 0.5f;
-    s.any = (y > -1.0f) && (x > -1.0f) && (y < (float)H) && (x < (float)W);
-    if (!s.any) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s.w[k] = 0.0f;
-            s.key[k] = 0;
-            if (GRAD) {
-                s.gx[k] = 0.0f;
-                s.gy[k] = 0.0f;
-            }
-        }
-        return;
-    }
+    const bool any = (y > -1.0f) && (x > -1.0f) && (y < (float)H) && (x < (float)W);
+    s.any = any;
     const float xf = floorf(x), yf = floorf(y);
-    const int x0 = (int)xf, y0 = (int)yf;
+    // clamp before the int conversion: far-away samples (|x| ~ 1e9) must not overflow it
+    const int x0 = (int)fminf(fmaxf(xf, -2.0f), (float)W), y0 = (int)fminf(fmaxf(yf, -2.0f), (float)H);
     const int x1 = x0 + 1, y1 = y0 + 1;
     const float lx = x - xf, ly = y - yf;
     const float hx = 1.0f - lx, hy = 1.0f - ly;
-    const bool vx0 = x0 >= 0, vx1 = x1 <= W - 1, vy0 = y0 >= 0, vy1 = y1 <= H - 1;
-    const int cx0 = vx0 ? x0 : 0, cx1 = vx1 ? x1 : W - 1;
-    const int cy0 = vy0 ? y0 : 0, cy1 = vy1 ? y1 : H - 1;
-    const bool v00 = vy0 && vx0, v01 = vy0 && vx1, v10 = vy1 && vx0, v11 = vy1 && vx1;
+    const bool vx0 = x0 >= 0 && x0 <= W - 1, vx1 = x1 >= 0 && x1 <= W - 1;
+    const bool vy0 = y0 >= 0 && y0 <= H - 1, vy1 = y1 >= 0 && y1 <= H - 1;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+    const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    const bool v00 = any && vy0 && vx0, v01 = any && vy0 && vx1, v10 = any && vy1 && vx0, v11 = any && vy1 && vx1;
     s.w[0] = v00 ? hy * hx : 0.0f;
     s.w[1] = v01 ? hy * lx : 0.0f;
     s.w[2] = v10 ? ly * hx : 0.0f;
     s.w[3] = v11 ? ly * lx : 0.0f;
-    s.key[0] = cy0 * W + cx0;
-    s.key[1] = cy0 * W + cx1;
-    s.key[2] = cy1 * W + cx0;
-    s.key[3] = cy1 * W + cx1;
+    s.key[0] = any ? cy0 * W + cx0 : 0;
+    s.key[1] = any ? cy0 * W + cx1 : 0;
+    s.key[2] = any ? cy1 * W + cx0 : 0;
+    s.key[3] = any ? cy1 * W + cx1 : 0;
     if (GRAD) {
         s.gx[0] = v00 ? -hy : 0.0f;
         s.gx[1] = v01 ? hy : 0.0f;

@@ -788,20 +788,48 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
         const unsigned char* tile0 = reinterpret_cast<const unsigned char*>(tile + M16::off0(lr));
         const unsigned char* tile1 = reinterpret_cast<const unsigned char*>(tile + M16::off1(lr));
 
-        for (int base = start + wave * 4; base < end; base += STEP) {
-            const int ia = base + row;
-            const bool alive = ia < end;
-            const int n = alive ? list[ia] : 0;
-            const unsigned m = alive ? (unsigned)vis[(size_t)b * Nq + n] : 0u;
-            const size_t qh = ((size_t)b * Nq + n) * heads + h;
-            const float lg = logits[qh * P + ap];
-            const float2 of = *reinterpret_cast<const float2*>(offs + (qh * P + ap) * 2);
-            const float2 u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + ad) * 2);
+        // operands are software pipelined like the forward kernel's: voxel ids two iterations ahead, the
+        // sample record (logit, offset, uv, grad row) one ahead -- otherwise every iteration starts with
+        // two dependent global-memory latencies (the kernel was bound by exactly that)
+        struct Sample {
+            unsigned m;
+            float lg;
+            float2 of, u;
             float g[CPL];
-            load_ch<HD, 16, float>(gslots + ((size_t)b * Nq + n) * heads * HD + (size_t)h * HD, lr, g);
+        };
+        auto load_id = [&](int base) -> int {
+            const int ia = base + row;
+            return ia < end ? list[ia] : -1;
+        };
+        auto load_sample = [&](int n) -> Sample {
+            Sample sm;
+            const int nn = n < 0 ? 0 : n;
+            const size_t qh = ((size_t)b * Nq + nn) * heads + h;
+            sm.m = n < 0 ? 0u : (unsigned)vis[(size_t)b * Nq + nn];
+            sm.lg = logits[qh * P + ap];
+            sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + ap) * 2);
+            sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
+            load_ch<HD, 16, float>(gslots + ((size_t)b * Nq + nn) * heads * HD + (size_t)h * HD, lr, sm.g);
+            return sm;
+        };
+        const int base0 = start + wave * 4;
+        int n_cur = load_id(base0);
+        int n_nxt = load_id(base0 + STEP);
+        Sample s_cur = load_sample(n_cur);
+        for (int base = base0; base < end; base += STEP) {
+            const Sample s_nxt = load_sample(n_nxt);
+            const int n_nxt2 = load_id(base + 2 * STEP);
+            const bool alive = n_cur >= 0;
+            const int n = alive ? n_cur : 0;
+            const unsigned m = s_cur.m;
+            const size_t qh = ((size_t)b * Nq + n) * heads + h;
+            const float lg = s_cur.lg;
+            const float2 of = s_cur.of;
+            const float2 u = s_cur.u;
+            float g[CPL];
             const float icnt = m ? 1.0f / (float)__popc(m) : 0.0f;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) g[j] *= icnt;
+            for (int j = 0; j < CPL; ++j) g[j] = s_cur.g[j] * icnt;
             // ---------------- phase A
             const float mx = group_max<16>(lg);
             const float e = __expf(lg - mx);
@@ -811,13 +839,15 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
             float wsel[2], gxs[2], gys[2];
             unsigned ksel[2];
             if constexpr (CPN == 2) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    wsel[r] = asub ? s.w[2 + r] : s.w[r];
-                    gxs[r] = asub ? s.gx[2 + r] : s.gx[r];
-                    gys[r] = asub ? s.gy[2 + r] : s.gy[r];
-                    ksel[r] = (unsigned)(asub ? s.key[2 + r] : s.key[r]) * kRowBytes;
-                }
+                // explicit selects: an index like s.w[2 * asub + r] sends the whole struct to scratch memory
+                wsel[0] = asub ? s.w[2] : s.w[0];
+                wsel[1] = asub ? s.w[3] : s.w[1];
+                gxs[0] = asub ? s.gx[2] : s.gx[0];
+                gxs[1] = asub ? s.gx[3] : s.gx[1];
+                gys[0] = asub ? s.gy[2] : s.gy[0];
+                gys[1] = asub ? s.gy[3] : s.gy[1];
+                ksel[0] = (unsigned)(asub ? s.key[2] : s.key[0]) * kRowBytes;
+                ksel[1] = (unsigned)(asub ? s.key[3] : s.key[1]) * kRowBytes;
             } else {
                 const int q = asub & 3;
                 wsel[0] = q == 0 ? s.w[0] : q == 1 ? s.w[1] : q == 2 ? s.w[2] : s.w[3];
@@ -880,6 +910,9 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_bwd_off(
                     atomicAdd(gw, gl);
                 }
             }
+            n_cur = n_nxt;
+            n_nxt = n_nxt2;
+            s_cur = s_nxt;
         }
     }
 }

@@ -1227,8 +1227,8 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                 const size_t tile_bytes = (size_t)map_h * map_w * head_dim * esz;
                 static const int off_threads = [] {
                     const char* ev = getenv("VER_SCA_BWD_THREADS");
-                    const int t = ev ? atoi(ev) : 1024;
-                    return (t == 512 || t == 1024) ? t : 1024;
+                    const int t = ev ? atoi(ev) : 512;
+                    return (t == 512 || t == 1024) ? t : 512;
                 }();
                 static const long off_min_wgs = [] {
                     const char* ev = getenv("VER_SCA_BWD_MIN_WGS");

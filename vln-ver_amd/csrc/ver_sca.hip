@@ -1163,7 +1163,15 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
         const int t = e ? atoi(e) : 512;               // measured: 512 beats 1024 by 5-15 % (B = 32..256)
         return (t == 512 || t == 1024) ? t : 512;
     }();
-    const int nbuf = (fwd_threads == kFwdThreads && 2 * tile_bytes <= kMaxLds) ? 2 : 1;
+    // double-buffer the tile inside the workgroup when the CU's LDS holds it for every resident
+    // workgroup (one of 16 waves, or two of 8 waves: bf16 tiles of 14x14x96 fit four times)
+    static const int force_nbuf = [] {
+        const char* e = getenv("VER_SCA_FWD_NBUF");
+        return e ? atoi(e) : 0;
+    }();
+    const size_t wgs_per_cu = fwd_threads == kFwdThreads ? 1 : 2;
+    int nbuf = 2 * wgs_per_cu * tile_bytes <= kMaxLds ? 2 : 1;
+    if (force_nbuf == 1 || (force_nbuf == 2 && 2 * tile_bytes <= kMaxLds)) nbuf = force_nbuf;
     const size_t lds = tile_bytes * nbuf;
     const int nchunks = (Nq + kFwdChunk - 1) / kFwdChunk;
     // heads are walked inside a workgroup (the tile stream is double buffered); split them over

@@ -306,7 +306,10 @@ __device__ __forceinline__ void stage_wait() {
 // LDS.  Rows of voxels seen by exactly one camera are plain stores; rows seen by several cameras
 // were zeroed by k_zero_rows and are accumulated with fp32 atomics (2 addends commute exactly, so
 // results stay bitwise reproducible as long as no voxel is seen by more than two cameras).
-constexpr int kFwdLoaders = 0;   // 0: every wave issues its share of the next tile's LDS-DMA
+#ifndef VER_FWD_LOADERS
+#define VER_FWD_LOADERS 0
+#endif
+constexpr int kFwdLoaders = VER_FWD_LOADERS;   // 0: every wave issues its share of the next tile's LDS-DMA
 
 #ifdef VER_DEBUG_TIMING
 __device__ long long g_dbg[256];

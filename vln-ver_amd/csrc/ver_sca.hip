@@ -159,7 +159,14 @@ struct ChMap {
     static constexpr int W0 = CPL >= 4 ? 4 : 2;
     static constexpr int W1 = CPL - W0;
     static_assert(CPL == 2 || CPL == 4 || CPL == 6 || CPL == 8, "unsupported channels per lane");
-    __device__ __forceinline__ static int off0(int gl) { return gl * W0; }
+    // G = 16, 16-byte segment-0 reads: a ds_read_b128 is served in lane groups {0-3,12-15,20-27}, ... that mix
+    // two voxels' lanes; with rows of HD*4 B = 32 banks (mod 64) apart the plain map collides 2-way whenever
+    // the two tile rows differ in parity.  Swapping the lane quads 8-11 <-> 12-15 makes every group's two
+    // bank sets complementary AND invariant under the 32-bank shift: conflict-free for any row pair.
+    __device__ __forceinline__ static int off0(int gl) {
+        if (G == 16 && W0 == 4) gl = (gl & 8) ? (gl ^ 4) : gl;
+        return gl * W0;
+    }
     __device__ __forceinline__ static int off1(int gl) { return G * W0 + gl * W1; }
 };
 

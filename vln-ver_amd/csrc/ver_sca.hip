@@ -1171,7 +1171,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     static const int fwd_threads = [] {
         const char* e = getenv("VER_SCA_FWD_THREADS");
         const int t = e ? atoi(e) : 512;               // measured: 512 beats 1024 by 5-15 % (B = 32..256)
-        return (t == 512 || t == 1024) ? t : 512;
+        return (t == 256 || t == 512 || t == 1024) ? t : 512;
     }();
     // double-buffer the tile inside the workgroup when the CU's LDS holds it for every resident
     // workgroup (one of 16 waves, or two of 8 waves: bf16 tiles of 14x14x96 fit four times)
@@ -1179,7 +1179,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
         const char* e = getenv("VER_SCA_FWD_NBUF");
         return e ? atoi(e) : 0;
     }();
-    const size_t wgs_per_cu = fwd_threads == kFwdThreads ? 1 : 2;
+    const size_t wgs_per_cu = kFwdThreads / fwd_threads;
     int nbuf = 2 * wgs_per_cu * tile_bytes <= kMaxLds ? 2 : 1;
     if (force_nbuf == 1 || (force_nbuf == 2 && 2 * tile_bytes <= kMaxLds)) nbuf = force_nbuf;
     const size_t lds = tile_bytes * nbuf;
@@ -1188,7 +1188,8 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     // several workgroups only while the grid would not yet fill the 256 CUs a few times over
     static const long min_wgs = [] {
         const char* e = getenv("VER_SCA_FWD_MIN_WGS");
-        return e ? atol(e) : 1536L;                    // >= 3 workgroups per residency slot (2 per CU)
+        return e ? atol(e) : 6144L;                    // heads split until >= 12 workgroups per residency slot
+                                                       // (2 per CU): 2-5 % over 1536 at B = 64..256
     }();
     int hsplit = 1;
     while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < min_wgs) hsplit *= 2;

@@ -129,7 +129,7 @@ def gather_algorithmic_bytes(hit_counts, B, ncam=6, nk=196, c=768, heads=8, poin
     return fwd, bwd
 
 
-def measured_traffic_per_viewpoint(kernel):
+def measured_traffic_per_viewpoint(kernel, dtype='fp32'):
     """HBM bytes per viewpoint and launch from the committed rocprofv3 PMC passes
     (profiles/*_gather_microbench_pmc_fetch_write.csv: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
     separate runs of scratch/bench_gather.py at 64 viewpoints per launch).  Units are KiB;
@@ -137,7 +137,11 @@ def measured_traffic_per_viewpoint(kernel):
     section HBM), so this is an upper bound on the read side."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_pmc_fetch_write.csv')))
+    files = []
+    if dtype == 'bf16':                     # bf16 value tiles run another forward kernel (k_sca_fwd8)
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_bf16_pmc_fetch_write.csv')))
+    if not files:
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_pmc_fetch_write.csv')))
     if not files:
         return None, None
     vals = {}
@@ -271,7 +275,7 @@ def main():
             if name in kt and kt[name]['count']:
                 avg_ms = kt[name]['ms'] / kt[name]['count']
                 ach = byts / (avg_ms * 1e-3) / 1e9
-                tpv, src = measured_traffic_per_viewpoint('k_sca_fwd' if name == 'ver_sca_forward' else 'k_sca_bwd')
+                tpv, src = measured_traffic_per_viewpoint('k_sca_fwd' if name == 'ver_sca_forward' else 'k_sca_bwd', args.dtype)
                 obj = dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=int(tpv * B) if tpv else None,
                            traffic_source=src, avg_launch_us=round(avg_ms * 1e3, 2),

@@ -224,7 +224,8 @@ def test_sca_gather_forward_backward_vs_oracle(heads, hd, P, grid, mhw):
     assert torch.equal(again, slots.detach())
 
 
-@pytest.mark.parametrize('heads,hd,P,grid', [(8, 96, 8, (4, 15, 15)), (2, 32, 4, (2, 6, 5)), (4, 8, 8, (2, 6, 5))])
+@pytest.mark.parametrize('heads,hd,P,grid', [(8, 96, 8, (4, 15, 15)), (2, 32, 4, (2, 6, 5)), (4, 8, 8, (2, 6, 5)),
+                                             (4, 64, 8, (2, 6, 5)), (2, 32, 8, (3, 7, 6))])
 def test_sca_gather_bf16_value(heads, hd, P, grid):
     """value stored as bf16 (what value_proj emits under bf16 autocast): the kernel reads bf16 and
     computes in fp32, so against the oracle evaluated on the SAME bf16-rounded values the fp32

@@ -596,6 +596,183 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
+// Forward, 8 lanes per voxel (P = 8 sampling points, HD % 32 == 0).  k_sca_fwd is bound by VALU issue
+// (47.5 M wave-instructions per 64-viewpoint launch = 77 us of the 1024 SIMDs): its 16 lanes per voxel
+// compute every sample's bilinear setup twice and spend 2 DPP broadcasts + 2 address adds on 3
+// v_pk_fma per corner.  Here a lane is ONE sampling point in phase A (setup once per sample) and
+// HD/8 channels in phase B; a wave carries 8 voxels.  The per-point records are broadcast inside the
+// 8-lane groups by ds_swizzle (bit-mask mode, and 0x18 | or N) -- on the LDS pipe, which has spare
+// issue slots, instead of the VALU -- and all channel vectors of a corner row share one address
+// (16-byte vectors at lane*16 + i*128).  VALU per voxel-head: ~57 instead of ~113.
+#ifndef VER_FWD8_MINW
+#define VER_FWD8_MINW 2
+#endif
+template <int N>
+__device__ __forceinline__ float swz8_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (N << 5) | 0x18));
+}
+template <int N>
+__device__ __forceinline__ unsigned swz8_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (N << 5) | 0x18);
+}
+
+// A lane carries CH/8 channels of its voxel as NV4 vectors of 4 channels (at l8*4 + i*32).
+template <int CH, typename VT>
+struct Map8 {
+    static constexpr int CPL = CH / 8;
+    static constexpr int NV4 = CPL / 4;
+    static_assert(CH % 32 == 0, "8 lanes x vectors of 4 channels");
+    static constexpr unsigned VB4 = 4 * sizeof(VT);
+};
+
+template <int CH, typename VT, int PT>
+struct PointLoop8 {
+    __device__ __forceinline__ static void run(unsigned base4, const float (&w)[4], const unsigned (&k)[4],
+                                               float (&acc)[CH / 8]) {
+        using M = Map8<CH, VT>;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float wb = swz8_f<PT>(w[t]);
+            const unsigned ko = swz8_u<PT>(k[t]);
+            const unsigned addr = base4 + ko;
+#pragma unroll
+            for (int i = 0; i < M::NV4; ++i) {
+                float v[4];
+                load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
+            }
+        }
+        PointLoop8<CH, VT, PT + 1>::run(base4, w, k, acc);
+    }
+};
+template <int CH, typename VT>
+struct PointLoop8<CH, VT, 8> {
+    __device__ __forceinline__ static void run(unsigned, const float (&)[4], const unsigned (&)[4],
+                                               float (&)[CH / 8]) {}
+};
+
+template <int HD, typename VT>
+__global__ __launch_bounds__(256, 2) void k_sca_fwd8(
+    const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
+    const int* __restrict__ vis_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
+    int nchunks, int chunk, int hsplit, int nbuf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = 8, CH = HD;
+    using M = Map8<CH, VT>;
+    constexpr int CPL = M::CPL;
+    constexpr unsigned kRowBytes = CH * sizeof(VT);
+    const int nwaves = (int)(blockDim.x >> 6);
+    const int Nk = mh * mw;
+    const size_t tile_elems = (size_t)Nk * CH;
+    VT* tiles = reinterpret_cast<VT*>(smem);
+    int bid = blockIdx.x;
+    const int ck = bid % nchunks;
+    bid /= nchunks;
+    const int hs = bid % hsplit;
+    bid /= hsplit;
+    const int c = bid % Ncam;
+    const int b = bid / Ncam;
+    const int cnt = vis_cnt[b * Ncam + c];
+    const int start = ck * chunk;
+    if (start >= cnt) return;
+    const int end = min(cnt, start + chunk);
+    const int heads_per = heads / hsplit, h0 = hs * heads_per;
+    const size_t rstride = (size_t)heads * HD;
+    const VT* vown = value + ((size_t)b * Ncam + c) * Nk * rstride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = lane >> 3, l8 = lane & 7;             // voxel slot of the wave, point / channel lane
+    const int ad = (D == 1) ? 0 : (l8 % D);
+    const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+    const int STEP = nwaves * 8;
+
+    if (nbuf == 2) stage_tile<CH, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave, nwaves);
+    for (int hh = 0; hh < heads_per; ++hh) {
+        const int h = h0 + hh;
+        const int cur = nbuf == 2 ? (hh & 1) : 0;
+        VT* tile = tiles + cur * tile_elems;
+        if (nbuf == 1) {
+            __syncthreads();
+            stage_tile<CH, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave, nwaves);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (nbuf == 2 && hh + 1 < heads_per)
+            stage_tile<CH, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, wave, nwaves);
+
+        struct Sample {
+            unsigned m;
+            float lg;
+            float2 of, u;
+        };
+        auto load_id = [&](int base) -> int {
+            const int ia = base + slot;
+            return ia < end ? list[ia] : -1;
+        };
+        auto load_sample = [&](int n) -> Sample {
+            Sample sm;
+            const int nn = n < 0 ? 0 : n;
+            const size_t qh = ((size_t)b * Nq + nn) * heads + h;
+            sm.m = n < 0 ? 0u : (unsigned)vis[(size_t)b * Nq + nn];
+            sm.lg = logits[qh * P + l8];
+            sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + l8) * 2);
+            sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
+            return sm;
+        };
+        const unsigned tile_lds = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(tile);
+        const unsigned base4 = tile_lds + (unsigned)l8 * M::VB4;
+        const int base0 = start + wave * 8;
+        int n_cur = load_id(base0);
+        int n_nxt = load_id(base0 + STEP);
+        Sample s_cur = load_sample(n_cur);
+        for (int base = base0; base < end; base += STEP) {
+            const Sample s_nxt = load_sample(n_nxt);
+            const int n_nxt2 = load_id(base + 2 * STEP);
+            // ---------------- phase A: lane = sampling point
+            const unsigned m = s_cur.m;
+            float w[4];
+            unsigned k[4];
+            {
+                const float mx = group_max<8>(s_cur.lg);
+                const float e = __expf(s_cur.lg - mx);
+                const float ssum = group_sum<8>(e);
+                const float a = m ? e * __builtin_amdgcn_rcpf(ssum * (float)__popc(m)) : 0.0f;
+                Bilinear s;
+                bilinear_setup<false>(s_cur.u.x + s_cur.of.x * inv_w, s_cur.u.y + s_cur.of.y * inv_h, mh, mw, s);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    w[t] = a * s.w[t];
+                    k[t] = (unsigned)s.key[t] * kRowBytes;
+                }
+            }
+            // ---------------- phase B: lane = CH/8 channels
+            float acc[CPL];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
+            PointLoop8<CH, VT, 0>::run(base4, w, k, acc);
+            if (n_cur >= 0) {
+                float* row = slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD;
+                float* r4 = row + l8 * 4;
+                if (__popc(m) == 1) {
+#pragma unroll
+                    for (int i = 0; i < M::NV4; ++i) store_vec<4>(r4 + i * 32, acc + i * 4);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < M::NV4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(r4 + i * 32 + j, acc[i * 4 + j]);
+                }
+            }
+            n_cur = n_nxt;
+            n_nxt = n_nxt2;
+            s_cur = s_nxt;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 template <int HD, int G, int P, typename VT>
 __global__ __launch_bounds__(512) void k_sca_bwd(const VT* __restrict__ value, const float* __restrict__ offs,
                                                  const float* __restrict__ logits,
@@ -1210,6 +1387,34 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                                vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsplit, nbuf);
             return ver_check_launch("ver_sca_forward");
         };
+        if constexpr (P == 8 && HD % 32 == 0) {
+            // bf16 tiles: 8 lanes per voxel (150 instead of 178 us at B = 64; with fp32 tiles the 16-lane kernel
+            // is the faster one, 152 vs 159 us). VER_SCA_FWD8=0 selects the 16-lane kernel here too.
+            static const int use8 = [] {
+                const char* e8 = getenv("VER_SCA_FWD8");
+                return e8 ? atoi(e8) : 1;
+            }();
+            if (use8 && value_dtype == VER_BF16) {
+                static const int t8 = [] {
+                    const char* et = getenv("VER_SCA_FWD8_THREADS");
+                    const int t = et ? atoi(et) : 256;
+                    return (t == 128 || t == 256) ? t : 256;
+                }();
+                const size_t per_cu = 8 * 64 / t8;                   // resident workgroups by registers
+                const int nb8 = 2 * per_cu * tile_bytes <= kMaxLds ? 2 : 1;
+                const size_t lds8 = tile_bytes * nb8;
+                auto kern = k_sca_fwd8<HD, uint16_t>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                if (e != hipSuccess)
+                    return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
+                const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(t8), lds8, st, (const uint16_t*)value, offsets, logits, uv,
+                                   vis, vis_list, vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks,
+                                   kFwdChunk, hsplit, nb8);
+                return ver_check_launch("ver_sca_forward");
+            }
+        }
         if constexpr (HD % 8 == 0) {
             if (value_dtype == VER_BF16) return launch(k_sca_fwd<HD, G, P, uint16_t>, (const uint16_t*)value);
         }

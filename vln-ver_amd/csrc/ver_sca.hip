@@ -661,8 +661,8 @@ struct PointLoop8<CH, VT, 8> {
                                                float (&)[CH / 8]) {}
 };
 
-template <int HD, typename VT>
-__global__ __launch_bounds__(256, 2) void k_sca_fwd8(
+template <int HD, typename VT, bool ROLL>
+__global__ __launch_bounds__(ROLL ? 512 : 256, ROLL ? 4 : 2) void k_sca_fwd8(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
     const int* __restrict__ vis_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
@@ -760,7 +760,31 @@ __global__ __launch_bounds__(256, 2) void k_sca_fwd8(
             float acc[CPL];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-            PointLoop8<CH, VT, 0>::run(base4, w, k, acc);
+            if constexpr (ROLL) {
+                // rolled walk over the points (ds_bpermute takes the source lane at run time): 116 instead of 216
+                // VGPRs, so four single-tile workgroups fit a CU instead of two double-buffered ones (146 -> 135 us)
+                const int src0 = (lane & ~7) << 2;
+#pragma unroll 1
+                for (int pt = 0; pt < P; ++pt) {
+                    const int src = src0 + (pt << 2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float wb = __builtin_bit_cast(
+                            float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w[t])));
+                        const unsigned ko = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)k[t]);
+                        const unsigned addr = base4 + ko;
+#pragma unroll
+                        for (int i = 0; i < M::NV4; ++i) {
+                            float v[4];
+                            load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
+                        }
+                    }
+                }
+            } else {
+                PointLoop8<CH, VT, 0>::run(base4, w, k, acc);
+            }
             if (n_cur >= 0) {
                 float* row = slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD;
                 float* r4 = row + l8 * 4;
@@ -1404,15 +1428,20 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                 return e8 ? atoi(e8) : 1;
             }();
             if (use8 && value_dtype == VER_BF16) {
-                static const int t8 = [] {
+                static const int t8_env = [] {
                     const char* et = getenv("VER_SCA_FWD8_THREADS");
                     const int t = et ? atoi(et) : 256;
-                    return (t == 128 || t == 256) ? t : 256;
+                    return (t == 128 || t == 256 || t == 512) ? t : 256;
                 }();
-                const size_t per_cu = 8 * 64 / t8;                   // resident workgroups by registers
+                static const int roll = [] {
+                    const char* er = getenv("VER_SCA_FWD8_ROLL");
+                    return er ? atoi(er) : 1;
+                }();
+                const int t8 = (!roll && t8_env == 512) ? 256 : t8_env;
+                const size_t per_cu = (roll ? 16 : 8) * 64 / t8;      // resident workgroups by registers
                 const int nb8 = 2 * per_cu * tile_bytes <= kMaxLds ? 2 : 1;
                 const size_t lds8 = tile_bytes * nb8;
-                auto kern = k_sca_fwd8<HD, uint16_t>;
+                auto kern = roll ? k_sca_fwd8<HD, uint16_t, true> : k_sca_fwd8<HD, uint16_t, false>;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
                 if (e != hipSuccess)

@@ -40,7 +40,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64, help='viewpoints per GPU per step')
+    ap.add_argument('--batch', type=int, default=None,
+                    help='viewpoints per GPU per step (default: 192 for vocc_c2f_train, 64 for the other workloads)')
     ap.add_argument('--micro', type=int, default=64, help='viewpoints per head micro-batch')
     ap.add_argument('--no-tuned-gemms', action='store_true',
                     help='do not load the recorded hipBLASLt solution table (vln-ver_amd/tuning)')
@@ -200,6 +201,8 @@ def main():
     if not args.no_tuned_gemms:
         tuned = importlib.import_module('vln-ver_amd.tuning').enable_tuned_gemms()
     pkg, syn, head, n_train = build_model(args, dev)
+    if args.batch is None:
+        args.batch = 192 if args.workload == 'vocc_c2f_train' and args.dtype == 'bf16' else 64
     B = args.batch
     train = args.workload in ('vocc_c2f_train', 'vocc_full_train')
     full = args.workload == 'vocc_full_train'

@@ -605,26 +605,15 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward, 8 lanes per voxel (P = 8 sampling points, HD % 32 == 0).  k_sca_fwd is bound by VALU issue
-// (47.5 M wave-instructions per 64-viewpoint launch = 77 us of the 1024 SIMDs): its 16 lanes per voxel
-// compute every sample's bilinear setup twice and spend 2 DPP broadcasts + 2 address adds on 3
-// v_pk_fma per corner.  Here a lane is ONE sampling point in phase A (setup once per sample) and
-// HD/8 channels in phase B; a wave carries 8 voxels.  The per-point records are broadcast inside the
-// 8-lane groups by ds_swizzle (bit-mask mode, and 0x18 | or N) -- on the LDS pipe, which has spare
-// issue slots, instead of the VALU -- and all channel vectors of a corner row share one address
-// (16-byte vectors at lane*16 + i*128).  VALU per voxel-head: ~57 instead of ~113.
-#ifndef VER_FWD8_MINW
-#define VER_FWD8_MINW 2
-#endif
-template <int N>
-__device__ __forceinline__ float swz8_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (N << 5) | 0x18));
-}
-template <int N>
-__device__ __forceinline__ unsigned swz8_u(unsigned v) {
-    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, (N << 5) | 0x18);
-}
-
+// Forward, 8 lanes per voxel (P = 8 sampling points, HD % 32 == 0; used for bf16 value tiles).  k_sca_fwd is
+// bound by VALU issue: its 16 lanes per voxel compute every sample's bilinear setup twice and spend 2 DPP
+// broadcasts + 2 address adds on 3 v_pk_fma per corner, and bf16 tiles add 6 unpack instructions per corner
+// read.  Here a lane is ONE sampling point in phase A (setup once per sample) and HD/8 channels in phase B; a
+// wave carries 8 voxels.  Phase B walks the points in a ROLLED loop: the point's weights / row offsets are
+// fetched from their phase-A lane by ds_bpermute (the source lane is a run-time value; on the LDS pipe, not the
+// VALU), all channel vectors of a corner row share one address.  The rolled form needs 116 VGPRs (216 when
+// unrolled with ds_swizzle), so four single-tile workgroups of four waves fit a CU -- workgroup slots, not
+// instructions, were what bounded the unrolled form.
 // A lane carries CH/8 channels of its voxel as NV4 vectors of 4 channels (at l8*4 + i*32).
 template <int CH, typename VT>
 struct Map8 {
@@ -634,35 +623,8 @@ struct Map8 {
     static constexpr unsigned VB4 = 4 * sizeof(VT);
 };
 
-template <int CH, typename VT, int PT>
-struct PointLoop8 {
-    __device__ __forceinline__ static void run(unsigned base4, const float (&w)[4], const unsigned (&k)[4],
-                                               float (&acc)[CH / 8]) {
-        using M = Map8<CH, VT>;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float wb = swz8_f<PT>(w[t]);
-            const unsigned ko = swz8_u<PT>(k[t]);
-            const unsigned addr = base4 + ko;
-#pragma unroll
-            for (int i = 0; i < M::NV4; ++i) {
-                float v[4];
-                load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
-            }
-        }
-        PointLoop8<CH, VT, PT + 1>::run(base4, w, k, acc);
-    }
-};
-template <int CH, typename VT>
-struct PointLoop8<CH, VT, 8> {
-    __device__ __forceinline__ static void run(unsigned, const float (&)[4], const unsigned (&)[4],
-                                               float (&)[CH / 8]) {}
-};
-
-template <int HD, typename VT, bool ROLL>
-__global__ __launch_bounds__(ROLL ? 512 : 256, ROLL ? 4 : 2) void k_sca_fwd8(
+template <int HD, typename VT>
+__global__ __launch_bounds__(512, 4) void k_sca_fwd8(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
     const int* __restrict__ vis_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
@@ -760,30 +722,24 @@ __global__ __launch_bounds__(ROLL ? 512 : 256, ROLL ? 4 : 2) void k_sca_fwd8(
             float acc[CPL];
 #pragma unroll
             for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-            if constexpr (ROLL) {
-                // rolled walk over the points (ds_bpermute takes the source lane at run time): 116 instead of 216
-                // VGPRs, so four single-tile workgroups fit a CU instead of two double-buffered ones (146 -> 135 us)
-                const int src0 = (lane & ~7) << 2;
+            const int src0 = (lane & ~7) << 2;
 #pragma unroll 1
-                for (int pt = 0; pt < P; ++pt) {
-                    const int src = src0 + (pt << 2);
+            for (int pt = 0; pt < P; ++pt) {
+                const int src = src0 + (pt << 2);                    // byte index of the point's phase-A lane
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float wb = __builtin_bit_cast(
-                            float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w[t])));
-                        const unsigned ko = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)k[t]);
-                        const unsigned addr = base4 + ko;
+                for (int t = 0; t < 4; ++t) {
+                    const float wb =
+                        __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w[t])));
+                    const unsigned ko = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)k[t]);
+                    const unsigned addr = base4 + ko;
 #pragma unroll
-                        for (int i = 0; i < M::NV4; ++i) {
-                            float v[4];
-                            load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
+                    for (int i = 0; i < M::NV4; ++i) {
+                        float v[4];
+                        load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
-                        }
+                        for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
                     }
                 }
-            } else {
-                PointLoop8<CH, VT, 0>::run(base4, w, k, acc);
             }
             if (n_cur >= 0) {
                 float* row = slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD;
@@ -1421,27 +1377,22 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             return ver_check_launch("ver_sca_forward");
         };
         if constexpr (P == 8 && HD % 32 == 0) {
-            // bf16 tiles: 8 lanes per voxel (150 instead of 178 us at B = 64; with fp32 tiles the 16-lane kernel
-            // is the faster one, 152 vs 159 us). VER_SCA_FWD8=0 selects the 16-lane kernel here too.
+            // bf16 tiles: 8 lanes per voxel (133 instead of 178 us at B = 64; with fp32 tiles the 16-lane kernel
+            // is the faster one, 145 vs 159 us). VER_SCA_FWD8=0 selects the 16-lane kernel here too.
             static const int use8 = [] {
                 const char* e8 = getenv("VER_SCA_FWD8");
                 return e8 ? atoi(e8) : 1;
             }();
             if (use8 && value_dtype == VER_BF16) {
-                static const int t8_env = [] {
+                static const int t8 = [] {
                     const char* et = getenv("VER_SCA_FWD8_THREADS");
                     const int t = et ? atoi(et) : 256;
                     return (t == 128 || t == 256 || t == 512) ? t : 256;
                 }();
-                static const int roll = [] {
-                    const char* er = getenv("VER_SCA_FWD8_ROLL");
-                    return er ? atoi(er) : 1;
-                }();
-                const int t8 = (!roll && t8_env == 512) ? 256 : t8_env;
-                const size_t per_cu = (roll ? 16 : 8) * 64 / t8;      // resident workgroups by registers
+                const size_t per_cu = 16 * 64 / t8;                  // resident workgroups by registers (4 waves / SIMD)
                 const int nb8 = 2 * per_cu * tile_bytes <= kMaxLds ? 2 : 1;
                 const size_t lds8 = tile_bytes * nb8;
-                auto kern = roll ? k_sca_fwd8<HD, uint16_t, true> : k_sca_fwd8<HD, uint16_t, false>;
+                auto kern = k_sca_fwd8<HD, uint16_t>;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
                 if (e != hipSuccess)

@@ -907,7 +907,8 @@ __global__ __launch_bounds__(512) void k_sca_bwd(const VT* __restrict__ value, c
 //     tile row at the end; no floating-point atomics (the retired kernel spent 52 % of its wave
 //     cycles waiting on ds_add_f32, which retires ~0.5 lane/clk/CU).
 constexpr int kValSub = 160;           // voxels per sub-chunk of k_sca_bwd_val
-constexpr int kValThreads = 1024;
+constexpr int kValThreads = 1024;      // (512 threads x 64..96 voxels, two workgroups per CU: same time)
+constexpr int kValGroups = kValThreads / 16;   // 16-lane groups, each owns tile rows g, g + kValGroups, ...
 constexpr int kValMaxRows = 256;       // tile rows (map_h*map_w) the register accumulators cover
 
 template <int HD, int P, typename VT>
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CPL = HD / 16;
     constexpr int NEV = kValSub * P * 4;               // events per sub-chunk
-    constexpr int NR = kValMaxRows / 64;               // tile rows per lane group
+    constexpr int NR = kValMaxRows / kValGroups;               // tile rows per lane group
     float* G = reinterpret_cast<float*>(smem);                                   // [kValSub][HD]
     float* ev_coef = G + kValSub * HD;                                           // [NEV]
     unsigned short* ev_key = reinterpret_cast<unsigned short*>(ev_coef + NEV);   // [NEV]
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
         // every lane group accumulates its tile rows from the LDS-resident grad rows
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            const int r = gidx + 64 * j;
+            const int r = gidx + kValGroups * j;
             if (r < Nk) {
                 const int i0 = rstart[r], i1 = i0 + rcnt[r];
                 for (int i = i0; i < i1; ++i) {
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
     float* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const int r = gidx + 64 * j;
+        const int r = gidx + kValGroups * j;
         if (r < Nk) {
             if (!atomic_flush) store_ch<HD, 16>(gv + (size_t)r * rstride, lr, acc[j]);
             else atomic_add_ch<HD, 16>(gv + (size_t)r * rstride, lr, 1.0f, acc[j]);
@@ -1441,11 +1442,11 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                 static const int off_threads = [] {
                     const char* ev = getenv("VER_SCA_BWD_THREADS");
                     const int t = ev ? atoi(ev) : 512;
-                    return (t == 512 || t == 1024) ? t : 512;
+                    return (t == 256 || t == 512 || t == 1024) ? t : 512;
                 }();
                 static const long off_min_wgs = [] {
                     const char* ev = getenv("VER_SCA_BWD_MIN_WGS");
-                    return ev ? atol(ev) : 768L;
+                    return ev ? atol(ev) : 12288L;      // one head per workgroup up to B*Ncam = 1536: 4-7 % faster than 768
                 }();
                 const int nbuf = (off_threads == kFwdThreads && 2 * tile_bytes <= kMaxLds) ? 2 : 1;
                 const size_t lds_off = tile_bytes * nbuf;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 13
+#define VER_ABI_VERSION 14
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -105,6 +105,10 @@ int ver_msda3d_backward(const float* value, const int64_t* shapes_dhw, const int
  *                                      output rows are zero-filled before the gather (unseen ->
  *                                      stay zero; seen by several cameras -> atomically summed)
  *   zero_cnt  i32 [B]
+ *   fwd_list  i32 [B, Ncam, Nq]        work order of ver_sca_forward for camera c: the voxels ONLY camera c
+ *                                      sees from the front (ascending), the voxels it shares with other
+ *                                      cameras from the back (fwd_list[Nq-1], fwd_list[Nq-2], ...)
+ *   fwd_cnt   i32 [B, Ncam, 2]         {#only-this-camera, #shared}; their sum is vis_cnt
  */
 
 /* VoxelFormerEncoder.get_reference_points('3d') + point_sampling
@@ -119,14 +123,16 @@ int ver_project_points(const float* world2pixel, const float* origin, const floa
                        int B, int Ncam, int bev_z, int bev_h, int bev_w,
                        float img_w, float img_h,
                        float* uv, uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                       int32_t* zero_list, int32_t* zero_cnt, void* stream);
+                       int32_t* zero_list, int32_t* zero_cnt, int32_t* fwd_list, int32_t* fwd_cnt,
+                       void* stream);
 
 /* Same lists from a caller-supplied mask in the reference's layout
  *   bev_mask u8/bool [Ncam, B, Nq, D]  (spatial_cross_attention.py:87,139-141,170).
  */
 int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
                        uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                       int32_t* zero_list, int32_t* zero_cnt, void* stream);
+                       int32_t* zero_list, int32_t* zero_cnt, int32_t* fwd_list, int32_t* fwd_cnt,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused multi-view gather = the body of SpatialCrossAttention.forward between the three
@@ -149,6 +155,7 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
 int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
                     const float* uv, const uint8_t* vis, const int32_t* vis_list,
                     const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
+                    const int32_t* fwd_list, const int32_t* fwd_cnt,
                     float* slots,
                     int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                     int map_h, int map_w, void* stream);

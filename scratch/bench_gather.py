@@ -20,6 +20,14 @@ value = torch.randn(B, 6, 196, 8, 96, device=dev, generator=g)
 if BF16: value = value.to(torch.bfloat16)
 offs = torch.randn(B, nq, 8, 8, 2, device=dev, generator=g) * 3
 logits = torch.randn(B, nq, 8, 8, device=dev, generator=g)
+if os.environ.get('VER_BENCH_RING'):      # the reference's initial offsets (spatial_cross_attention.py:255-270), uniform attention
+    import math
+    th = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+    gdir = torch.stack([th.cos(), th.sin()], -1)
+    gdir = gdir / gdir.abs().max(-1, keepdim=True)[0]
+    ring = gdir[:, None, :] * torch.arange(1, 9, dtype=torch.float32)[None, :, None]       # [heads, points, 2]
+    offs = ring.to(dev)[None, None].expand(B, nq, 8, 8, 2).contiguous()
+    logits = torch.zeros(B, nq, 8, 8, device=dev)
 gs = torch.randn(B, nq, 768, device=dev, generator=g)
 sn = int(hit.vis_cnt.sum())
 fwd_b = B*6*196*768*4 + sn*(128+64+768)*4

@@ -18,24 +18,55 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-mun
          '-Wall', '-Wno-unused-function']
 
 
-def stale():
-    if not os.path.exists(LIB):
+OBJ_DIR = os.path.join(HERE, 'build')
+CFLAGS = [f for f in FLAGS if f != '-shared']
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force=False, verbose=True):
-    if not force and not stale():
+def stale():
+    deps = [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return _newer(LIB, deps)
+
+
+def build_hip(force=False, verbose=True, defines=(), lib=None):
+    """Compile each source to csrc/build/<name>.o (only the stale ones) and link libver_hip.so.
+    ``defines`` / ``lib``: experiment builds (scratch/) with extra -D flags into another .so."""
+    lib = lib or LIB
+    if not force and not defines and lib == LIB and not stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ['-o', LIB]
+    tag = ''.join('_' + d.replace('=', '-') for d in defines)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, procs = [], []
+    for src in SOURCES:
+        path = os.path.join(HERE, src)
+        # only the gather kernels take experiment defines
+        mytag = tag if (defines and src == 'ver_sca.hip') else ''
+        obj = os.path.join(OBJ_DIR, src.replace('.hip', mytag + '.o'))
+        objs.append(obj)
+        if force or _newer(obj, [path] + hdrs):
+            cmd = [hipcc] + CFLAGS + (['-D' + d for d in defines] if mytag else []) + ['-c', path, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    build_hip(force='--force' in sys.argv)
+    defs = tuple(a[2:] for a in sys.argv[1:] if a.startswith('-D'))
+    out = [a[6:] for a in sys.argv[1:] if a.startswith('--lib=')]
+    build_hip(force='--force' in sys.argv, defines=defs, lib=out[0] if out else None)

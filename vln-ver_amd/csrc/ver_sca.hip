@@ -89,47 +89,59 @@ __global__ __launch_bounds__(256) void k_mask_to_vis(const uint8_t* __restrict__
 // ordered (ascending voxel id) compaction: per camera the voxels it sees (= the reference's
 // `indexes[c]`), and per viewpoint (built by the camera-0 workgroup) the voxels NOT seen by exactly
 // one camera -- their output rows are zero-filled before the gather (unseen: stay zero; seen by
-// several cameras: accumulated with atomics).
+// several cameras: accumulated with atomics).  fwd_list is the forward kernel's work order for the
+// camera: voxels only this camera sees first (plain stores), voxels shared with other cameras from the
+// back of the array (atomic adds); fwd_cnt = {#single, #shared}.
 __global__ __launch_bounds__(256) void k_build_lists(const uint8_t* __restrict__ vis, int Ncam, int Nq,
                                                      int* __restrict__ vis_list, int* __restrict__ vis_cnt,
-                                                     int* __restrict__ zero_list, int* __restrict__ zero_cnt) {
-    __shared__ int wsum[2][4];
+                                                     int* __restrict__ zero_list, int* __restrict__ zero_cnt,
+                                                     int* __restrict__ fwd_list, int* __restrict__ fwd_cnt) {
+    __shared__ int wsum[4][4];
     const int c = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     int* vl = vis_list + ((size_t)b * Ncam + c) * Nq;
     int* zl = zero_list + (size_t)b * Nq;
-    int base_v = 0, base_z = 0;
+    int* fl = fwd_list + ((size_t)b * Ncam + c) * Nq;
+    int base_v = 0, base_z = 0, base_s = 0, base_m = 0;
     for (int n0 = 0; n0 < Nq; n0 += 256) {
         const int n = n0 + tid;
         const bool valid = n < Nq;
         const unsigned m = valid ? vis[(size_t)b * Nq + n] : 0u;
         const bool is_v = valid && ((m >> c) & 1u);
         const bool is_z = valid && c == 0 && __popc(m) != 1;
-        const unsigned long long bv = __ballot(is_v), bz = __ballot(is_z);
+        const bool is_s = is_v && __popc(m) == 1, is_m = is_v && __popc(m) > 1;
+        const unsigned long long bv = __ballot(is_v), bz = __ballot(is_z), bs = __ballot(is_s), bm = __ballot(is_m);
         if (lane == 0) {
             wsum[0][wave] = __popcll(bv);
             wsum[1][wave] = __popcll(bz);
+            wsum[2][wave] = __popcll(bs);
+            wsum[3][wave] = __popcll(bm);
         }
         __syncthreads();
-        int off_v = base_v, off_z = base_z, tot_v = 0, tot_z = 0;
+        int off[4] = {base_v, base_z, base_s, base_m}, tot[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w < wave) {
-                off_v += wsum[0][w];
-                off_z += wsum[1][w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (w < wave) off[q] += wsum[q][w];
+                tot[q] += wsum[q][w];
             }
-            tot_v += wsum[0][w];
-            tot_z += wsum[1][w];
         }
-        if (is_v) vl[off_v + __popcll(bv & lt)] = n;
-        if (is_z) zl[off_z + __popcll(bz & lt)] = n;
-        base_v += tot_v;
-        base_z += tot_z;
+        if (is_v) vl[off[0] + __popcll(bv & lt)] = n;
+        if (is_z) zl[off[1] + __popcll(bz & lt)] = n;
+        if (is_s) fl[off[2] + __popcll(bs & lt)] = n;                    // single-camera voxels from the front
+        if (is_m) fl[Nq - 1 - (off[3] + __popcll(bm & lt))] = n;         // multi-camera voxels from the back
+        base_v += tot[0];
+        base_z += tot[1];
+        base_s += tot[2];
+        base_m += tot[3];
         __syncthreads();
     }
     if (tid == 0) {
         vis_cnt[b * Ncam + c] = base_v;
+        fwd_cnt[(b * Ncam + c) * 2 + 0] = base_s;
+        fwd_cnt[(b * Ncam + c) * 2 + 1] = base_m;
         if (c == 0) zero_cnt[b] = base_z;
     }
 }
@@ -341,6 +353,28 @@ extern "C" int ver_debug_read(long long* out, int n) {
 #define VER_STAMP(slot, cond) \
     do {                      \
     } while (0)
+#endif
+#ifdef VER_DEBUG_TIMELINE
+// timeline of a few probe workgroups of k_sca_fwd_q: g_tl[probe][wave][event] = s_memtime
+__device__ long long g_tl[4 * 16 * 64];
+__device__ __forceinline__ int tl_probe() {
+    const int nb = gridDim.x;
+    const int pb[4] = {nb / 8, (3 * nb) / 8, (5 * nb) / 8, (7 * nb) / 8};
+    for (int i = 0; i < 4; ++i)
+        if ((int)blockIdx.x == pb[i]) return i;
+    return -1;
+}
+#define VER_TL(ev)                                                                                        \
+    do {                                                                                                  \
+        const int pr_ = tl_probe();                                                                       \
+        if (pr_ >= 0 && (threadIdx.x & 63) == 0 && (ev) < 64)                                              \
+            g_tl[(pr_ * 16 + (threadIdx.x >> 6)) * 64 + (ev)] = (long long)__builtin_amdgcn_s_memtime();  \
+    } while (0)
+extern "C" int ver_timeline_read(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl), n * sizeof(long long));
+}
+#else
+#define VER_TL(ev) do { } while (0)
 #endif
 
 template <int N>
@@ -605,158 +639,376 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
 }
 
 // ------------------------------------------------------------------------------------------
-// Forward, 8 lanes per voxel (P = 8 sampling points, HD % 32 == 0; used for bf16 value tiles).  k_sca_fwd is
-// bound by VALU issue: its 16 lanes per voxel compute every sample's bilinear setup twice and spend 2 DPP
-// broadcasts + 2 address adds on 3 v_pk_fma per corner, and bf16 tiles add 6 unpack instructions per corner
-// read.  Here a lane is ONE sampling point in phase A (setup once per sample) and HD/8 channels in phase B; a
-// wave carries 8 voxels.  Phase B walks the points in a ROLLED loop: the point's weights / row offsets are
-// fetched from their phase-A lane by ds_bpermute (the source lane is a run-time value; on the LDS pipe, not the
-// VALU), all channel vectors of a corner row share one address.  The rolled form needs 116 VGPRs (216 when
-// unrolled with ds_swizzle), so four single-tile workgroups of four waves fit a CU -- workgroup slots, not
-// instructions, were what bounded the unrolled form.
-// A lane carries CH/8 channels of its voxel as NV4 vectors of 4 channels (at l8*4 + i*32).
-template <int CH, typename VT>
-struct Map8 {
-    static constexpr int CPL = CH / 8;
-    static constexpr int NV4 = CPL / 4;
-    static_assert(CH % 32 == 0, "8 lanes x vectors of 4 channels");
-    static constexpr unsigned VB4 = 4 * sizeof(VT);
-};
+// Forward, "corner slots" (P = 8 points, head_dim % 32 == 0; fp32 and bf16 tiles).  What round 1's kernels were
+// bound by, measured (scratch/r02/, profiles/r02_*):
+//   * the LDS pipe: per corner row and wave k_sca_fwd8 issued two ds_bpermute_b32 (9 LDS cycles each on gfx950) and
+//     three ds_read_b64 whose four voxels per 32-lane service group sat on random tile rows (2.1-way bank conflicts on
+//     average, ubench_lds.hip): 72 % LDS-busy, 43 % VALU-busy;
+//   * s_waitcnt vmcnt(0) in front of every operand use, because stores / atomics / clamped loads sat under branches
+//     and the compiler cannot count conditional vector-memory operations;
+//   * one wave finishing a camera's shared-voxel list alone while the workgroup's other waves idled.
+// This kernel:
+//   * makes the four 8-lane slots of a half wave the FOUR BILINEAR CORNERS OF ONE SAMPLE and keeps the tile PLANAR in
+//     LDS: plane i holds channels [32i, 32i+32) of every tile row, so a plane row is 128 B (fp32) or 64 B (bf16) and
+//     the corner rows (r, r+1, r+W, r+W+1) of a 14-wide map fall on four disjoint bank sets -- every read of the
+//     gather is conflict free by construction (rows that coincide at the map border broadcast).  The planes are too
+//     far apart for the compiler to fuse a row's reads into half-rate ds_read2.  LDS-DMA writes lane-linear 16-byte
+//     chunks, so the planar image only changes the per-lane SOURCE address;
+//   * walks two voxels per wave at a time (one per half wave), one sampling point per step; the {corner weight, row
+//     offset} records of a pair travel through a 512-B per-wave LDS table (four conflict-free ds_read_b128 per slot
+//     and pair instead of two ds_bpermute per corner row), published one pair ahead;
+//   * folds the four corner partial sums once per (voxel, head): v_permlane16_swap on pairs of accumulators (a
+//     transposing reduction across the two 16-lane rows of a half wave) + one DPP row_ror:8 add; a lane then owns
+//     2 x HD/32 adjacent channels of its voxel's output row;
+//   * issues every global load and store unconditionally (clamped indices, dead lanes -> g_sca_dummy_row / zero adds),
+//     so the compiler's vmcnt waits are exact and never drain the young output stores.
+// Result on MI355X: LDS bank conflicts 29.7 M -> 2.6 M cycles per launch, LDS-busy 72 % -> 28 %, and the kernel is now
+// bound by VALU issue (60 % busy: 12 FMAs + 12 bf16 unpacks per lane and corner row) -- see DESIGN.md section 3.1
+// for why the launch time did not move.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T* lds_ptr_mut(unsigned addr) {
+    return reinterpret_cast<T*>((unsigned char*)(__attribute__((address_space(3))) unsigned char*)(uintptr_t)addr);
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    // rows (16 lanes) 1 and 3 of `a` <-> rows 0 and 2 of `b`.  (The ROCm 7.2 builtin returns the first
+    // result twice; the s_nop covers the VALU-write -> permlane-read wait states the compiler cannot see.)
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 
-template <int HD, typename VT>
-__global__ __launch_bounds__(512, 4) void k_sca_fwd8(
+// Rows that dead lanes (the pad entry of an odd list) write to, so that every store of the gather loop is
+// unconditional: with stores or loads under a branch the compiler cannot count the vector-memory operations in
+// flight and falls back to s_waitcnt vmcnt(0) in front of every operand use.
+__device__ float g_sca_dummy_row[256 * 256];        // one 1-KiB slice per (blockIdx & 255): no chip-wide hot line
+
+// ------------------------------------------------------------------------------------------
+// Forward, corner-slot kernel with a merged work list, sample compaction and (optionally) streaming loader waves.
+//
+// A workgroup walks a contiguous range of (viewpoint, camera, chunk, head group) units, one (camera, head) tile
+// at a time:
+//   nload > 0  persistent form: the last `nload` waves only stream tiles (LDS-DMA of tile i+1 while the consumers
+//              work on tile i; two tile buffers, one barrier per tile);
+//   nload == 0 every wave stages its share of the tile, then all of them gather from it (one buffer; several
+//              workgroups per CU overlap each other's staging).
+// The consumer waves split a tile's voxel PAIRS into contiguous ranges over the merged list
+// [voxels only this camera sees, padded to a whole pair | voxels shared with other cameras]: a pair is either all
+// plain stores or all atomic adds (wave-uniform).  Voxel ids / visibility of a unit are fetched once for all its
+// heads, and the first operands of a tile are requested before the tile barrier.
+// Samples whose footprint misses the map entirely (or whose voxel is dead) have an all-zero record: phase A
+// COMPACTS the live samples of a voxel to the front of its record row, and a pair only walks
+// max(live samples of its two voxels) points -- with the reference's initial ring of offsets (1..8 px on a 14-px
+// map, spatial_cross_attention.py:255-270) more than a third of the samples are outside.
+template <int HD, typename VT, int NKT>
+__global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
-    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ vis_list,
-    const int* __restrict__ vis_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
-    int nchunks, int chunk, int hsplit, int nbuf) {
+    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
+    const int* __restrict__ fwd_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
+    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int P = 8, CH = HD;
-    using M = Map8<CH, VT>;
-    constexpr int CPL = M::CPL;
-    constexpr unsigned kRowBytes = CH * sizeof(VT);
+    constexpr int P = 8;
+    constexpr bool F32 = sizeof(VT) == 4;
+    constexpr int NV = HD / 32;
+    constexpr unsigned RB = 32 * sizeof(VT);
+    constexpr int CPR = 32 * sizeof(VT) / 16, EPC = 16 / sizeof(VT);
+    static_assert(HD % 32 == 0, "8 lanes x vectors of 4 channels");
     const int nwaves = (int)(blockDim.x >> 6);
-    const int Nk = mh * mw;
-    const size_t tile_elems = (size_t)Nk * CH;
-    VT* tiles = reinterpret_cast<VT*>(smem);
-    int bid = blockIdx.x;
-    const int ck = bid % nchunks;
-    bid /= nchunks;
-    const int hs = bid % hsplit;
-    bid /= hsplit;
-    const int c = bid % Ncam;
-    const int b = bid / Ncam;
-    const int cnt = vis_cnt[b * Ncam + c];
-    const int start = ck * chunk;
-    if (start >= cnt) return;
-    const int end = min(cnt, start + chunk);
-    const int heads_per = heads / hsplit, h0 = hs * heads_per;
-    const size_t rstride = (size_t)heads * HD;
-    const VT* vown = value + ((size_t)b * Ncam + c) * Nk * rstride;
+    const int ncons = nwaves - nload;
+    const int nbuf = nload > 0 ? 2 : 1;
+    const int Nk = NKT ? NKT : mh * mw;
+    const unsigned plane = (unsigned)Nk * RB;
+    const unsigned tile_bytes = (NV * plane + 15u) & ~15u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = lane >> 3, l8 = lane & 7;             // voxel slot of the wave, point / channel lane
-    const int ad = (D == 1) ? 0 : (l8 % D);
-    const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
-    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
-    const int STEP = nwaves * 8;
+    const int heads_per = heads / hsplit;
+    const size_t rstride = (size_t)heads * HD;
+    const int u0 = blockIdx.x * units_per_wg, u1 = min(u0 + units_per_wg, units_total);
+    const int ntiles = (u1 - u0) * heads_per;
+    if (ntiles <= 0) return;
+    VER_TL(0);
 
-    if (nbuf == 2) stage_tile<CH, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, wave, nwaves);
-    for (int hh = 0; hh < heads_per; ++hh) {
-        const int h = h0 + hh;
-        const int cur = nbuf == 2 ? (hh & 1) : 0;
-        VT* tile = tiles + cur * tile_elems;
-        if (nbuf == 1) {
-            __syncthreads();
-            stage_tile<CH, VT>(tile, vown + (size_t)h * HD, rstride, Nk, wave, nwaves);
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (nbuf == 2 && hh + 1 < heads_per)
-            stage_tile<CH, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, wave, nwaves);
-
-        struct Sample {
-            unsigned m;
-            float lg;
-            float2 of, u;
-        };
-        auto load_id = [&](int base) -> int {
-            const int ia = base + slot;
-            return ia < end ? list[ia] : -1;
-        };
-        auto load_sample = [&](int n) -> Sample {
-            Sample sm;
-            const int nn = n < 0 ? 0 : n;
-            const size_t qh = ((size_t)b * Nq + nn) * heads + h;
-            sm.m = n < 0 ? 0u : (unsigned)vis[(size_t)b * Nq + nn];
-            sm.lg = logits[qh * P + l8];
-            sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + l8) * 2);
-            sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
-            return sm;
-        };
-        const unsigned tile_lds = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(tile);
-        const unsigned base4 = tile_lds + (unsigned)l8 * M::VB4;
-        const int base0 = start + wave * 8;
-        int n_cur = load_id(base0);
-        int n_nxt = load_id(base0 + STEP);
-        Sample s_cur = load_sample(n_cur);
-        for (int base = base0; base < end; base += STEP) {
-            const Sample s_nxt = load_sample(n_nxt);
-            const int n_nxt2 = load_id(base + 2 * STEP);
-            // ---------------- phase A: lane = sampling point
-            const unsigned m = s_cur.m;
-            float w[4];
-            unsigned k[4];
-            {
-                const float mx = group_max<8>(s_cur.lg);
-                const float e = __expf(s_cur.lg - mx);
-                const float ssum = group_sum<8>(e);
-                const float a = m ? e * __builtin_amdgcn_rcpf(ssum * (float)__popc(m)) : 0.0f;
-                Bilinear s;
-                bilinear_setup<false>(s_cur.u.x + s_cur.of.x * inv_w, s_cur.u.y + s_cur.of.y * inv_h, mh, mw, s);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    w[t] = a * s.w[t];
-                    k[t] = (unsigned)s.key[t] * kRowBytes;
-                }
+    // Tile staging.  A lone loader wave runs its address arithmetic as one dependent chain, so the per-DMA work is a
+    // handful of instructions: the lane's (plane, row) position advances incrementally and the tile's base pointer
+    // is wave-uniform.  (Two integer divisions per DMA cost a loader wave 23 k cycles per 75-KB tile.)
+    const int dma_wave = nload ? wave - ncons : wave, dma_waves = nload ? nload : nwaves;
+    const int total_chunks = NV * Nk * CPR;
+    const int rows_per_step = 64 * dma_waves / CPR;                // plane rows covered by one step of all DMA waves
+    const int q_first = dma_wave * 64 + lane;
+    const int jc = q_first % CPR;
+    const int i_first = (q_first / CPR) / Nk, k_first = (q_first / CPR) - i_first * Nk;
+    auto stage = [&](int i) {
+        int r = u0 + i / heads_per;
+        const int hs = r % hsplit;
+        r /= hsplit;
+        r /= nchunks;
+        const int c = r % Ncam, b = r / Ncam;
+        const int h = hs * heads_per + i % heads_per;
+        const VT* src = value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD + jc * EPC;
+        VT* dst = reinterpret_cast<VT*>(smem + (nbuf == 2 ? (i & 1) : 0) * tile_bytes);
+        int pi = i_first, pk = k_first;
+        for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
+            if (q0 + lane < total_chunks) {
+                const VT* g = src + (size_t)pk * rstride + pi * 32;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, 0);
             }
-            // ---------------- phase B: lane = CH/8 channels
-            float acc[CPL];
+            pk += rows_per_step;
+            while (pk >= Nk) {
+                pk -= Nk;
+                pi += 1;
+            }
+        }
+    };
+
+    if (nload > 0 && wave >= ncons) {
+        // ------------------------------------------------------------ loader waves: stream the tiles
+        stage(0);
+        for (int i = 0; i < ntiles; ++i) {
+            __builtin_amdgcn_s_waitcnt(0);            // this wave's share of tile i has landed
+            VER_TL(1 + i);
+            __syncthreads();                          // tile i complete; the consumers are done with tile i - 1
+            if (i + 1 < ntiles) stage(i + 1);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------- consumer waves
+    const int s4 = lane >> 4, v2 = (lane >> 3) & 1, l8 = lane & 7;   // phase A: pair of the iteration, voxel of the pair, point
+    const int half = lane >> 5, rho = (lane >> 4) & 1, sigma = (lane >> 3) & 1;
+    const int ad = (D == 1) ? 0 : (l8 % D);
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+    const unsigned smem_lds = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(smem);
+    // records {weight, row offset} of a voxel pair: [voxel of the pair][corner][slot], 8 B each: a corner slot reads
+    // its 8 sample slots as four conflict-free ds_read_b128 (corner rows are 64 B = 16 banks apart)
+    const unsigned rec_wave = smem_lds + (unsigned)nbuf * tile_bytes + (unsigned)wave * 512u;
+    const unsigned rec_wr0 = rec_wave + (unsigned)v2 * 256u;                                      // + slot * 8 + corner * 64
+    const unsigned rec_rd = rec_wave + (unsigned)half * 256u + (unsigned)((lane >> 3) & 3) * 64u;
+    const unsigned lane_off = (unsigned)l8 * (F32 ? 16u : 8u);
+    struct Sample {
+        unsigned m;
+        float lg;
+        float2 of, u;
+    };
+    int ti = 0;                                       // tile counter of this workgroup
+    for (int un = u0; un < u1; ++un) {
+        int r = un;
+        const int hs = r % hsplit;
+        r /= hsplit;
+        const int ck = r % nchunks;
+        r /= nchunks;
+        const int c = r % Ncam, b = r / Ncam;
+        const int h0 = hs * heads_per;
+        const int n_single = fwd_cnt[(b * Ncam + c) * 2], n_multi = fwd_cnt[(b * Ncam + c) * 2 + 1];
+        const int w_start = ck * chunk;
+        const int s_n = max(0, min(n_single - w_start, chunk)), m_n = max(0, min(n_multi - w_start, chunk));
+        const int s_n2 = (s_n + 1) & ~1, s_pairs = s_n2 >> 1;
+        const int TP = s_pairs + ((m_n + 1) >> 1);
+        const int p_lo = (int)((long)wave * TP / ncons), p_hi = (int)((long)(wave + 1) * TP / ncons);
+        const int iters = (p_hi - p_lo + 3) >> 2;
+        const int* list = fwd_list + ((size_t)b * Ncam + c) * Nq;
+        // list entry of this lane in wave iteration `it`; dead entries (pad, odd tail, pairs of other waves) return
+        // -(id of a live voxel of the same region) - 1
+        auto load_id = [&](int it) -> int {
+            const int pp = min(p_lo + 4 * it + s4, TP - 1);
+            const int e = 2 * pp + v2;
+            const bool multi = e >= s_n2;
+            const int idx = multi ? e - s_n2 : e;
+            const int lim = multi ? m_n : s_n;
+            const int pos = multi ? (Nq - 1 - w_start - min(idx, lim - 1)) : (w_start + min(idx, lim - 1));
+            const int n = list[pos];
+            return (idx < lim && p_lo + 4 * it + s4 < p_hi) ? n : -n - 1;
+        };
+        int un0 = -1, un1 = -1, un2 = -1;
+        if (iters > 0) {
+            un0 = load_id(0);
+            un1 = load_id(1);
+            un2 = load_id(2);
+        }
+        for (int hh = 0; hh < heads_per; ++hh, ++ti) {
+            const int h = h0 + hh;
+            if (nload == 0) {
+                if (ti) __syncthreads();              // everyone is done with the previous tile
+                stage(ti);
+            }
+            auto load_sample = [&](int n) -> Sample {
+                Sample sm;
+                const int nn = n < 0 ? -n - 1 : n;
+                const size_t qh = ((size_t)b * Nq + nn) * heads + h;
+                const unsigned mv = (unsigned)vis[(size_t)b * Nq + nn];
+                sm.m = n < 0 ? 0u : mv;
+                sm.lg = logits[qh * P + l8];
+                sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + l8) * 2);
+                sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
+                return sm;
+            };
+            int n0 = un0, n1 = un1, n2 = un2;
+            Sample s0 = {};
+            if (iters > 0) s0 = load_sample(n0);      // requested before the tile barrier: the latency hides behind it
+            if (nload == 0) __builtin_amdgcn_s_waitcnt(0);         // this wave's share of the tile has landed
+            __syncthreads();                          // tile ti is complete
+            VER_TL(1 + ti);
+            const unsigned base4 = smem_lds + (nbuf == 2 ? (unsigned)(ti & 1) * tile_bytes : 0u) + lane_off;
+            // operands: voxel ids two wave iterations ahead, sample records one ahead (all loads and stores of the loop
+            // are unconditional, so the compiler's vmcnt waits never have to drain the young output stores)
+            for (int it = 0; it < iters; ++it) {
+                const Sample s1 = load_sample(n1);
+                const int n3 = load_id(it + 3);
+                // ---------------- phase A: lane = sampling point l8 of voxel (s4, v2)
+                const unsigned m = s0.m;
+                float w[4];
+                unsigned k[4];
+                int cnt;                              // live samples of this lane's voxel
+                unsigned rec_wr;
+                {
+                    const float mx = group_max<8>(s0.lg);
+                    const float e = __expf(s0.lg - mx);
+                    const float ssum = group_sum<8>(e);
+                    const float a = m ? e * __builtin_amdgcn_rcpf(ssum * (float)__popc(m)) : 0.0f;
+                    Bilinear s;
+                    bilinear_setup<false>(s0.u.x + s0.of.x * inv_w, s0.u.y + s0.of.y * inv_h, mh, mw, s);
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) acc[j] = 0.0f;
-            const int src0 = (lane & ~7) << 2;
-#pragma unroll 1
-            for (int pt = 0; pt < P; ++pt) {
-                const int src = src0 + (pt << 2);                    // byte index of the point's phase-A lane
+                    for (int t = 0; t < 4; ++t) {
+                        w[t] = a * s.w[t];
+                        k[t] = (unsigned)s.key[t] * RB;            // row offset inside a plane
+                    }
+                    // compaction: live samples first (in point order), all-zero records behind them
+                    const bool live = (w[0] + w[1] + w[2] + w[3]) != 0.0f;      // weights are >= 0
+                    const unsigned long long bal = __ballot(live);
+                    const unsigned gm = (unsigned)(bal >> (lane & ~7)) & 0xffu;
+                    const unsigned below = (1u << l8) - 1u;
+                    cnt = __popc(gm);
+                    const int slot = live ? __popc(gm & below) : cnt + __popc(~gm & below);
+                    rec_wr = rec_wr0 + (unsigned)slot * 8u;
+                }
+                // ---------------- phase B: two voxels per sub-iteration, lane = (voxel, corner, 4*NV channels)
+                const int nsub = min(4, p_hi - p_lo - 4 * it);
+                // Records travel from the phase-A lanes to the corner slots through the wave's 512-B LDS table.  Other
+                // lanes of the wave read them: LDS serves one wave's requests in order, so no wait is needed in hardware,
+                // but the compiler must know (without the fence it forwarded the previous pair's loads to the lanes that
+                // did not store -- legal for a single thread, wrong here).
+                u32x4_t recs[P / 2];
+                if (s4 == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float wb =
-                        __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, w[t])));
-                    const unsigned ko = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)k[t]);
-                    const unsigned addr = base4 + ko;
+                    for (int t = 0; t < 4; ++t)
+                        *lds_ptr_mut<unsigned long long>(rec_wr + (unsigned)t * 64u) =
+                            (unsigned long long)__float_as_uint(w[t]) | ((unsigned long long)k[t] << 32);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-                    for (int i = 0; i < M::NV4; ++i) {
-                        float v[4];
-                        load_vec<4>(lds_ptr<VT>(addr + i * 8 * M::VB4), v);
+                for (int pp = 0; pp < P / 2; ++pp) recs[pp] = *lds_ptr<u32x4_t>(rec_rd + (unsigned)pp * 16u);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i * 4 + j] += wb * v[j];
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= nsub) break;                          // wave-uniform
+                    const bool atomic = p_lo + 4 * it + j >= s_pairs;   // wave-uniform: the pair is in the shared region
+                    const int npts = max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8));
+                    // `recs` holds this pair's records (requested during the previous pair's epilogue).  Publish the next
+                    // pair's now -- LDS serves the wave's requests in order, so the reads of this pair's records are
+                    // already done -- and request them after the FMA loop, when `recs` is free again: neither the
+                    // write -> read round trip through LDS nor the read latency is exposed (85 us of a 474-us launch
+                    // when they were).
+                    if (j + 1 < nsub && s4 == j + 1) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            *lds_ptr_mut<unsigned long long>(rec_wr + (unsigned)t * 64u) =
+                                (unsigned long long)__float_as_uint(w[t]) | ((unsigned long long)k[t] << 32);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    float acc[4 * NV];
+#pragma unroll
+                    for (int i = 0; i < 4 * NV; ++i) acc[i] = 0.0f;
+                    // tile vectors of a point are requested one point ahead of their FMAs (explicitly: left to itself the
+                    // compiler, short of registers, funnelled every read through one register pair with a full
+                    // lgkmcnt(0) wait in front of each group of FMAs)
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    typedef typename std::conditional<F32, f32x4_t, u32x2_t>::type tv_t;
+                    auto rec_w = [&](int pt) { return __uint_as_float((pt & 1) ? recs[pt / 2].z : recs[pt / 2].x); };
+                    auto rec_a = [&](int pt) { return base4 + ((pt & 1) ? recs[pt / 2].w : recs[pt / 2].y); };
+                    // (volatile: an ordinary load whose only use is in the next point's block gets sunk into it)
+                    auto tile_ld = [&](unsigned addr) -> tv_t {
+                        return *(const volatile __attribute__((address_space(3))) tv_t*)(uintptr_t)addr;
+                    };
+                    tv_t tnx[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) tnx[i] = tile_ld(rec_a(0) + (unsigned)i * plane);
+#pragma unroll
+                    for (int pt = 0; pt < P; ++pt) {
+                        if (pt >= npts) break;                     // wave-uniform: the pair has no more live samples
+                        const float wb = rec_w(pt);
+                        tv_t tc[NV];
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) tc[i] = tnx[i];
+                        if (pt + 1 < P) {
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) tnx[i] = tile_ld(rec_a(pt + 1) + (unsigned)i * plane);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            float v[4];
+                            if constexpr (F32) {
+                                v[0] = tc[i].x; v[1] = tc[i].y; v[2] = tc[i].z; v[3] = tc[i].w;
+                            } else {
+                                v[0] = __uint_as_float(tc[i].x << 16); v[1] = __uint_as_float(tc[i].x & 0xffff0000u);
+                                v[2] = __uint_as_float(tc[i].y << 16); v[3] = __uint_as_float(tc[i].y & 0xffff0000u);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[i * 4 + q] = __builtin_fmaf(wb, v[q], acc[i * 4 + q]);
+                        }
+                    }
+                    if (j + 1 < nsub) {                            // next pair's records: the latency hides behind the epilogue
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                        for (int pp = 0; pp < P / 2; ++pp) recs[pp] = *lds_ptr<u32x4_t>(rec_rd + (unsigned)pp * 16u);
+                    }
+                    // fold the four corner slots: rows of 16 lanes first (transposing: even rows keep channels {0,1}
+                    // of each vector, odd rows {2,3}), then the two slots of a row
+                    float out[2 * NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        permlane16_swap(acc[i * 4 + 0], acc[i * 4 + 2]);
+                        permlane16_swap(acc[i * 4 + 1], acc[i * 4 + 3]);
+                        out[2 * i + 0] = acc[i * 4 + 0] + acc[i * 4 + 2];
+                        out[2 * i + 1] = acc[i * 4 + 1] + acc[i * 4 + 3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2 * NV; ++i) out[i] += dpp_mov<0x128>(out[i]);      // row_ror:8
+                    const int na = __builtin_amdgcn_readlane(n0, 16 * j), nb = __builtin_amdgcn_readlane(n0, 16 * j + 8);
+                    const int n = half ? nb : na;
+                    const size_t rowoff =
+                        ((size_t)b * Nq + (n < 0 ? -n - 1 : n)) * heads * HD + (size_t)h * HD + l8 * 4 + rho * 2;
+                    if (!atomic) {
+                        // both slots of a row hold the sums and share the stores; a dead voxel (pad of an odd count)
+                        // writes to the dummy row
+                        float* row = n >= 0 ? slots + rowoff : g_sca_dummy_row + (blockIdx.x & 255) * 256 + l8 * 4 + rho * 2;
+#pragma unroll
+                        for (int kk = 0; kk < (NV + 1) / 2; ++kk) {
+                            float o2[2];
+                            float* dst;
+                            if (2 * kk + 1 < NV) {
+                                float a0 = out[4 * kk], a1 = out[4 * kk + 1], b0 = out[4 * kk + 2], b1 = out[4 * kk + 3];
+                                asm("" : "+v"(b0), "+v"(b1));      // (keeps the selects out of scratch memory)
+                                o2[0] = sigma ? b0 : a0;
+                                o2[1] = sigma ? b1 : a1;
+                                dst = row + (2 * kk + sigma) * 32;
+                            } else {                               // odd plane count: both slots write the last vector
+                                o2[0] = out[4 * kk];
+                                o2[1] = out[4 * kk + 1];
+                                dst = row + 2 * kk * 32;
+                            }
+                            store_vec<2, true>(dst, o2);
+                        }
+                    } else {
+                        float* row = slots + rowoff;               // dead voxel (odd tail): adds zeros to a live shared row
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            float a0 = out[2 * i], b0 = out[2 * i + 1];
+                            asm("" : "+v"(b0));
+                            const float val = n < 0 ? 0.0f : (sigma ? b0 : a0);
+                            atomicAdd(row + i * 32 + sigma, val);
+                        }
                     }
                 }
+                n0 = n1; n1 = n2; n2 = n3;
+                s0 = s1;
             }
-            if (n_cur >= 0) {
-                float* row = slots + ((size_t)b * Nq + n_cur) * heads * HD + (size_t)h * HD;
-                float* r4 = row + l8 * 4;
-                if (__popc(m) == 1) {
-#pragma unroll
-                    for (int i = 0; i < M::NV4; ++i) store_vec<4, true>(r4 + i * 32, acc + i * 4);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < M::NV4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) atomicAdd(r4 + i * 32 + j, acc[i * 4 + j]);
-                }
-            }
-            n_cur = n_nxt;
-            n_nxt = n_nxt2;
-            s_cur = s_nxt;
         }
     }
 }
@@ -1232,6 +1484,11 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
 // ------------------------------------------------------------------------------------------
 namespace {
 
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 constexpr int kFwdChunk = 2048;
 constexpr int kBwdChunk = 4096;
 constexpr size_t kMaxLds = 160 * 1024;
@@ -1277,8 +1534,10 @@ int check_sca(const void* value, int vdt, const void* a, const void* b, const vo
 extern "C" int ver_project_points(const float* world2pixel, const float* origin, const float* pc_range, int B,
                                   int Ncam, int bev_z, int bev_h, int bev_w, float img_w, float img_h,
                                   float* uv, uint8_t* vis, int32_t* vis_list, int32_t* vis_cnt,
-                                  int32_t* zero_list, int32_t* zero_cnt, void* stream) {
-    VER_REQUIRE(world2pixel && origin && pc_range && uv && vis && vis_list && vis_cnt && zero_list && zero_cnt,
+                                  int32_t* zero_list, int32_t* zero_cnt, int32_t* fwd_list, int32_t* fwd_cnt,
+                                  void* stream) {
+    VER_REQUIRE(world2pixel && origin && pc_range && uv && vis && vis_list && vis_cnt && zero_list && zero_cnt &&
+                    fwd_list && fwd_cnt,
                 VER_EINVAL, "ver_project_points: null pointer argument");
     VER_REQUIRE(Ncam >= 1 && Ncam <= 8, VER_EUNSUPPORTED, "ver_project_points: Ncam %d outside 1..8", Ncam);
     VER_REQUIRE(B >= 0 && bev_z > 0 && bev_h > 0 && bev_w > 0, VER_EINVAL, "ver_project_points: bad grid");
@@ -1294,14 +1553,14 @@ extern "C" int ver_project_points(const float* world2pixel, const float* origin,
     int rc = ver_check_launch("ver_project_points/k_project");
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_lists, dim3(Ncam, B), dim3(256), 0, st, vis, Ncam, Nq, vis_list, vis_cnt,
-                       zero_list, zero_cnt);
+                       zero_list, zero_cnt, fwd_list, fwd_cnt);
     return ver_check_launch("ver_project_points/k_build_lists");
 }
 
 extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D, uint8_t* vis,
                                   int32_t* vis_list, int32_t* vis_cnt, int32_t* zero_list, int32_t* zero_cnt,
-                                  void* stream) {
-    VER_REQUIRE(bev_mask && vis && vis_list && vis_cnt && zero_list && zero_cnt, VER_EINVAL,
+                                  int32_t* fwd_list, int32_t* fwd_cnt, void* stream) {
+    VER_REQUIRE(bev_mask && vis && vis_list && vis_cnt && zero_list && zero_cnt && fwd_list && fwd_cnt, VER_EINVAL,
                 "ver_hits_from_mask: null pointer argument");
     VER_REQUIRE(Ncam >= 1 && Ncam <= 8, VER_EUNSUPPORTED, "ver_hits_from_mask: Ncam %d outside 1..8", Ncam);
     VER_REQUIRE(B >= 0 && Nq > 0 && D > 0, VER_EINVAL, "ver_hits_from_mask: bad sizes");
@@ -1311,19 +1570,21 @@ extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int 
     int rc = ver_check_launch("ver_hits_from_mask/k_mask_to_vis");
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_lists, dim3(Ncam, B), dim3(256), 0, st, vis, Ncam, Nq, vis_list, vis_cnt,
-                       zero_list, zero_cnt);
+                       zero_list, zero_cnt, fwd_list, fwd_cnt);
     return ver_check_launch("ver_hits_from_mask/k_build_lists");
 }
 
 extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
                                const float* uv, const uint8_t* vis, const int32_t* vis_list,
                                const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
+                               const int32_t* fwd_list, const int32_t* fwd_cnt,
                                float* slots, int B, int Ncam, int Nq, int D, int heads,
                                int head_dim, int points, int map_h, int map_w, void* stream) {
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
-    VER_REQUIRE(slots && zero_list && zero_cnt, VER_EINVAL, "ver_sca_forward: null pointer argument");
+    VER_REQUIRE(slots && zero_list && zero_cnt && fwd_list && fwd_cnt, VER_EINVAL,
+                "ver_sca_forward: null pointer argument");
     VER_REQUIRE((heads * head_dim) % 4 == 0, VER_EUNSUPPORTED, "ver_sca_forward: row width not a multiple of 4");
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
@@ -1378,31 +1639,60 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             return ver_check_launch("ver_sca_forward");
         };
         if constexpr (P == 8 && HD % 32 == 0) {
-            // bf16 tiles: 8 lanes per voxel (133 instead of 178 us at B = 64; with fp32 tiles the 16-lane kernel
-            // is the faster one, 145 vs 159 us). VER_SCA_FWD8=0 selects the 16-lane kernel here too.
-            static const int use8 = [] {
-                const char* e8 = getenv("VER_SCA_FWD8");
-                return e8 ? atoi(e8) : 1;
-            }();
-            if (use8 && value_dtype == VER_BF16) {
-                static const int t8 = [] {
-                    const char* et = getenv("VER_SCA_FWD8_THREADS");
-                    const int t = et ? atoi(et) : 256;
-                    return (t == 128 || t == 256 || t == 512) ? t : 256;
-                }();
-                const size_t per_cu = 16 * 64 / t8;                  // resident workgroups by registers (4 waves / SIMD)
-                const int nb8 = 2 * per_cu * tile_bytes <= kMaxLds ? 2 : 1;
-                const size_t lds8 = tile_bytes * nb8;
-                auto kern = k_sca_fwd8<HD, uint16_t>;
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-                if (e != hipSuccess)
-                    return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
-                const unsigned blocks = (unsigned)B * Ncam * hsplit * nchunks;
-                hipLaunchKernelGGL(kern, dim3(blocks), dim3(t8), lds8, st, (const uint16_t*)value, offsets, logits, uv,
-                                   vis, vis_list, vis_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks,
-                                   kFwdChunk, hsplit, nb8);
-                return ver_check_launch("ver_sca_forward");
+            // corner-slot kernel (fp32 and bf16 tiles); VER_SCA_FWD_CS=0 falls back to the generic 16-lane kernel.
+            // Launch shape = measured optima at the vocc size (scratch/r02/sweep_*.sh); the environment variables
+            // exist for scratch/bench_gather.py sweeps:
+            //   threads   256 (bf16 tiles: four single-tile workgroups per CU) / 512 (fp32 tiles: two per CU)
+            //   nload     0: every wave stages its share of the tile, one buffer; > 0: that many loader waves stream
+            //             tiles through two buffers for a workgroup that walks many tiles (measured slower here: one
+            //             16-wave workgroup per CU cannot hold more waves than four small ones, and its tiles split
+            //             into 4-5 pairs per wave with a second, nearly empty phase-A pass)
+            //   hsplit    heads are split over this many units (8: one head per unit)
+            //   units/wg  1: one unit per workgroup (0: as many as it takes to fill the CUs `wgs_per_cu` times)
+            static const int use_cs = env_int("VER_SCA_FWD_CS", 1);
+            const bool f32 = value_dtype == VER_F32;
+            static const int cs_threads_f32 = env_int("VER_SCA_CS_THREADS_F32", 512);
+            static const int cs_threads_bf16 = env_int("VER_SCA_CS_THREADS_BF16", 256);
+            static const int cs_nload = env_int("VER_SCA_CS_NLOAD", 0);
+            static const int cs_hsplit = env_int("VER_SCA_CS_HSPLIT", 8);
+            static const int cs_upw = env_int("VER_SCA_CS_UNITS_PER_WG", 1);
+            static const int cs_wgs_per_cu = env_int("VER_SCA_CS_WGS_PER_CU", 1);
+            int pt = f32 ? cs_threads_f32 : cs_threads_bf16;
+            if (pt != 256 && pt != 512 && pt != 1024) pt = f32 ? 512 : 256;
+            const int nlp = (cs_nload >= 0 && cs_nload < pt / 64) ? cs_nload : 0;
+            const size_t tb = (tile_bytes + 15) & ~(size_t)15;
+            const size_t ldsp = (nlp > 0 ? 2 : 1) * tb + (size_t)(pt / 64) * 512;
+            if (use_cs && ldsp <= kMaxLds) {
+                int hsp = 1;
+                while (hsp < cs_hsplit && hsp < heads && heads % (hsp * 2) == 0) hsp *= 2;
+                const int units = B * Ncam * nchunks * hsp;
+                int upw = cs_upw;
+                if (upw <= 0) {
+                    int dev = 0, cus = 256;
+                    if (hipGetDevice(&dev) == hipSuccess)
+                        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                    if (cus <= 0) cus = 256;
+                    const int slots_wg = cus * (cs_wgs_per_cu > 0 ? cs_wgs_per_cu : 1);
+                    upw = (units + slots_wg - 1) / slots_wg;
+                }
+                const int grid = (units + upw - 1) / upw;
+                auto launch_cs = [&](auto kern, auto vptr) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+                    if (e != hipSuccess)
+                        return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(pt), ldsp, st, vptr, offsets, logits, uv, vis, fwd_list,
+                                       fwd_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsp, units, upw,
+                                       nlp);
+                    return ver_check_launch("ver_sca_forward");
+                };
+                const bool k196 = map_h * map_w == 196;                // plane offsets become immediates
+                if (f32) {
+                    if (k196) return launch_cs(k_sca_fwd_cs<HD, float, 196>, (const float*)value);
+                    return launch_cs(k_sca_fwd_cs<HD, float, 0>, (const float*)value);
+                }
+                if (k196) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196>, (const uint16_t*)value);
+                return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0>, (const uint16_t*)value);
             }
         }
         if constexpr (HD % 8 == 0) {

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -156,7 +156,8 @@ MultiScaleDeformableAttnFunction_fp16 = MultiScaleDeformableAttnFunction_fp32
 class HitTable:
     """Per-batch visibility structure (layout: include/ver_ops.h, "Hit table")."""
 
-    __slots__ = ('uv', 'vis', 'vis_list', 'vis_cnt', 'zero_list', 'zero_cnt', 'B', 'Ncam', 'Nq', 'D')
+    __slots__ = ('uv', 'vis', 'vis_list', 'vis_cnt', 'zero_list', 'zero_cnt', 'fwd_list', 'fwd_cnt',
+                 'B', 'Ncam', 'Nq', 'D')
 
     def __init__(self, B, Ncam, Nq, D, device):
         self.B, self.Ncam, self.Nq, self.D = B, Ncam, Nq, D
@@ -166,6 +167,8 @@ class HitTable:
         self.vis_cnt = torch.empty(B, Ncam, dtype=torch.int32, device=device)
         self.zero_list = torch.empty(B, Nq, dtype=torch.int32, device=device)
         self.zero_cnt = torch.empty(B, dtype=torch.int32, device=device)
+        self.fwd_list = torch.empty(B, Ncam, Nq, dtype=torch.int32, device=device)
+        self.fwd_cnt = torch.empty(B, Ncam, 2, dtype=torch.int32, device=device)
 
     def mask(self):
         """bool [Ncam, B, Nq, 1] in the reference's bev_mask layout (for inspection/tests)."""
@@ -186,7 +189,7 @@ def project_points(world2pixel, origin, pc_range, bev_z, bev_h, bev_w, img_w=128
     _launch('ver_project_points', lambda: lib().ver_project_points(
         _p(w2p), _p(org), rng, B, ncam, bev_z, bev_h, bev_w, ctypes.c_float(img_w), ctypes.c_float(img_h),
         _p(hit.uv), _p(hit.vis), _p(hit.vis_list), _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt),
-        _stream()))
+        _p(hit.fwd_list), _p(hit.fwd_cnt), _stream()))
     return hit
 
 
@@ -198,7 +201,8 @@ def hits_from_mask(reference_points_cam, bev_mask):
     hit = HitTable(B, ncam, nq, D, mask.device)
     hit.uv.copy_(reference_points_cam.to(torch.float32).permute(1, 0, 2, 3, 4))
     _check(lib().ver_hits_from_mask(_p(mask), B, ncam, nq, D, _p(hit.vis), _p(hit.vis_list),
-                                    _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _stream()),
+                                    _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(hit.fwd_list),
+                                    _p(hit.fwd_cnt), _stream()),
            'ver_hits_from_mask')
     return hit
 
@@ -225,7 +229,8 @@ class SCAGatherFunction(Function):
         slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)
         _launch('ver_sca_forward', lambda: lib().ver_sca_forward(
             _p(value), vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
-            _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(slots), B, ncam, nq, hit.D, heads, hd,
+            _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(slots),
+            B, ncam, nq, hit.D, heads, hd,
             points, map_h, map_w, _stream()))
         ctx.save_for_backward(value, offsets, logits)
         ctx.hit, ctx.map_hw, ctx.vdt = hit, (map_h, map_w), vdt

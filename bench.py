@@ -107,6 +107,12 @@ def build_model(args, dev):
     head = pkg.registry.build_head(cfg)
     head.init_weights()
     if args.workload == 'vocc_full_train':
+        # add_layout is off in vocc.py: the layout branches / layout query embedding are built (state-dict parity
+        # with the reference) but never run, and DDP without find_unused_parameters stalls on parameters that get
+        # no gradient -- freeze them, like everything else the step does not touch
+        for k, p in head.named_parameters():
+            if k.startswith(('layout_branches.', 'query_layout_embedding.')):
+                p.requires_grad_(False)
         n_train = sum(p.numel() for p in head.parameters() if p.requires_grad)
         return pkg, syn, head.to(dev), n_train
     # the lifting path does not touch the detection decoder / branches: freeze them so that

@@ -139,8 +139,10 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  * input projections and output_proj (spatial_cross_attention.py:139-173 together with
  * MSDeformableAttention3D.forward :345-398): per-camera re-batching, softmax over the
  * points, location arithmetic, bilinear sampling, scatter-add over cameras and division by
- * the camera count -- without padded rows or host syncs (fp32 atomics only on the rows of
- * voxels seen by more than one camera).
+ * the camera count -- without padded rows or host syncs.  Rows of voxels seen by exactly one
+ * camera are plain stores; rows seen by several cameras are zero-filled first and accumulated
+ * with fp32 atomic adds, so the result is bitwise reproducible run to run as long as no voxel is
+ * seen by more than two cameras (with three or more the last bit depends on the add order).
  *
  *   value   f32|bf16 [B, Ncam, map_h*map_w, heads, head_dim]   value_proj output
  *   offsets f32 [B, Nq, heads, points, 2]     sampling_offsets output, in pixels (one level)

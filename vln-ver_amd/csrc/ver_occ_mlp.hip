@@ -505,13 +505,9 @@ extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float
     VER_REQUIRE(logits, VER_EINVAL, "ver_occ_mlp_forward: null logits pointer");
     constexpr int RT = 4;
     const size_t lds = (size_t)kFwdFrags * 1024 + kVecFloats * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_occ_mlp_fwd<RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    // (the attribute is per device: set it on every call, as ver_sca does -- it is a host-side table write)
+    hipError_t e = hipFuncSetAttribute((const void*)k_occ_mlp_fwd<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 16 * RT - 1) / (16 * RT);
     long grid = (nblk + 3) / 4;
     if (grid > 512) grid = 512;                            // 2 workgroups per CU, persistent
@@ -533,12 +529,8 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1, VER_EINVAL,
                 "ver_occ_mlp_backward: null pointer argument");
     const size_t lds = (size_t)kAllFrags * 1024 + kVecFloats * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: LDS attribute: %s", hipGetErrorString(e));
-        attr_done = true;
-    }
+    e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 15) / 16;
     long grid = (nblk + 3) / 4;
     if (grid > 256) grid = 256;                            // one 4-wave workgroup per CU (LDS bound), persistent

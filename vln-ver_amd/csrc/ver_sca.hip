@@ -7,18 +7,18 @@
 //   uv     [B, Ncam, Nq, D, 2]  vis [B, Nq]  lists [B, Ncam, Nq] + counts [B, Ncam]
 //   offsets/logits/slots are voxel-major: row (b, n) holds all heads.
 //
-// Forward kernel: one workgroup per (viewpoint, camera, head [, chunk of the camera's
-// owned-voxel list]).  The 14x14xHD value tile of that (camera, head) is staged once into
-// LDS with 16-byte coalesced loads (75 KB at HD=96 fp32 -> two workgroups per CU), then
-// aligned groups of G=16 lanes each take one voxel: every lane carries HD/G channels, walks
-// the 8 sampling points x 4 bilinear corners with ds_read_b64 and accumulates in registers.
-// A voxel's output row is produced by exactly one workgroup (the lowest camera that sees it),
-// which adds the other cameras' contributions straight from L2 -- so there are no atomics, no
-// zero-fill pass, no padded rows, and the result is run-to-run deterministic.
+// Forward (ver_sca_forward): k_zero_rows zero-fills the output rows of voxels NOT seen by exactly one camera,
+// then one workgroup per (viewpoint, camera, head [, list chunk]) stages the 14x14xHD value tile of its
+// (camera, head) into LDS by LDS-DMA and gathers from it (k_sca_fwd_cs for 8 points and head_dim % 32 == 0,
+// k_sca_fwd otherwise).  Rows of voxels seen by exactly one camera are written with plain stores; rows seen by
+// several cameras are accumulated with fp32 atomic adds on the zeroed rows, so the DETERMINISM CONTRACT is:
+// bitwise run-to-run reproducible as long as no voxel is seen by more than two cameras (two addends commute);
+// with three or more the last bit may vary with the order of the adds.  Voxels seen by no camera get exact zeros.
 //
-// Backward kernel: same tiling with a second LDS tile that accumulates d(value) through
-// ds_add_f32 and is flushed once; d(offsets), d(logits) are reduced over the G lanes with
-// wave shuffles, softmax backward fused.
+// Backward (ver_sca_backward): k_sca_bwd_off (d offsets, d logits; the forward's structure) + k_sca_bwd_val
+// (d value by a counting sort of the sampling events per tile row, no floating-point atomics in LDS); a single
+// LDS-atomic kernel (k_sca_bwd) remains for head_dim < 32.  d(value) may differ in the last bit run to run (the
+// order of a tile row's events inside the sort is not fixed), as the reference's CUDA backward does.
 #include <cstdlib>
 #include <type_traits>
 #include "ver_common.h"

@@ -53,7 +53,6 @@ def voxel_multi_scale_deformable_attn(value, value_spatial_shapes, sampling_loca
 class VoxelCustomMSDeformableAttention(BaseModule):
     """voxel_decoder.py:135-337 (sequence-first, with output_proj + dropout + identity)."""
 
-    _ver_deformable_init = True
 
     def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
                  dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None):

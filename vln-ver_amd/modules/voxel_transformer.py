@@ -61,7 +61,9 @@ class VoxelPerceptionTransformer(BaseModule):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
         for m in self.modules():
-            if isinstance(m, MSDeformableAttention3D) or hasattr(m, '_ver_deformable_init'):
+            # only these three classes are re-initialised by the reference (:107-114); the decoder's
+            # VoxelCustomMSDeformableAttention is a plain BaseModule there and keeps its xavier weights
+            if isinstance(m, MSDeformableAttention3D):
                 m.init_weights()
         nn.init.normal_(self.level_embeds)
         nn.init.normal_(self.cams_embeds)

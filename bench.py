@@ -126,38 +126,44 @@ def build_model(args, dev):
     return pkg, syn, head.to(dev), n_train
 
 
-def gather_algorithmic_bytes(hit_counts, B, ncam=6, nk=196, c=768, heads=8, points=8):
-    """per viewpoint and layer, forward = 6*196*768*4 + Sigma_n*(128+64+768)*4 B
-    (value once + loc + weights + output per visible (camera,voxel) pair);
-    backward = 2*value + Sigma_n*5376."""
+def gather_algorithmic_bytes(hit_counts, B, value_bytes, ncam=6, nk=196, c=768, heads=8, points=8):
+    """SURVEY.md 8(d) with `s` = the bytes per element of each operand AS THE KERNEL SEES IT: per viewpoint and
+    layer, forward = value once (6*196*768*s_v, s_v = 2 under bf16 autocast: value_proj emits bf16) +
+    Sigma_n*(128 + 64 + 768)*4 (offsets, logits and the output row of every visible (camera, voxel) pair are fp32);
+    backward = value read (s_v) + d(value) written (fp32) + Sigma_n*(768 + 2*192 + 192)*4.
+    (Round 1 priced the bf16 value tensor at 4 B/element: its 0.48 was 0.36 by this rule.)"""
     sn = float(hit_counts)
-    fwd = B * ncam * nk * c * 4 + sn * (heads * points * 2 + heads * points + c) * 4
-    bwd = 2 * B * ncam * nk * c * 4 + sn * 5376
+    nval = B * ncam * nk * c
+    fwd = nval * value_bytes + sn * (heads * points * 2 + heads * points + c) * 4
+    bwd = nval * (value_bytes + 4) + sn * 5376
     return fwd, bwd
 
 
-def measured_traffic_per_viewpoint(kernel, dtype='fp32'):
-    """HBM bytes per viewpoint and launch from the committed rocprofv3 PMC passes
-    (profiles/*_gather_microbench_pmc_fetch_write.csv: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`,
-    separate runs of scratch/bench_gather.py at 64 viewpoints per launch).  Units are KiB;
-    FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md
-    section HBM), so this is an upper bound on the read side."""
+def measured_traffic(kernels, B):
+    """HBM bytes per launch of the gather kernels from the committed rocprofv3 PMC passes of THIS command
+    (profiles/rNN_bench_pmc_fetch_write.csv: `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py ...` and
+    the same with WRITE_SIZE, separate runs, scratch/r02/run_bench_profiles.sh).  Units are KiB per dispatch;
+    FETCH_SIZE is doubled (on gfx950 it reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM;
+    the value tiles arrive as 16-byte-per-lane LDS-DMA), WRITE_SIZE is taken as reported (calibrated on
+    k_zero_rows, whose byte count is known: profiles/README.md).  Only used when the profile was taken at the
+    same number of viewpoints per launch."""
     import csv
     import glob
-    files = []
-    if dtype == 'bf16':                     # bf16 value tiles run another forward kernel (k_sca_fwd8)
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_bf16_pmc_fetch_write.csv')))
-    if not files:
-        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_gather_microbench_pmc_fetch_write.csv')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_pmc_fetch_write.csv')))
     if not files:
         return None, None
-    vals = {}
+    vals, batch = {}, None
+    for line in open(files[-1]):
+        if line.startswith('# viewpoints_per_launch'):
+            batch = int(line.split('=')[1])
+    if batch != B:
+        return None, None
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith('#')):
-        if len(row) == 4 and kernel in row[0] and row[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
-            vals[row[1]] = vals.get(row[1], 0.0) + float(row[2])      # backward = two kernels
+        if len(row) == 4 and any(k in row[0] for k in kernels) and row[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
+            vals[row[1]] = vals.get(row[1], 0.0) + float(row[2])          # several kernels of one launch add up
     if len(vals) != 2:
         return None, None
-    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0 / 64.0, os.path.basename(files[-1])
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, os.path.basename(files[-1])
 
 
 def cpu_baseline(head, syn, seconds):
@@ -278,18 +284,20 @@ def main():
         kt = timer.summary()
         hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
         sigma_n = int(hit.vis_cnt.sum())
-        fwd_b, bwd_b = gather_algorithmic_bytes(sigma_n, B)
+        vbytes = 2 if args.dtype == 'bf16' else 4          # value_proj emits bf16 under autocast
+        fwd_b, bwd_b = gather_algorithmic_bytes(sigma_n, B, vbytes)
         roof, others = None, []
-        for name, byts in (('ver_sca_forward', fwd_b), ('ver_sca_backward', bwd_b)):
+        for name, byts, kernels in (('ver_sca_forward', fwd_b, ('k_sca_fwd', 'k_zero_rows')),
+                                    ('ver_sca_backward', bwd_b, ('k_sca_bwd',))):
             if name in kt and kt[name]['count']:
                 avg_ms = kt[name]['ms'] / kt[name]['count']
                 ach = byts / (avg_ms * 1e-3) / 1e9
-                tpv, src = measured_traffic_per_viewpoint('k_sca_fwd' if name == 'ver_sca_forward' else 'k_sca_bwd', args.dtype)
+                traffic, src = measured_traffic(kernels, B)
                 obj = dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                           frac=round(ach / HBM_PEAK_GBS, 4), traffic=int(tpv * B) if tpv else None,
+                           frac=round(ach / HBM_PEAK_GBS, 4), traffic=int(traffic) if traffic else None,
                            traffic_source=src, avg_launch_us=round(avg_ms * 1e3, 2),
                            launches=kt[name]['count'], algorithmic_bytes_per_launch=int(byts),
-                           viewpoints_per_launch=B, sigma_n=sigma_n)
+                           value_bytes_per_element=vbytes, viewpoints_per_launch=B, sigma_n=sigma_n)
                 if name == 'ver_sca_forward':
                     roof = obj
                 else:

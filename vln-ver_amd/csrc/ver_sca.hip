@@ -721,7 +721,12 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int heads_per = heads / hsplit;
     const size_t rstride = (size_t)heads * HD;
-    const int u0 = blockIdx.x * units_per_wg, u1 = min(u0 + units_per_wg, units_total);
+    // XCD-aware placement: workgroup b runs on XCD b % 8 and every XCD has its own L2, so the grid is dealt to the
+    // XCDs in contiguous blocks -- the heads of one (viewpoint, camera) share its voxel lists, visibility, uv and the
+    // 128-byte lines of the offsets / logits / value rows, and now meet them in ONE L2 instead of eight.
+    const int wg_per_xcd = (int)(gridDim.x >> 3);                 // the grid is a multiple of 8
+    const int wg = (int)(blockIdx.x & 7) * wg_per_xcd + (int)(blockIdx.x >> 3);
+    const int u0 = wg * units_per_wg, u1 = min(u0 + units_per_wg, units_total);
     const int ntiles = (u1 - u0) * heads_per;
     if (ntiles <= 0) return;
     VER_TL(0);
@@ -829,15 +834,22 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 if (ti) __syncthreads();              // everyone is done with the previous tile
                 stage(ti);
             }
+            // per-tile WAVE-UNIFORM base pointers; a lane's address is base + 32-bit byte offset (one 24-bit multiply-add),
+            // which the memory instructions take as SGPR base + VGPR offset -- no 64-bit VALU arithmetic per access
+            const char* lg_base = reinterpret_cast<const char*>(logits + ((size_t)b * Nq * heads + h) * P);
+            const char* of_base = reinterpret_cast<const char*>(offs + ((size_t)b * Nq * heads + h) * P * 2);
+            const char* uv_base = reinterpret_cast<const char*>(uv + ((size_t)b * Ncam + c) * Nq * D * 2);
+            const uint8_t* vis_base = vis + (size_t)b * Nq;
+            char* out_base = reinterpret_cast<char*>(slots + ((size_t)b * Nq * heads + h) * HD);
+            const unsigned hp4 = (unsigned)(heads * P * 4), hhd4 = (unsigned)(heads * HD * 4), d8 = (unsigned)(D * 8);
             auto load_sample = [&](int n) -> Sample {
                 Sample sm;
-                const int nn = n < 0 ? -n - 1 : n;
-                const size_t qh = ((size_t)b * Nq + nn) * heads + h;
-                const unsigned mv = (unsigned)vis[(size_t)b * Nq + nn];
+                const unsigned nn = (unsigned)(n < 0 ? -n - 1 : n);          // < 2^24 voxels (checked by the host wrapper)
+                const unsigned mv = (unsigned)vis_base[nn];
                 sm.m = n < 0 ? 0u : mv;
-                sm.lg = logits[qh * P + l8];
-                sm.of = *reinterpret_cast<const float2*>(offs + (qh * P + l8) * 2);
-                sm.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + nn) * D + ad) * 2);
+                sm.lg = *reinterpret_cast<const float*>(lg_base + (__umul24(nn, hp4) + (unsigned)l8 * 4u));
+                sm.of = *reinterpret_cast<const float2*>(of_base + (__umul24(nn, hp4) * 2u + (unsigned)l8 * 8u));
+                sm.u = *reinterpret_cast<const float2*>(uv_base + (__umul24(nn, d8) + (unsigned)ad * 8u));
                 return sm;
             };
             int n0 = un0, n1 = un1, n2 = un2;
@@ -926,28 +938,26 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     auto tile_ld = [&](unsigned addr) -> tv_t {
                         return *(const volatile __attribute__((address_space(3))) tv_t*)(uintptr_t)addr;
                     };
-                    tv_t tnx[NV];
+                    tv_t tb[2][NV];                                // two buffers by point parity: no register copies
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) tnx[i] = tile_ld(rec_a(0) + (unsigned)i * plane);
+                    for (int i = 0; i < NV; ++i) tb[0][i] = tile_ld(rec_a(0) + (unsigned)i * plane);
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) {
                         if (pt >= npts) break;                     // wave-uniform: the pair has no more live samples
                         const float wb = rec_w(pt);
-                        tv_t tc[NV];
-#pragma unroll
-                        for (int i = 0; i < NV; ++i) tc[i] = tnx[i];
                         if (pt + 1 < P) {
 #pragma unroll
-                            for (int i = 0; i < NV; ++i) tnx[i] = tile_ld(rec_a(pt + 1) + (unsigned)i * plane);
+                            for (int i = 0; i < NV; ++i) tb[(pt + 1) & 1][i] = tile_ld(rec_a(pt + 1) + (unsigned)i * plane);
                         }
 #pragma unroll
                         for (int i = 0; i < NV; ++i) {
+                            const tv_t tc = tb[pt & 1][i];
                             float v[4];
                             if constexpr (F32) {
-                                v[0] = tc[i].x; v[1] = tc[i].y; v[2] = tc[i].z; v[3] = tc[i].w;
+                                v[0] = tc.x; v[1] = tc.y; v[2] = tc.z; v[3] = tc.w;
                             } else {
-                                v[0] = __uint_as_float(tc[i].x << 16); v[1] = __uint_as_float(tc[i].x & 0xffff0000u);
-                                v[2] = __uint_as_float(tc[i].y << 16); v[3] = __uint_as_float(tc[i].y & 0xffff0000u);
+                                v[0] = __uint_as_float(tc.x << 16); v[1] = __uint_as_float(tc.x & 0xffff0000u);
+                                v[2] = __uint_as_float(tc.y << 16); v[3] = __uint_as_float(tc.y & 0xffff0000u);
                             }
 #pragma unroll
                             for (int q = 0; q < 4; ++q) acc[i * 4 + q] = __builtin_fmaf(wb, v[q], acc[i * 4 + q]);
@@ -972,12 +982,14 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     for (int i = 0; i < 2 * NV; ++i) out[i] += dpp_mov<0x128>(out[i]);      // row_ror:8
                     const int na = __builtin_amdgcn_readlane(n0, 16 * j), nb = __builtin_amdgcn_readlane(n0, 16 * j + 8);
                     const int n = half ? nb : na;
-                    const size_t rowoff =
-                        ((size_t)b * Nq + (n < 0 ? -n - 1 : n)) * heads * HD + (size_t)h * HD + l8 * 4 + rho * 2;
+                    const unsigned rowoff = __umul24((unsigned)(n < 0 ? -n - 1 : n), hhd4) + (unsigned)(l8 * 4 + rho * 2) * 4u;
+                    float* live_row = reinterpret_cast<float*>(out_base + rowoff);
+                    // the only dead voxel of the plain-store region is the pad entry of an odd single count: last pair
+                    const bool has_pad = !atomic && (s_n & 1) && p_lo + 4 * it + j == s_pairs - 1;     // wave-uniform
                     if (!atomic) {
-                        // both slots of a row hold the sums and share the stores; a dead voxel (pad of an odd count)
-                        // writes to the dummy row
-                        float* row = n >= 0 ? slots + rowoff : g_sca_dummy_row + (blockIdx.x & 255) * 256 + l8 * 4 + rho * 2;
+                        // both slots of a row hold the sums and share the stores
+                        float* row = live_row;
+                        if (has_pad && n < 0) row = g_sca_dummy_row + (blockIdx.x & 255) * 256 + l8 * 4 + rho * 2;
 #pragma unroll
                         for (int kk = 0; kk < (NV + 1) / 2; ++kk) {
                             float o2[2];
@@ -996,7 +1008,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                             store_vec<2, true>(dst, o2);
                         }
                     } else {
-                        float* row = slots + rowoff;               // dead voxel (odd tail): adds zeros to a live shared row
+                        float* row = live_row;                     // dead voxel (odd tail): adds zeros to a live shared row
 #pragma unroll
                         for (int i = 0; i < NV; ++i) {
                             float a0 = out[2 * i], b0 = out[2 * i + 1];
@@ -1585,6 +1597,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     if (rc) return rc;
     VER_REQUIRE(slots && zero_list && zero_cnt && fwd_list && fwd_cnt, VER_EINVAL,
                 "ver_sca_forward: null pointer argument");
+    VER_REQUIRE(Nq < (1 << 24), VER_EUNSUPPORTED, "ver_sca_forward: more than 2^24 voxels per viewpoint");
     VER_REQUIRE((heads * head_dim) % 4 == 0, VER_EUNSUPPORTED, "ver_sca_forward: row width not a multiple of 4");
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
@@ -1675,7 +1688,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                     const int slots_wg = cus * (cs_wgs_per_cu > 0 ? cs_wgs_per_cu : 1);
                     upw = (units + slots_wg - 1) / slots_wg;
                 }
-                const int grid = (units + upw - 1) / upw;
+                const int grid = ((units + upw - 1) / upw + 7) & ~7;     // multiple of 8: dealt to the XCDs in blocks
                 auto launch_cs = [&](auto kern, auto vptr) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);

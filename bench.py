@@ -113,6 +113,8 @@ def build_model(args, dev):
         for k, p in head.named_parameters():
             if k.startswith(('layout_branches.', 'query_layout_embedding.')):
                 p.requires_grad_(False)
+        # (main() additionally freezes whatever a probing step leaves without a gradient, e.g. the positional
+        # encoding the reference computes but never adds in this encoder: SURVEY.md section 0.6)
         n_train = sum(p.numel() for p in head.parameters() if p.requires_grad)
         return pkg, syn, head.to(dev), n_train
     # the lifting path does not touch the detection decoder / branches: freeze them so that
@@ -221,7 +223,8 @@ def main():
     model = (FullTrainer(head, args.dtype) if full else LiftTrainer(head, args.micro, args.dtype)).to(dev)
     model.train(train)
     ddp = model                                 # train(): dropout ON, as in the reference's step
-    if world > 1 and train:
+    probe_unused = train and full               # the full head has parameters its forward never touches
+    if world > 1 and train and not probe_unused:
         ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev,
                                                                   bf16_gradients=args.backend == 'nccl')
     params = [p for p in model.parameters() if p.requires_grad]
@@ -253,6 +256,22 @@ def main():
             out = [head.occupancy_from_volume(emb[s:s + args.micro]) for s in range(0, B, args.micro)]
             return out[-1].float().mean()
 
+    if probe_unused:
+        # One un-wrapped probing step: parameters that end it without a gradient are not part of this workload's
+        # graph (the reference pays find_unused_parameters=True for them, apis/mmdet_train.py:73); freeze them so
+        # that DDP reduces -- and AdamW updates -- exactly what the step trains.
+        loss = model(feats[:, :2], w2p[:2], org[:2], gt[:2], gt_boxes[:2], gt_labels[:2])
+        loss.backward()
+        for prm in model.parameters():
+            if prm.requires_grad and prm.grad is None:
+                prm.requires_grad_(False)
+            prm.grad = None
+        params = [prm for prm in model.parameters() if prm.requires_grad]
+        n_train = sum(prm.numel() for prm in params)
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        if world > 1:
+            ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev,
+                                                                      bf16_gradients=args.backend == 'nccl')
     # Setup: two untimed priming steps.  The first step allocates ~55 GiB through hipMalloc and creates
     # the AdamW state, so the caching allocator still grows during the second; with them here the W
     # warm-up steps the caller asks for (even W = 0) are not spent on one-time allocator / library work.

@@ -3,6 +3,9 @@ golden vectors.  Needs an MI355X: run with ``-m gpu``.
 
 Tolerances: forward 1e-4 absolute (north_star, fp32); gradients |a-b| <= 1e-4 + 1e-5*|b|
 (values reach O(100)); visibility masks / index lists bit-exact."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -249,6 +252,79 @@ def test_sca_gather_bf16_value(heads, hd, P, grid):
     assert close(of.grad.cpu(), oc.grad)
     assert close(lg.grad.cpu(), lc.grad)
     assert close(vb.grad.float().cpu(), vc.grad, atol=2e-2, rtol=1e-2)      # grad rounded to bf16
+
+
+def test_forward_work_lists_partition_the_visible_voxels():
+    """fwd_list / fwd_cnt (the forward kernel's work order): per camera the voxels only it sees from the front, the
+    voxels it shares with other cameras from the back; together exactly vis_list."""
+    hip = pkg('hipops')
+    rng = np.random.default_rng(3)
+    B, nq = 2, 77
+    mask = rng.uniform(size=(6, B, nq, 1)) < 0.3
+    mask[:, :, :3] = True                                             # voxels seen by every camera but the blind one
+    mask[4] = False                                                   # a camera that sees nothing
+    hit = hip.hits_from_mask(torch.zeros(6, B, nq, 1, 2, device=DEV), T(mask).to(DEV))
+    vis = hit.vis.cpu().numpy()
+    for b in range(B):
+        for c in range(6):
+            n_single, n_multi = hit.fwd_cnt[b, c].cpu().tolist()
+            assert n_single + n_multi == int(hit.vis_cnt[b, c])
+            lst = hit.fwd_list[b, c].cpu().numpy()
+            single, multi = lst[:n_single], lst[nq - n_multi:][::-1]
+            seen = np.nonzero((vis[b] >> c) & 1)[0]
+            pop = np.array([bin(int(v)).count('1') for v in vis[b]])
+            assert np.array_equal(single, seen[pop[seen] == 1])       # ascending
+            assert np.array_equal(multi, seen[pop[seen] > 1])
+    assert hit.fwd_cnt[:, 4].abs().sum().item() == 0
+
+
+def test_sca_gather_samples_outside_the_map():
+    """The forward compacts the samples whose footprint misses the map: the reference's initial ring of offsets (40 %
+    outside), offsets that throw EVERY sample out (visible voxels must come out as exact zeros), and a single live
+    sample per voxel."""
+    hip = pkg('hipops')
+    o = oracle()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sca_modes_helper as H
+    _, hit, value, offsets, logits = H.case(6, 2, (4, 15, 15), 8, 96, True)
+    mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()
+    for vt in (value, value.bfloat16()):
+        got = hip.sca_gather(vt, offsets, logits, hit, 14, 14)
+        ref = oracle_slots(o, vt.float().cpu(), offsets.cpu(), logits.cpu(), hit.uv.cpu(), mask, (14, 14))
+        assert maxdiff(got.cpu(), ref) < 2e-5
+        far = hip.sca_gather(vt, offsets + 40.0, logits, hit, 14, 14)
+        assert float(far.abs().max()) == 0.0
+        one = offsets + 40.0
+        one[:, :, :, 3] = offsets[:, :, :, 3] * 0.25                   # only point 3 can land inside
+        got1 = hip.sca_gather(vt, one, logits, hit, 14, 14)
+        ref1 = oracle_slots(o, vt.float().cpu(), one.cpu(), logits.cpu(), hit.uv.cpu(), mask, (14, 14))
+        assert maxdiff(got1.cpu(), ref1) < 2e-5
+
+
+def test_sca_gather_launch_modes(tmp_path):
+    """The other launch shapes of ver_sca_forward -- persistent workgroups with loader waves, several units per
+    workgroup, the generic 16-lane kernel -- give the default shape's result (the environment is read once per
+    process: each mode runs in its own interpreter)."""
+    import subprocess
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sca_modes_helper.py')
+    modes = {
+        'default': {},
+        'generic': {'VER_SCA_FWD_CS': '0'},
+        'loaders': {'VER_SCA_CS_NLOAD': '1', 'VER_SCA_CS_THREADS_BF16': '1024', 'VER_SCA_CS_THREADS_F32': '1024',
+                    'VER_SCA_CS_HSPLIT': '2', 'VER_SCA_CS_UNITS_PER_WG': '0'},
+        'loaders2': {'VER_SCA_CS_NLOAD': '2', 'VER_SCA_CS_THREADS_BF16': '512', 'VER_SCA_CS_THREADS_F32': '1024',
+                     'VER_SCA_CS_HSPLIT': '1', 'VER_SCA_CS_UNITS_PER_WG': '3'},
+        'multi_unit': {'VER_SCA_CS_HSPLIT': '4', 'VER_SCA_CS_UNITS_PER_WG': '5', 'VER_SCA_CS_THREADS_BF16': '512'},
+    }
+    res = {}
+    for name, env in modes.items():
+        out = str(tmp_path / (name + '.npz'))
+        subprocess.run([sys.executable, helper, out], check=True, env=dict(os.environ, **env), timeout=600)
+        res[name] = np.load(out)
+    for name in modes:
+        for key in res['default'].files:
+            d = float(np.abs(res[name][key] - res['default'][key]).max())
+            assert d < 2e-5, (name, key, d)
 
 
 def test_sca_gather_multi_camera_and_anchors():

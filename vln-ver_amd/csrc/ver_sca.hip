@@ -339,23 +339,9 @@ __device__ __forceinline__ void stage_wait() {
 #endif
 constexpr int kFwdLoaders = VER_FWD_LOADERS;   // 0: every wave issues its share of the next tile's LDS-DMA
 
-#ifdef VER_DEBUG_TIMING
-__device__ long long g_dbg[256];
-#define VER_STAMP(slot, cond)                                                       \
-    do {                                                                            \
-        if ((cond) && blockIdx.x == VER_DEBUG_BLOCK && (threadIdx.x & 63) == 0)     \
-            g_dbg[slot] = (long long)__builtin_amdgcn_s_memtime();                  \
-    } while (0)
-extern "C" int ver_debug_read(long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), n * sizeof(long long));
-}
-#else
-#define VER_STAMP(slot, cond) \
-    do {                      \
-    } while (0)
-#endif
 #ifdef VER_DEBUG_TIMELINE
-// timeline of a few probe workgroups of k_sca_fwd_q: g_tl[probe][wave][event] = s_memtime
+// timeline of four probe workgroups of k_sca_fwd_cs (scratch/r02/timeline_p.py; build with -DVER_DEBUG_TIMELINE):
+// g_tl[probe][wave][event] = s_memtime
 __device__ long long g_tl[4 * 16 * 64];
 __device__ __forceinline__ int tl_probe() {
     const int nb = gridDim.x;
@@ -505,9 +491,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
     const int* list = vis_list + ((size_t)b * Ncam + c) * Nq;
     const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
 
-    VER_STAMP(0, wave == 0);
     if (issues_dma && nbuf == 2) stage_tile<HD, VT>(tiles, vown + (size_t)h0 * HD, rstride, Nk, dma_wave, kDmaWaves);
-    VER_STAMP(1, loader);
 
     for (int hh = 0; hh < heads_per; ++hh) {
         const int h = h0 + hh;
@@ -518,10 +502,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
             if (issues_dma) stage_tile<HD, VT>(tile, vown + (size_t)h * HD, rstride, Nk, dma_wave, kDmaWaves);
         }
         if (issues_dma) __builtin_amdgcn_s_waitcnt(0);    // this wave's share of the head's tile has landed
-        VER_STAMP(8 + hh * 8 + 0, loader);
-        VER_STAMP(8 + hh * 8 + 1, wave == 0);
         __syncthreads();
-        VER_STAMP(8 + hh * 8 + 2, wave == 0);
         if (issues_dma && nbuf == 2 && hh + 1 < heads_per)
             stage_tile<HD, VT>(tiles + (cur ^ 1) * tile_elems, vown + (size_t)(h + 1) * HD, rstride, Nk, dma_wave,
                                kDmaWaves);
@@ -562,7 +543,6 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
             int n_cur = load_id(base0);
             int n_nxt = load_id(base0 + STEP);
             Sample s_cur = load_sample(n_cur);
-            VER_STAMP(8 + hh * 8 + 3, wave == 0);
 
             for (int base = base0; base < end; base += STEP) {
                 const Sample s_nxt = load_sample(n_nxt);
@@ -607,7 +587,6 @@ __global__ __launch_bounds__(kFwdThreads) void k_sca_fwd(
                 n_nxt = n_nxt2;
                 s_cur = s_nxt;
             }
-            VER_STAMP(8 + hh * 8 + 4, wave == 0);
         } else {
             // narrow heads (HD < 32, test sizes): plain per-lane path, G lanes per voxel
             constexpr int VPW = VER_WAVE / G;

@@ -9,5 +9,5 @@ export PYTORCH_TUNABLEOP_ENABLED=1
 export PYTORCH_TUNABLEOP_FILENAME=$GRAFT_REPO_ROOT/gpurun_out/tunableop_next.csv
 export PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=15
 export PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS=5
-PYTORCH_TUNABLEOP_TUNING=1 timeout 1200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tuned-gemms > gpurun_out/tune.json 2> gpurun_out/tune.err; echo "tune $?"
+PYTORCH_TUNABLEOP_TUNING=1 timeout 2400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-tuned-gemms ${BENCH_ARGS:-} > gpurun_out/tune.json 2> gpurun_out/tune.err; echo "tune $?"
 wc -l vln-ver_amd/tuning/tunableop_gfx950_vocc.csv gpurun_out/tunableop_next*.csv; cut -c1-120 gpurun_out/tune.json; tail -2 gpurun_out/tune.err

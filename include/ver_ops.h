@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 14
+#define VER_ABI_VERSION 15
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -171,7 +171,8 @@ int ver_sca_forward(const void* value, int value_dtype, const float* offsets, co
  */
 int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                      const float* uv, const uint8_t* vis, const int32_t* vis_list,
-                     const int32_t* vis_cnt, const float* grad_slots,
+                     const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
+                     const float* grad_slots,
                      float* grad_value, float* grad_offsets, float* grad_logits,
                      int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                      int map_h, int map_w, void* stream);

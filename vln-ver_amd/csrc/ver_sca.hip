@@ -1473,6 +1473,267 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward on the matrix cores (bf16 value tiles, 8 points, head_dim % 32 == 0): d(offsets), d(logits) AND d(value)
+// in one kernel.  Unlike the forward, the backward has dense structure to give the MFMA units:
+//   * every d(offset) / d(logit) is a combination of dots <g[v], V[k]> between a voxel's grad row and a tile row.
+//     D^T = V x G^T for ALL (tile row k, voxel v) pairs of a 32-voxel chunk is 13 x 2 x 3 MFMA tiles x 2 (G split
+//     into bf16 hi + lo); a sampling point then just picks its four dots.  6.5x more dots than needed, and still
+//     a fraction of what the per-corner dot products cost on the VALU (12 FMAs + 12 unpacks + a 16-lane reduction
+//     per corner row);
+//   * d(value) = S^T x G is a true reduction over voxels (S[v][k] = softmax weight x bilinear weight of every
+//     sample of voxel v that touches row k): the 4 x 8 x 32 events of a chunk are added into a dense fp32
+//     S^T[k][v] in LDS (ds_add_f32 resolves two samples on one row), which then feeds 13 x 6 MFMA tiles x 3
+//     (S and G each split hi + lo, lo x lo dropped: 16 mantissa bits in both factors).
+// One workgroup (4 waves) per (viewpoint, camera, head): the tile is staged once by LDS-DMA, the camera's voxels
+// are walked in chunks of 32 in the forward's work order (only-this-camera voxels padded to a multiple of 8, then the
+// shared ones: a wave's 8 voxels are all plain stores or all atomics), a thread = (voxel, sampling point) in the
+// scalar phases.  G is read once, nothing is sorted, and there are no floating-point atomics on global memory
+// except for voxels seen by several cameras.
+typedef __bf16 mm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short mm_s16x4 __attribute__((ext_vector_type(4)));
+typedef short mm_s16x8 __attribute__((ext_vector_type(8)));
+constexpr int kMmDss = 36;            // floats per row of the D / S^T buffer [tile row][32 voxels + pad]: rows 4 banks apart
+
+__device__ __forceinline__ void mm_split(const float (&f)[8], mm_bf16x8& hi, mm_bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+
+template <int HD, int NKT>
+__global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
+    const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
+    const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, float* __restrict__ gvalue, float* goffs,
+    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int P = 8, NT = HD / 16, KS = HD / 32;
+    static_assert(HD % 32 == 0, "k-steps of 32 channels");
+    const int Nk = NKT ? NKT : mh * mw;
+    const int MT = (Nk + 15) >> 4;                    // tile-row tiles of 16 (the last one reads past the tile: see below)
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);                                   // [Nk][HD] bf16
+    float* DS = reinterpret_cast<float*>(smem + (((size_t)Nk * HD * 2 + 15) & ~(size_t)15));   // [Nk][kMmDss] fp32
+    uint16_t* Gh = reinterpret_cast<uint16_t*>(DS + (size_t)Nk * kMmDss);                  // [32][HD] bf16 hi
+    uint16_t* Gl = Gh + 32 * HD;                                                           // [32][HD] bf16 lo
+    // (rows Nk .. 16 MT - 1 of the last tile-row tile are read from whatever follows the tile / DS in LDS: they only
+    //  feed D rows that are never stored and d(value) rows that are never written; the host wrapper checks the slack)
+    int bid = blockIdx.x;
+    const int h = bid % heads;
+    bid /= heads;
+    const int c = bid % Ncam, b = bid / Ncam;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cc = lane & 15, g = lane >> 4;
+    const int vloc = tid >> 3, p = tid & 7;           // scalar phases: voxel of the chunk, sampling point
+    const int ad = (D == 1) ? 0 : (p % D);
+    const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
+    const size_t rstride = (size_t)heads * HD;
+    const int n_single = fwd_cnt[(b * Ncam + c) * 2], n_multi = fwd_cnt[(b * Ncam + c) * 2 + 1];
+    const int s8 = (n_single + 7) & ~7;               // a wave's 8 voxels never straddle the two regions
+    const int total = s8 + n_multi;
+    const int* list = fwd_list + ((size_t)b * Ncam + c) * Nq;
+
+    stage_tile<HD, uint16_t>(tile, value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD, rstride, Nk, wave, 4);
+
+    const f32x4_t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4_t acc[4][NT];                               // d(value): tile-row tiles wave, wave + 4, ...; lane (channel cc, rows 4g..4g+3)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = zero4;
+
+    // operands of this thread's (voxel, point) and its share of the voxel's grad row, software pipelined over the
+    // chunks: voxel ids two chunks ahead, everything that hangs off the id one chunk ahead (a chunk is ~2 us of work;
+    // without this every chunk started with two dependent global-memory latencies)
+    constexpr int SEG = HD / 8;                        // floats of the grad row this thread converts (12)
+    struct Ops {
+        unsigned m;
+        float lg;
+        float2 of, u;
+        float gf[SEG];
+    };
+    auto entry_of = [&](int e0, bool& live, bool& multi) -> int {     // voxel id (clamped to a live one), flags
+        const int e = e0 + vloc;
+        multi = e >= s8;
+        const int idx = multi ? e - s8 : e;
+        const int lim = multi ? n_multi : n_single;
+        live = e < total && idx < lim;
+        const int pos = multi ? Nq - 1 - min(idx, max(lim - 1, 0)) : min(idx, max(lim - 1, 0));
+        return lim > 0 ? list[pos] : 0;                // (an empty region's slots of the list are uninitialised)
+    };
+    auto load_ops = [&](int n) -> Ops {
+        Ops o;
+        const size_t qh = ((size_t)b * Nq + n) * heads + h;
+        o.m = (unsigned)vis[(size_t)b * Nq + n];
+        o.lg = logits[qh * P + p];
+        o.of = *reinterpret_cast<const float2*>(offs + (qh * P + p) * 2);
+        o.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + ad) * 2);
+        const float* grow = gslots + qh * HD + p * SEG;
+#pragma unroll
+        for (int i = 0; i < SEG / 4; ++i) {
+            const float4 t4 = *reinterpret_cast<const float4*>(grow + 4 * i);
+            o.gf[4 * i] = t4.x; o.gf[4 * i + 1] = t4.y; o.gf[4 * i + 2] = t4.z; o.gf[4 * i + 3] = t4.w;
+        }
+        return o;
+    };
+    bool live_c = false, multi_c = false, live_n = false, multi_n = false;
+    int n_c = total > 0 ? entry_of(0, live_c, multi_c) : 0;
+    int n_n = total > 32 ? entry_of(32, live_n, multi_n) : 0;
+    Ops ops = {};
+    if (total > 0) ops = load_ops(n_c);
+    for (int e0 = 0; e0 < total; e0 += 32) {
+        const bool live = live_c, multi = multi_c;     // multi is wave-uniform
+        const int n = n_c;
+        const unsigned m = live ? ops.m : 0u;
+        const float icnt = m ? 1.0f / (float)__popc(m) : 0.0f;
+        const size_t qh = ((size_t)b * Nq + n) * heads + h;
+        const float lg = ops.lg;
+        const float2 of = ops.of, u = ops.u;
+        {
+            uint16_t* gh = Gh + vloc * HD + p * SEG;
+            uint16_t* gl = Gl + vloc * HD + p * SEG;
+#pragma unroll
+            for (int i = 0; i < SEG / 4; ++i) {
+                __bf16 hi[4], lo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gs = ops.gf[4 * i + j] * icnt;
+                    hi[j] = (__bf16)gs;
+                    lo[j] = (__bf16)(gs - (float)hi[j]);
+                }
+                *reinterpret_cast<uint2*>(gh + 4 * i) = *reinterpret_cast<const uint2*>(hi);
+                *reinterpret_cast<uint2*>(gl + 4 * i) = *reinterpret_cast<const uint2*>(lo);
+            }
+        }
+        // next chunk's operands and the id after that: in flight during the rest of this chunk
+        n_c = n_n;
+        live_c = live_n;
+        multi_c = multi_n;
+        if (e0 + 32 < total) ops = load_ops(n_c);
+        if (e0 + 64 < total) n_n = entry_of(e0 + 64, live_n, multi_n);
+        if (e0 == 0) __builtin_amdgcn_s_waitcnt(0);   // the tile's LDS-DMA has landed
+        __syncthreads();
+        // ---------------- D^T[k][v] = sum_ch V[k][ch] G[v][ch]   (A = tile rows, B = grad rows, both row-major in LDS)
+        for (int mi = 0; mi < 4; ++mi) {
+            const int mt = wave + 4 * mi;
+            if (mt >= MT) break;
+            f32x4_t d[2] = {zero4, zero4};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const mm_bf16x8 a = *reinterpret_cast<const mm_bf16x8*>(tile + (size_t)(mt * 16 + cc) * HD + ks * 32 + 8 * g);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const mm_bf16x8 bh = *reinterpret_cast<const mm_bf16x8*>(Gh + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
+                    const mm_bf16x8 bl = *reinterpret_cast<const mm_bf16x8*>(Gl + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
+                    d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, d[nt], 0, 0, 0);
+                    d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, d[nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = mt * 16 + 4 * g + i;
+                    if (row < Nk) DS[row * kMmDss + nt * 16 + cc] = d[nt][i];
+                }
+        }
+        __syncthreads();
+        // ---------------- this thread's sample: pick its four dots, d(offset), d(logit), and its four events
+        float coef[4];
+        int key[4];
+        {
+            const float mx = group_max<8>(lg);
+            const float ex = __expf(lg - mx);
+            const float a = ex / group_sum<8>(ex);
+            Bilinear s;
+            bilinear_setup<true>(u.x + of.x * inv_w, u.y + of.y * inv_h, mh, mw, s);
+            float sa = 0.0f, sx = 0.0f, sy = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float dot = DS[s.key[t] * kMmDss + vloc];
+                sa += s.w[t] * dot;
+                sx += s.gx[t] * dot;
+                sy += s.gy[t] * dot;
+                coef[t] = live ? a * s.w[t] : 0.0f;
+                key[t] = s.key[t];
+            }
+            const float dsum = group_sum<8>(a * sa);
+            const float gx = a * sx, gy = a * sy, gl = a * (sa - dsum);         // d x_pix / d offset = 1
+            if (live) {
+                float* go = goffs + (qh * P + p) * 2;
+                float* gw = glogits + qh * P + p;
+                if (!multi) {
+                    *reinterpret_cast<float2*>(go) = make_float2(gx, gy);
+                    *gw = gl;
+                } else {
+                    atomicAdd(go, gx);
+                    atomicAdd(go + 1, gy);
+                    atomicAdd(gw, gl);
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- S^T[k][v]: zero, then add the chunk's events
+        for (int i = tid; i < Nk * kMmDss / 4; i += 256) reinterpret_cast<float4*>(DS)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (coef[t] != 0.0f) atomicAdd(&DS[key[t] * kMmDss + vloc], coef[t]);
+        __syncthreads();
+        // ---------------- d(value)[k][ch] += sum_v S^T[k][v] G[v][ch]   (B = grad rows read transposed: 8 voxels of one channel)
+        mm_bf16x8 bh[NT], bl[NT];
+        {
+            const unsigned toff = (unsigned)((8 * g + (cc >> 2)) * HD + 4 * (cc & 3));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const mm_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gh + toff + nt * 16));
+                const mm_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gh + toff + nt * 16 + 4 * HD));
+                const mm_s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16));
+                const mm_s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16 + 4 * HD));
+                bh[nt] = __builtin_bit_cast(mm_bf16x8, (mm_s16x8)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                bl[nt] = __builtin_bit_cast(mm_bf16x8, (mm_s16x8)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int mt = wave + 4 * mi;
+            if (mt < MT) {
+                const float* srow = DS + (size_t)(mt * 16 + cc) * kMmDss + 8 * g;
+                const float4 f0 = *reinterpret_cast<const float4*>(srow), f1 = *reinterpret_cast<const float4*>(srow + 4);
+                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                mm_bf16x8 ah, al;
+                mm_split(f, ah, al);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mi][nt], 0, 0, 0);
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mi][nt], 0, 0, 0);
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mi][nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- d(value) tile of this (camera, head): written in full (zeros for a camera that sees nothing)
+    float* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int mt = wave + 4 * mi;
+        if (mt < MT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = mt * 16 + 4 * g + i;
+                if (row < Nk) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) gv[(size_t)row * rstride + nt * 16 + cc] = acc[mi][nt][i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 namespace {
 
 int env_int(const char* name, int dflt) {
@@ -1696,14 +1957,15 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
 
 extern "C" int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                                 const float* uv, const uint8_t* vis, const int32_t* vis_list,
-                                const int32_t* vis_cnt, const float* grad_slots, float* grad_value,
+                                const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
+                                const float* grad_slots, float* grad_value,
                                 float* grad_offsets, float* grad_logits, int B, int Ncam, int Nq, int D,
                                 int heads, int head_dim, int points, int map_h, int map_w, void* stream) {
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
-    VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits, VER_EINVAL,
-                "ver_sca_backward: null gradient pointer");
+    VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits && fwd_list && fwd_cnt, VER_EINVAL,
+                "ver_sca_backward: null pointer argument");
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
     const size_t lds = (size_t)map_h * map_w * head_dim * (sizeof(float) + esz);
@@ -1717,6 +1979,29 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_backward: memset: %s", hipGetErrorString(e));
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
+        if constexpr (P == 8 && HD % 32 == 0) {
+            // bf16 value tiles: everything on the matrix cores, one kernel (VER_SCA_BWD_MM=0: the two-kernel path below)
+            static const int use_mm = env_int("VER_SCA_BWD_MM", 1);
+            const int nk = map_h * map_w, mt = (nk + 15) / 16;
+            const size_t tile_b = ((size_t)nk * HD * 2 + 15) & ~(size_t)15, ds_b = (size_t)nk * kMmDss * 4, g_b = (size_t)2 * 32 * HD * 2;
+            // the last tile-row tile reads (16 mt - nk) rows past the tile / past DS: they must stay inside the allocation
+            const bool slack_ok = (size_t)(16 * mt - nk) * HD * 2 <= ds_b && (size_t)(16 * mt - nk) * kMmDss * 4 <= g_b;
+            if (use_mm && value_dtype == VER_BF16 && mt <= 16 && slack_ok && tile_b + ds_b + g_b <= kMaxLds) {
+                const size_t lds_mm = tile_b + ds_b + g_b;
+                auto launch_mm = [&](auto kern) {
+                    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
+                    if (e2 != hipSuccess)
+                        return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
+                    hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * heads), dim3(256), lds_mm, st, (const uint16_t*)value,
+                                       offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, grad_value, grad_offsets,
+                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w);
+                    return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
+                };
+                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196>);
+                return launch_mm(k_sca_bwd_mm<HD, 0>);
+            }
+        }
         if constexpr (G == 16) {
             if (map_h * map_w <= kValMaxRows) {
                 // ---- d(offsets), d(logits): forward-shaped kernel

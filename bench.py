@@ -134,12 +134,13 @@ def gather_algorithmic_bytes(hit_counts, B, value_bytes, ncam=6, nk=196, c=768, 
     """SURVEY.md 8(d) with `s` = the bytes per element of each operand AS THE KERNEL SEES IT: per viewpoint and
     layer, forward = value once (6*196*768*s_v, s_v = 2 under bf16 autocast: value_proj emits bf16) +
     Sigma_n*(128 + 64 + 768)*4 (offsets, logits and the output row of every visible (camera, voxel) pair are fp32);
-    backward = value read (s_v) + d(value) written (fp32) + Sigma_n*(768 + 2*192 + 192)*4.
+    backward = value read (s_v) + d(value) written (s_v too: the matrix-core backward writes bf16 for bf16 tiles,
+    fp32 for fp32 tiles) + Sigma_n*(768 + 2*192 + 192)*4.
     (Round 1 priced the bf16 value tensor at 4 B/element: its 0.48 was 0.36 by this rule.)"""
     sn = float(hit_counts)
     nval = B * ncam * nk * c
     fwd = nval * value_bytes + sn * (heads * points * 2 + heads * points + c) * 4
-    bwd = nval * (value_bytes + 4) + sn * 5376
+    bwd = nval * (value_bytes + value_bytes) + sn * 5376
     return fwd, bwd
 
 

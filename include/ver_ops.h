@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 15
+#define VER_ABI_VERSION 16
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -164,16 +164,19 @@ int ver_sca_forward(const void* value, int value_dtype, const float* offsets, co
 
 /* Gradient of ver_sca_forward.
  *   grad_slots   f32 [B, Nq, heads*head_dim]
- *   grad_value   f32 [B, Ncam, map_h*map_w, heads, head_dim]  (written in full)
+ *   grad_value   f32 | bf16 [B, Ncam, map_h*map_w, heads, head_dim]  (written in full); grad_value_dtype = VER_F32
+ *                always works, VER_BF16 only where ver_sca_backward_grad_dtype() says so (the matrix-core path
+ *                rounds its fp32 accumulators once, instead of a separate cast pass over the tensor)
  *   grad_offsets f32 [B, Nq, heads, points, 2]                (written in full)
  *   grad_logits  f32 [B, Nq, heads, points]                   (written in full; softmax bwd fused)
  * None of the outputs needs to be zeroed by the caller.
  */
+int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int points, int map_h, int map_w);
 int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                      const float* uv, const uint8_t* vis, const int32_t* vis_list,
                      const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
                      const float* grad_slots,
-                     float* grad_value, float* grad_offsets, float* grad_logits,
+                     void* grad_value, int grad_value_dtype, float* grad_offsets, float* grad_logits,
                      int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                      int map_h, int map_w, void* stream);
 

@@ -1503,11 +1503,11 @@ __device__ __forceinline__ void mm_split(const float (&f)[8], mm_bf16x8& hi, mm_
     }
 }
 
-template <int HD, int NKT>
+template <int HD, int NKT, typename GVT>          // GVT: d(value) is written as float or as bf16 (uint16_t)
 __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
     const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
-    const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, float* __restrict__ gvalue, float* goffs,
+    const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
     float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = 8, NT = HD / 16, KS = HD / 32;
@@ -1583,7 +1583,9 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
     int n_n = total > 32 ? entry_of(32, live_n, multi_n) : 0;
     Ops ops = {};
     if (total > 0) ops = load_ops(n_c);
+    VER_TL(0);
     for (int e0 = 0; e0 < total; e0 += 32) {
+        if (e0 == 64) VER_TL(1);
         const bool live = live_c, multi = multi_c;     // multi is wave-uniform
         const int n = n_c;
         const unsigned m = live ? ops.m : 0u;
@@ -1613,33 +1615,58 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         multi_c = multi_n;
         if (e0 + 32 < total) ops = load_ops(n_c);
         if (e0 + 64 < total) n_n = entry_of(e0 + 64, live_n, multi_n);
+        if (e0 == 64) VER_TL(2);
         if (e0 == 0) __builtin_amdgcn_s_waitcnt(0);   // the tile's LDS-DMA has landed
         __syncthreads();
+        if (e0 == 64) VER_TL(3);
         // ---------------- D^T[k][v] = sum_ch V[k][ch] G[v][ch]   (A = tile rows, B = grad rows, both row-major in LDS)
-        for (int mi = 0; mi < 4; ++mi) {
-            const int mt = wave + 4 * mi;
-            if (mt >= MT) break;
-            f32x4_t d[2] = {zero4, zero4};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const mm_bf16x8 a = *reinterpret_cast<const mm_bf16x8*>(tile + (size_t)(mt * 16 + cc) * HD + ks * 32 + 8 * g);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const mm_bf16x8 bh = *reinterpret_cast<const mm_bf16x8*>(Gh + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
-                    const mm_bf16x8 bl = *reinterpret_cast<const mm_bf16x8*>(Gl + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
-                    d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, d[nt], 0, 0, 0);
-                    d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, d[nt], 0, 0, 0);
-                }
-            }
+        // The 2 x KS grad-row fragments (hi, lo) are read once per chunk; the MT x 2 output tiles are dealt to the waves
+        // one by one (26 tiles over 4 waves: 7, 7, 6, 6).
+        {
+            mm_bf16x8 gbh[2][KS], gbl[2][KS];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = mt * 16 + 4 * g + i;
-                    if (row < Nk) DS[row * kMmDss + nt * 16 + cc] = d[nt][i];
+                for (int ks = 0; ks < KS; ++ks) {
+                    gbh[nt][ks] = *reinterpret_cast<const mm_bf16x8*>(Gh + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
+                    gbl[nt][ks] = *reinterpret_cast<const mm_bf16x8*>(Gl + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
                 }
+            // (unrolled: the 7 tiles of a wave are independent accumulation chains for the scheduler to interleave;
+            //  a chain of 2 KS dependent MFMAs per tile was 780 cycles per tile when executed one tile at a time)
+            constexpr int UMAX = NKT ? (2 * ((NKT + 15) / 16) + 3) / 4 : 8;
+            f32x4_t d[UMAX];
+#pragma unroll
+            for (int ui = 0; ui < UMAX; ++ui) d[ui] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int ui = 0; ui < UMAX; ++ui) {
+                    const int un = wave + 4 * ui;
+                    if (un < 2 * MT) {
+                        const int mt = un >> 1, nt = un & 1;
+                        const mm_bf16x8 a = *reinterpret_cast<const mm_bf16x8*>(tile + (size_t)(mt * 16 + cc) * HD + ks * 32 + 8 * g);
+                        const mm_bf16x8 bhh = nt ? gbh[1][ks] : gbh[0][ks], bll = nt ? gbl[1][ks] : gbl[0][ks];
+                        d[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bhh, d[ui], 0, 0, 0);
+                        d[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bll, d[ui], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ui = 0; ui < UMAX; ++ui) {
+                const int un = wave + 4 * ui;
+                if (un < 2 * MT) {
+                    const int mt = un >> 1, nt = un & 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = mt * 16 + 4 * g + i;
+                        if (row < Nk) DS[row * kMmDss + nt * 16 + cc] = d[ui][i];
+                    }
+                }
+            }
         }
+        if (e0 == 64) VER_TL(4);
         __syncthreads();
+        if (e0 == 64) VER_TL(5);
         // ---------------- this thread's sample: pick its four dots, d(offset), d(logit), and its four events
         float coef[4];
         int key[4];
@@ -1674,14 +1701,20 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
                 }
             }
         }
+        if (e0 == 64) VER_TL(6);
         __syncthreads();
+        if (e0 == 64) VER_TL(7);
         // ---------------- S^T[k][v]: zero, then add the chunk's events
         for (int i = tid; i < Nk * kMmDss / 4; i += 256) reinterpret_cast<float4*>(DS)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
+        if (e0 == 64) VER_TL(8);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (coef[t] != 0.0f) atomicAdd(&DS[key[t] * kMmDss + vloc], coef[t]);
+        for (int t = 0; t < 4; ++t)          // S <= 1: 2^-30 fixed point, integer LDS atomics (float ones retire ~0.5 lane/clk)
+            if (coef[t] != 0.0f)
+                atomicAdd(reinterpret_cast<unsigned*>(DS) + key[t] * kMmDss + vloc, __float2uint_rn(coef[t] * 1073741824.0f));
+        if (e0 == 64) VER_TL(9);
         __syncthreads();
+        if (e0 == 64) VER_TL(10);
         // ---------------- d(value)[k][ch] += sum_v S^T[k][v] G[v][ch]   (B = grad rows read transposed: 8 voxels of one channel)
         mm_bf16x8 bh[NT], bl[NT];
         {
@@ -1701,8 +1734,10 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
             const int mt = wave + 4 * mi;
             if (mt < MT) {
                 const float* srow = DS + (size_t)(mt * 16 + cc) * kMmDss + 8 * g;
-                const float4 f0 = *reinterpret_cast<const float4*>(srow), f1 = *reinterpret_cast<const float4*>(srow + 4);
-                const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                const uint4 q0 = *reinterpret_cast<const uint4*>(srow), q1 = *reinterpret_cast<const uint4*>(srow + 4);
+                constexpr float kFix = 1.0f / 1073741824.0f;
+                const float f[8] = {(float)q0.x * kFix, (float)q0.y * kFix, (float)q0.z * kFix, (float)q0.w * kFix,
+                                    (float)q1.x * kFix, (float)q1.y * kFix, (float)q1.z * kFix, (float)q1.w * kFix};
                 mm_bf16x8 ah, al;
                 mm_split(f, ah, al);
 #pragma unroll
@@ -1713,10 +1748,13 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
                 }
             }
         }
+        if (e0 == 64) VER_TL(11);
         __syncthreads();
+        if (e0 == 64) VER_TL(12);
     }
+    VER_TL(13);
     // ---------------- d(value) tile of this (camera, head): written in full (zeros for a camera that sees nothing)
-    float* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
+    GVT* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int mt = wave + 4 * mi;
@@ -1726,7 +1764,14 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
                 const int row = mt * 16 + 4 * g + i;
                 if (row < Nk) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) gv[(size_t)row * rstride + nt * 16 + cc] = acc[mi][nt][i];
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (sizeof(GVT) == 4) {
+                            gv[(size_t)row * rstride + nt * 16 + cc] = acc[mi][nt][i];
+                        } else {
+                            const __bf16 r16 = (__bf16)acc[mi][nt][i];
+                            gv[(size_t)row * rstride + nt * 16 + cc] = __builtin_bit_cast(uint16_t, r16);
+                        }
+                    }
                 }
             }
         }
@@ -1955,10 +2000,22 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     });
 }
 
+// dtype ver_sca_backward writes d(value) in most cheaply for this problem: VER_BF16 on the matrix-core path (bf16 value
+// tiles, 8 points, head_dim % 32 == 0, tile fits), else VER_F32.  VER_F32 is always accepted.
+extern "C" int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int points, int map_h, int map_w) {
+    if (value_dtype != VER_BF16 || points != 8 || head_dim % 32 != 0 || head_dim > 128) return VER_F32;
+    if (env_int("VER_SCA_BWD_MM", 1) == 0) return VER_F32;
+    const int nk = map_h * map_w, mt = (nk + 15) / 16;
+    const size_t tile_b = ((size_t)nk * head_dim * 2 + 15) & ~(size_t)15, ds_b = (size_t)nk * kMmDss * 4,
+                 g_b = (size_t)2 * 32 * head_dim * 2;
+    const bool slack_ok = (size_t)(16 * mt - nk) * head_dim * 2 <= ds_b && (size_t)(16 * mt - nk) * kMmDss * 4 <= g_b;
+    return (mt <= 16 && slack_ok && tile_b + ds_b + g_b <= kMaxLds) ? VER_BF16 : VER_F32;
+}
+
 extern "C" int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                                 const float* uv, const uint8_t* vis, const int32_t* vis_list,
                                 const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
-                                const float* grad_slots, float* grad_value,
+                                const float* grad_slots, void* grad_value, int grad_value_dtype,
                                 float* grad_offsets, float* grad_logits, int B, int Ncam, int Nq, int D,
                                 int heads, int head_dim, int points, int map_h, int map_w, void* stream) {
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
@@ -1966,6 +2023,10 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     if (rc) return rc;
     VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits && fwd_list && fwd_cnt, VER_EINVAL,
                 "ver_sca_backward: null pointer argument");
+    VER_REQUIRE(grad_value_dtype == ver_sca_backward_grad_dtype(value_dtype, head_dim, points, map_h, map_w) ||
+                    grad_value_dtype == VER_F32,
+                VER_EUNSUPPORTED, "ver_sca_backward: grad_value_dtype %d not available for this shape (ask "
+                "ver_sca_backward_grad_dtype)", grad_value_dtype);
     if (B == 0 || Nq == 0) return VER_OK;
     const size_t esz = value_dtype == VER_BF16 ? 2 : 4;
     const size_t lds = (size_t)map_h * map_w * head_dim * (sizeof(float) + esz);
@@ -1974,8 +2035,9 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     const size_t nsmall = (size_t)B * Nq * heads * points;
     hipError_t e = hipMemsetAsync(grad_offsets, 0, nsmall * 2 * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(grad_logits, 0, nsmall * sizeof(float), st);
-    if (e == hipSuccess && nchunks > 1)
+    if (e == hipSuccess && nchunks > 1 && grad_value_dtype == VER_F32)      // (the chunked two-kernel path flushes with atomics)
         e = hipMemsetAsync(grad_value, 0, (size_t)B * Ncam * map_h * map_w * heads * head_dim * sizeof(float), st);
+    float* grad_value_f32 = reinterpret_cast<float*>(grad_value);          // (the two-kernel paths write fp32 only)
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_backward: memset: %s", hipGetErrorString(e));
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
@@ -1988,18 +2050,23 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
             const bool slack_ok = (size_t)(16 * mt - nk) * HD * 2 <= ds_b && (size_t)(16 * mt - nk) * kMmDss * 4 <= g_b;
             if (use_mm && value_dtype == VER_BF16 && mt <= 16 && slack_ok && tile_b + ds_b + g_b <= kMaxLds) {
                 const size_t lds_mm = tile_b + ds_b + g_b;
-                auto launch_mm = [&](auto kern) {
+                auto launch_mm = [&](auto kern, auto gptr) {
                     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
                     if (e2 != hipSuccess)
                         return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
+                    typedef std::remove_pointer_t<decltype(gptr)> gv_t;
                     hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * heads), dim3(256), lds_mm, st, (const uint16_t*)value,
-                                       offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, grad_value, grad_offsets,
+                                       offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, (gv_t*)grad_value, grad_offsets,
                                        grad_logits, Ncam, Nq, D, heads, map_h, map_w);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
                 };
-                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196>);
-                return launch_mm(k_sca_bwd_mm<HD, 0>);
+                if (grad_value_dtype == VER_BF16) {
+                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t>, (uint16_t*)nullptr);
+                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t>, (uint16_t*)nullptr);
+                }
+                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, float>, (float*)nullptr);
+                return launch_mm(k_sca_bwd_mm<HD, 0, float>, (float*)nullptr);
             }
         }
         if constexpr (G == 16) {
@@ -2048,7 +2115,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                 if (e3 != hipSuccess)
                     return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e3));
                 hipLaunchKernelGGL(kv, dim3((unsigned)B * Ncam * heads * nchunks), dim3(kValThreads), lds_val, st, offsets,
-                                   logits, uv, vis, vis_list, vis_cnt, grad_slots, grad_value, Ncam, Nq, D, heads,
+                                   logits, uv, vis, vis_list, vis_cnt, grad_slots, grad_value_f32, Ncam, Nq, D, heads,
                                    map_h, map_w, nchunks, kBwdChunk);
                 return ver_check_launch("ver_sca_backward/k_sca_bwd_val");
             }
@@ -2063,7 +2130,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                 return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
             const unsigned blocks = (unsigned)B * Ncam * heads * nchunks;
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), lds, st, vptr, offsets, logits, uv, vis, vis_list, vis_cnt,
-                               grad_slots, grad_value, grad_offsets, grad_logits, Ncam, Nq, D, heads, map_h, map_w,
+                               grad_slots, grad_value_f32, grad_offsets, grad_logits, Ncam, Nq, D, heads, map_h, map_w,
                                nchunks, kBwdChunk);
             return ver_check_launch("ver_sca_backward");
         };

@@ -13,8 +13,8 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 15
-SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_msda_forward', 'ver_msda_backward',
+ABI_VERSION = 16
+SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
@@ -245,12 +245,14 @@ class SCAGatherFunction(Function):
         B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
         gs = _gpu(grad_slots, 'grad_slots').float().contiguous()
-        g_value = torch.empty(value.shape, dtype=torch.float32, device=value.device)
+        # the matrix-core backward rounds d(value) to bf16 itself (no separate cast pass over the tensor)
+        gdt = lib().ver_sca_backward_grad_dtype(ctx.vdt, hd, points, map_h, map_w)
+        g_value = torch.empty(value.shape, dtype=torch.bfloat16 if gdt == 1 else torch.float32, device=value.device)
         g_off = torch.empty_like(offsets)
         g_log = torch.empty_like(logits)
         _launch('ver_sca_backward', lambda: lib().ver_sca_backward(
             _p(value), ctx.vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
-            _p(hit.vis_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(gs), _p(g_value), _p(g_off), _p(g_log), B, ncam,
+            _p(hit.vis_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(gs), _p(g_value), gdt, _p(g_off), _p(g_log), B, ncam,
             hit.Nq, hit.D, heads,
             hd, points, map_h, map_w, _stream()))
         return g_value.to(value.dtype), g_off, g_log, None, None, None

@@ -1492,6 +1492,12 @@ __global__ __launch_bounds__(kValThreads) void k_sca_bwd_val(
 typedef __bf16 mm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short mm_s16x4 __attribute__((ext_vector_type(4)));
 typedef short mm_s16x8 __attribute__((ext_vector_type(8)));
+#ifndef VER_MM_WAVES
+#define VER_MM_WAVES 4
+#endif
+// waves per workgroup of k_sca_bwd_mm.  4 (two workgroups per CU, 246 VGPRs) measured 591 us per 192-viewpoint launch;
+// 8 (one workgroup per CU at 179 VGPRs) 771 us; 8 squeezed into 128 VGPRs for two workgroups per CU spills: 1759 us.
+constexpr int kMmWaves = VER_MM_WAVES;
 constexpr int kMmDss = 36;            // floats per row of the D / S^T buffer [tile row][32 voxels + pad]: rows 4 banks apart
 
 __device__ __forceinline__ void mm_split(const float (&f)[8], mm_bf16x8& hi, mm_bf16x8& lo) {
@@ -1503,14 +1509,16 @@ __device__ __forceinline__ void mm_split(const float (&f)[8], mm_bf16x8& hi, mm_
     }
 }
 
-template <int HD, int NKT, typename GVT>          // GVT: d(value) is written as float or as bf16 (uint16_t)
-__global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
+// GVT: d(value) is written as float or as bf16 (uint16_t).  NW waves per workgroup: the first four carry the scalar phases
+// (256 threads = 32 voxels x 8 points), all NW share the matrix phases, the zero fill and the tile staging.
+template <int HD, int NKT, typename GVT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
-    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw) {
+    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int P = 8, NT = HD / 16, KS = HD / 32;
+    constexpr int P = 8, NT = HD / 16, KS = HD / 32, MI = 16 / NW;
     static_assert(HD % 32 == 0, "k-steps of 32 channels");
     const int Nk = NKT ? NKT : mh * mw;
     const int MT = (Nk + 15) >> 4;                    // tile-row tiles of 16 (the last one reads past the tile: see below)
@@ -1520,13 +1528,17 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
     uint16_t* Gl = Gh + 32 * HD;                                                           // [32][HD] bf16 lo
     // (rows Nk .. 16 MT - 1 of the last tile-row tile are read from whatever follows the tile / DS in LDS: they only
     //  feed D rows that are never stored and d(value) rows that are never written; the host wrapper checks the slack)
-    int bid = blockIdx.x;
+    // XCD-aware placement (see k_sca_fwd_cs): the heads of a (viewpoint, camera) share lists, uv and the lines of the
+    // grad / offset / logit rows
+    int bid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (bid >= total_wgs) return;
     const int h = bid % heads;
     bid /= heads;
     const int c = bid % Ncam, b = bid / Ncam;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int cc = lane & 15, g = lane >> 4;
-    const int vloc = tid >> 3, p = tid & 7;           // scalar phases: voxel of the chunk, sampling point
+    const bool scalar = tid < 256;                    // this thread is a (voxel, point) of the scalar phases
+    const int vloc = (tid & 255) >> 3, p = tid & 7;   // voxel of the chunk, sampling point
     const int ad = (D == 1) ? 0 : (p % D);
     const float inv_w = 1.0f / (float)mw, inv_h = 1.0f / (float)mh;
     const size_t rstride = (size_t)heads * HD;
@@ -1535,12 +1547,12 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
     const int total = s8 + n_multi;
     const int* list = fwd_list + ((size_t)b * Ncam + c) * Nq;
 
-    stage_tile<HD, uint16_t>(tile, value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD, rstride, Nk, wave, 4);
+    stage_tile<HD, uint16_t>(tile, value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD, rstride, Nk, wave, NW);
 
     const f32x4_t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4_t acc[4][NT];                               // d(value): tile-row tiles wave, wave + 4, ...; lane (channel cc, rows 4g..4g+3)
+    f32x4_t acc[MI][NT];                              // d(value): tile-row tiles wave, wave + NW, ...; lane (channel cc, rows 4g..4g+3)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = zero4;
 
@@ -1579,10 +1591,10 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         return o;
     };
     bool live_c = false, multi_c = false, live_n = false, multi_n = false;
-    int n_c = total > 0 ? entry_of(0, live_c, multi_c) : 0;
-    int n_n = total > 32 ? entry_of(32, live_n, multi_n) : 0;
+    int n_c = (scalar && total > 0) ? entry_of(0, live_c, multi_c) : 0;
+    int n_n = (scalar && total > 32) ? entry_of(32, live_n, multi_n) : 0;
     Ops ops = {};
-    if (total > 0) ops = load_ops(n_c);
+    if (scalar && total > 0) ops = load_ops(n_c);
     VER_TL(0);
     for (int e0 = 0; e0 < total; e0 += 32) {
         if (e0 == 64) VER_TL(1);
@@ -1593,7 +1605,7 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         const size_t qh = ((size_t)b * Nq + n) * heads + h;
         const float lg = ops.lg;
         const float2 of = ops.of, u = ops.u;
-        {
+        if (scalar) {
             uint16_t* gh = Gh + vloc * HD + p * SEG;
             uint16_t* gl = Gl + vloc * HD + p * SEG;
 #pragma unroll
@@ -1613,8 +1625,8 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         n_c = n_n;
         live_c = live_n;
         multi_c = multi_n;
-        if (e0 + 32 < total) ops = load_ops(n_c);
-        if (e0 + 64 < total) n_n = entry_of(e0 + 64, live_n, multi_n);
+        if (scalar && e0 + 32 < total) ops = load_ops(n_c);
+        if (scalar && e0 + 64 < total) n_n = entry_of(e0 + 64, live_n, multi_n);
         if (e0 == 64) VER_TL(2);
         if (e0 == 0) __builtin_amdgcn_s_waitcnt(0);   // the tile's LDS-DMA has landed
         __syncthreads();
@@ -1633,7 +1645,7 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
                 }
             // (unrolled: the 7 tiles of a wave are independent accumulation chains for the scheduler to interleave;
             //  a chain of 2 KS dependent MFMAs per tile was 780 cycles per tile when executed one tile at a time)
-            constexpr int UMAX = NKT ? (2 * ((NKT + 15) / 16) + 3) / 4 : 8;
+            constexpr int UMAX = NKT ? (2 * ((NKT + 15) / 16) + NW - 1) / NW : 32 / NW;
             f32x4_t d[UMAX];
 #pragma unroll
             for (int ui = 0; ui < UMAX; ++ui) d[ui] = zero4;
@@ -1641,7 +1653,7 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                 for (int ui = 0; ui < UMAX; ++ui) {
-                    const int un = wave + 4 * ui;
+                    const int un = wave + NW * ui;
                     if (un < 2 * MT) {
                         const int mt = un >> 1, nt = un & 1;
                         const mm_bf16x8 a = *reinterpret_cast<const mm_bf16x8*>(tile + (size_t)(mt * 16 + cc) * HD + ks * 32 + 8 * g);
@@ -1653,7 +1665,7 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
             }
 #pragma unroll
             for (int ui = 0; ui < UMAX; ++ui) {
-                const int un = wave + 4 * ui;
+                const int un = wave + NW * ui;
                 if (un < 2 * MT) {
                     const int mt = un >> 1, nt = un & 1;
 #pragma unroll
@@ -1668,9 +1680,9 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         __syncthreads();
         if (e0 == 64) VER_TL(5);
         // ---------------- this thread's sample: pick its four dots, d(offset), d(logit), and its four events
-        float coef[4];
-        int key[4];
-        {
+        float coef[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int key[4] = {0, 0, 0, 0};
+        if (scalar) {
             const float mx = group_max<8>(lg);
             const float ex = __expf(lg - mx);
             const float a = ex / group_sum<8>(ex);
@@ -1705,7 +1717,7 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
         __syncthreads();
         if (e0 == 64) VER_TL(7);
         // ---------------- S^T[k][v]: zero, then add the chunk's events
-        for (int i = tid; i < Nk * kMmDss / 4; i += 256) reinterpret_cast<float4*>(DS)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = tid; i < Nk * kMmDss / 4; i += NW * 64) reinterpret_cast<float4*>(DS)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         __syncthreads();
         if (e0 == 64) VER_TL(8);
 #pragma unroll
@@ -1730,8 +1742,8 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
             }
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int mt = wave + 4 * mi;
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mt = wave + NW * mi;
             if (mt < MT) {
                 const float* srow = DS + (size_t)(mt * 16 + cc) * kMmDss + 8 * g;
                 const uint4 q0 = *reinterpret_cast<const uint4*>(srow), q1 = *reinterpret_cast<const uint4*>(srow + 4);
@@ -1756,8 +1768,8 @@ __global__ __launch_bounds__(256, 2) void k_sca_bwd_mm(
     // ---------------- d(value) tile of this (camera, head): written in full (zeros for a camera that sees nothing)
     GVT* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        const int mt = wave + 4 * mi;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int mt = wave + NW * mi;
         if (mt < MT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2056,17 +2068,18 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                     if (e2 != hipSuccess)
                         return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
                     typedef std::remove_pointer_t<decltype(gptr)> gv_t;
-                    hipLaunchKernelGGL(kern, dim3((unsigned)B * Ncam * heads), dim3(256), lds_mm, st, (const uint16_t*)value,
+                    const int wgs = B * Ncam * heads;
+                    hipLaunchKernelGGL(kern, dim3((unsigned)((wgs + 7) & ~7)), dim3(kMmWaves * 64), lds_mm, st, (const uint16_t*)value,
                                        offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, (gv_t*)grad_value, grad_offsets,
-                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w);
+                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
                 };
                 if (grad_value_dtype == VER_BF16) {
-                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t>, (uint16_t*)nullptr);
-                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t>, (uint16_t*)nullptr);
+                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t, kMmWaves>, (uint16_t*)nullptr);
+                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t, kMmWaves>, (uint16_t*)nullptr);
                 }
-                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, float>, (float*)nullptr);
-                return launch_mm(k_sca_bwd_mm<HD, 0, float>, (float*)nullptr);
+                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, float, kMmWaves>, (float*)nullptr);
+                return launch_mm(k_sca_bwd_mm<HD, 0, float, kMmWaves>, (float*)nullptr);
             }
         }
         if constexpr (G == 16) {

@@ -1,0 +1,26 @@
+"""Phase timeline (s_memtime) of four probe workgroups of k_sca_fwd_mm, second chunk (library built with -DVER_DEBUG_TIMELINE)."""
+import sys, importlib, ctypes, os
+sys.path.insert(0,'.'); sys.path.insert(0,'tests/golden')
+import torch, numpy as np
+hip = importlib.import_module('vln-ver_amd.hipops'); syn = importlib.import_module('vln-ver_amd.synthetic')
+import cases
+hip.LIB_PATH = os.path.abspath('scratch/r02/lib_timeline.so')
+B = 192; dev='cuda'
+w2p, org = syn.camera_batch(B, seed=1)
+hit = hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, 4,15,15)
+g = torch.Generator(device=dev).manual_seed(0)
+value = torch.randn(B,6,196,8,96, device=dev, generator=g).bfloat16()
+offs = torch.randn(B,900,8,8,2, device=dev, generator=g)*3; logits = torch.randn(B,900,8,8, device=dev, generator=g)
+for _ in range(3): s = hip.sca_gather(value, offs, logits, hit, 14, 14)
+torch.cuda.synchronize()
+N = 4*16*64
+out = (ctypes.c_longlong*N)()
+hip.lib().ver_timeline_read(out, N)
+t = np.array(list(out), dtype=np.int64).reshape(4, 16, 64)
+names = ['start','tile landed','frags+sample0','chunk1 top','scattered','B1','product done','next sample','stored','B2','loop end']
+for pr in range(4):
+    t0 = t[pr, :4, 0].min()
+    print('== probe workgroup', pr)
+    for w in range(4):
+        r = t[pr, w] - t0
+        print(' wave', w, ' '.join('%s=%d' % (names[i], r[i]) for i in range(11)))

@@ -254,6 +254,38 @@ def test_sca_gather_bf16_value(heads, hd, P, grid):
     assert close(vb.grad.float().cpu(), vc.grad, atol=2e-2, rtol=1e-2)      # grad rounded to bf16
 
 
+def test_sca_backward_grad_value_dtype_contract():
+    """C ABI: ver_sca_backward_grad_dtype names the cheapest d(value) dtype (bf16 on the matrix-core path), and
+    VER_F32 is accepted for the same problem: both buffers hold the same gradient up to bf16 rounding, and the
+    d(offsets) / d(logits) of the two calls are bitwise equal."""
+    hip = pkg('hipops')
+    lib = hip.lib()
+    heads, hd, P = 8, 96, 8
+    assert lib.ver_sca_backward_grad_dtype(1, hd, P, 14, 14) == 1          # bf16 tiles, 8 points: matrix cores
+    assert lib.ver_sca_backward_grad_dtype(0, hd, P, 14, 14) == 0          # fp32 tiles
+    assert lib.ver_sca_backward_grad_dtype(1, hd, 4, 14, 14) == 0          # 4 points
+    assert lib.ver_sca_backward_grad_dtype(1, 8, P, 14, 14) == 0           # head_dim 8
+    hit, value, offsets, logits, gslots = _random_sca_case(23, 2, (4, 15, 15), heads, hd, P)
+    vb = T(value).to(DEV).to(torch.bfloat16)
+    of, lg, gs = T(offsets).to(DEV), T(logits).to(DEV), T(gslots).to(DEV)
+    B, ncam = vb.shape[0], vb.shape[1]
+    p = hip._p
+    res = {}
+    for gdt, dt in ((1, torch.bfloat16), (0, torch.float32)):
+        gv = torch.full(vb.shape, float('nan'), dtype=dt, device=DEV)      # every element must be written
+        go, gl = torch.empty_like(of), torch.empty_like(lg)
+        rc = lib.ver_sca_backward(p(vb), 1, p(of), p(lg), p(hit.uv), p(hit.vis), p(hit.vis_list), p(hit.vis_cnt),
+                                  p(hit.fwd_list), p(hit.fwd_cnt), p(gs), p(gv), gdt, p(go), p(gl), B, ncam, hit.Nq,
+                                  hit.D, heads, hd, P, 14, 14, hip._stream())
+        assert rc == 0, lib.ver_last_error()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(gv.float()).all())
+        res[gdt] = (gv.float().cpu(), go.cpu(), gl.cpu())
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert close(res[1][0], res[0][0], atol=2e-2, rtol=1e-2)               # bf16 rounding of the fp32 result
+    assert torch.equal(res[0][0].bfloat16(), res[1][0].bfloat16())          # ... and exactly that rounding
+
+
 def test_forward_work_lists_partition_the_visible_voxels():
     """fwd_list / fwd_cnt (the forward kernel's work order): per camera the voxels only it sees from the front, the
     voxels it shares with other cameras from the back; together exactly vis_list."""

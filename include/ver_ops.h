@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 16
+#define VER_ABI_VERSION 17
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -266,12 +266,16 @@ int ver_focal_loss_backward(const void* logits, const int64_t* target, const flo
  *             (ver_occ_mlp_image_bytes() bytes, 16-byte aligned): MFMA weight fragments
  *   vectors : f32 [ver_occ_mlp_vector_floats()] = b1 gamma1 beta1 b2 gamma2 beta2 (128 each) b3 (16)
  *   forward : x bf16 [N,128] -> logits bf16 [N,16]
+ *   first_linear = 0: the first Linear has been folded into the producer of x (two Linears in a row compose:
+ *             `occ_proj` :571 feeds `occ_branches[0]` :580 with nothing in between), x is ITS output and the chain
+ *             starts at the first LayerNorm; W1 / b1 of image / vectors are ignored, grad_a1 may be NULL,
+ *             grad_x = d loss / d x is then the gradient w.r.t. that output, and no dW1 is to be formed.
  */
 long ver_occ_mlp_image_bytes(void);
 int ver_occ_mlp_vector_floats(void);
 int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W3, void* image, void* stream);
 int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits,
-                        long N, int width, int classes, float eps, void* stream);
+                        long N, int width, int classes, float eps, int first_linear, void* stream);
 /*   backward: re-computes the forward from x, then
  *     grad_x  bf16 [N,128]                      d loss / d x
  *     grad_a1, grad_a2 bf16 [N,128]             gradients w.r.t. the outputs of Linear 1 / Linear 2
@@ -284,7 +288,8 @@ int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, 
  */
 int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
                          void* grad_x, void* grad_a1, void* grad_a2, void* h1,
-                         float* param_grads, long N, int width, int classes, float eps, void* stream);
+                         float* param_grads, long N, int width, int classes, float eps, int first_linear,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -55,11 +55,11 @@ def test_argument_validation_of_the_head_entry_points():
     lib.ver_occ_mlp_image_bytes.restype = ctypes.c_long
     assert lib.ver_occ_mlp_image_bytes() == 140 * 1024 and lib.ver_occ_mlp_vector_floats() == 6 * 128 + 16
     buf = (ctypes.c_float * 16)()
-    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 64, 16, ctypes.c_float(1e-5), None)
+    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 64, 16, ctypes.c_float(1e-5), 1, None)
     assert rc == -2 and b'width' in lib.ver_last_error()                  # built for 128 / 16
-    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 128, 16, ctypes.c_float(1e-5), None)
+    rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 128, 16, ctypes.c_float(1e-5), 1, None)
     assert rc == -1 and b'null' in lib.ver_last_error()
-    assert lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(0), 128, 16, ctypes.c_float(1e-5), None) == 0
+    assert lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(0), 128, 16, ctypes.c_float(1e-5), 1, None) == 0
     rc = lib.ver_focal_loss_forward(None, None, None, ctypes.c_long(8), 10, ctypes.c_float(2), ctypes.c_float(.25), 0, None)
     assert rc == -2 and b'multiple of 8' in lib.ver_last_error()
     assert lib.ver_focal_loss_blocks(ctypes.c_long(0), 16) == 1

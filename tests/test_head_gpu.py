@@ -125,3 +125,35 @@ def test_vocc_head_bf16_autocast_within_1e2():
     assert float((got - want).abs().mean()) < 2e-2
     assert abs(float(occ.double().norm()) - float(g['c3_b0_occ_norm'])) < 1e-2 * float(g['c3_b0_occ_norm'])
     assert rel_l2(emb[0, ::7].float().cpu(), T(g['c3_b0_bev'])) < 1e-2
+
+
+def test_vocc_head_bf16_backward_with_folded_first_linear():
+    """bf16 autocast backward of the bench's arithmetic.  On this path ``occ_branches[0]`` is folded into
+    ``occ_proj`` (two Linears in a row) and its weight gradient comes back through the folded product:
+    gradient norms of every parameter against the reference's fp32 vectors within bf16 accuracy, and the
+    gradients of the layers around the fold against the UNFOLDED bf16 path (same kernels, reference order) --
+    no further from our fp32 path than that one is."""
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    gg = T(np.random.default_rng(60).standard_normal((504000, 16)).astype(np.float32)).to(DEV)
+    grads = {}
+    for mode in ('fp32', 'bf16_unfolded', 'bf16'):
+        head = _head(cases.vocc_head_cfg(), 7)
+        head.fold_first_occ_linear = mode == 'bf16'
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'fp32'):
+            outs = head(T(feats[0]).to(DEV).unsqueeze(1), _metas(w2p, org, [0]))
+        (outs['occupancy_preds'][0].float() * gg).sum().backward()
+        grads[mode] = {k: p.grad.float().cpu() for k, p in head.named_parameters() if p.grad is not None}
+    names = [str(s) for s in g['c3_grad_names']]
+    assert set(names) <= set(grads['bf16'])
+    for name, want in zip(names, g['c3_grad_norms']):
+        got = float(grads['bf16'][name].double().norm())
+        assert abs(got - want) <= 3e-2 * max(1e-3, abs(want)), (name, got, want)
+    for name in ('occ_proj.weight', 'occ_proj.bias', 'occ_branches.0.weight', 'occ_branches.0.bias',
+                 'occ_branches.1.weight', 'occ_branches.3.weight', 'up_sample.2.weight'):
+        folded = rel_l2(grads['bf16'][name], grads['fp32'][name])
+        unfolded = rel_l2(grads['bf16_unfolded'][name], grads['fp32'][name])
+        print(name, 'folded', folded, 'unfolded', unfolded)
+        assert folded < max(1.25 * unfolded, 1e-2), (name, folded, unfolded)

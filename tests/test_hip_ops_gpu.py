@@ -700,6 +700,44 @@ def test_occ_mlp_fused_backward():
         assert rel(pd[k].grad, pr[k].grad) < 8e-2, (k, rel(pd[k].grad, pr[k].grad))
 
 
+def test_occ_mlp_fused_with_folded_first_linear():
+    """first_linear = 0 (the first Linear folded into the producer of x): the kernels start at the first LayerNorm.
+    x := bf16(Linear1(x0)); forward and every gradient (d x = gradient w.r.t. that output) vs autograd through the
+    fp64 chain LayerNorm -> ReLU -> Linear2 -> LayerNorm -> ReLU -> Linear3 on the same x."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(13)
+    p = _occ_mlp_params(gen)
+    n = 8000 + 16 * 7 + 3
+    x0 = (torch.randn(n, 128, generator=gen) * 1.5)
+    a1 = (x0 @ p['w1'].t() + p['b1']).bfloat16()
+    gy = (torch.randn(n, 16, generator=gen) * 0.1).bfloat16()
+    keys = ('g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+    pd = {k: p[k].to(DEV).requires_grad_(True) for k in keys}
+    xd = a1.to(DEV).requires_grad_(True)
+    out = hip.occ_mlp(xd, None, None, *(pd[k] for k in keys))
+    out.backward(gy.to(DEV))
+    pr = {k: (v.bfloat16().double() if k.startswith('w') else v.double()).requires_grad_(True) for k, v in p.items()}
+    xr = a1.double().requires_grad_(True)
+    F = torch.nn.functional
+    h = F.relu(F.layer_norm(xr, (128,), pr['g1'], pr['be1'], 1e-5))
+    h = F.relu(F.layer_norm(h @ pr['w2'].t() + pr['b2'], (128,), pr['g2'], pr['be2'], 1e-5))
+    ref = h @ pr['w3'].t() + pr['b3']
+    ref.backward(gy.double())
+
+    def rel(a, b):
+        return float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(out.detach().float(), ref.detach()) < 5e-3
+    assert xd.grad.dtype == torch.bfloat16 and xd.grad.shape == a1.shape
+    assert rel(xd.grad.float(), xr.grad) < 6e-2, rel(xd.grad.float(), xr.grad)
+    for k in keys:
+        assert pd[k].grad.shape == p[k].shape
+        assert rel(pd[k].grad, pr[k].grad) < 8e-2, (k, rel(pd[k].grad, pr[k].grad))
+    assert hip.occ_mlp_forward(torch.zeros(0, 128, device=DEV, dtype=torch.bfloat16),
+                               hip.occ_mlp_pack(p['w1'].to(DEV), p['w2'].to(DEV), p['w3'].to(DEV)),
+                               hip.occ_mlp_vectors(*(p[k].to(DEV) for k in ('b1', 'g1', 'be1', 'b2', 'g2', 'be2', 'b3'))),
+                               first_linear=False).shape == (0, 16)
+
+
 # ------------------------------------------------------------------------------- next row 2: occupancy loss
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('gamma,alpha', [(2.0, 0.25), (1.5, 0.4)])

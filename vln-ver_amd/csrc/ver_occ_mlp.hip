@@ -135,7 +135,65 @@ __device__ __forceinline__ void ln_relu_tile(f32x4 (&acc)[8], const float* gam, 
 }
 }  // namespace
 
-template <int RT>
+namespace {
+// The same on a row tile in the NATURAL fragment layout (what a 16-byte load of x gives: lane (row c, g) holds features
+// 32t + 8g + j of the row in x[t][j]).  Used when the first Linear has been folded into the producer of x
+// (first_linear = 0): x is the pre-LayerNorm activation itself.  gam / bet already offset by 8g.
+// KEEP: also return the normalised values (bf16) and form the output from those rounded values (backward pass).
+template <bool KEEP>
+__device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, const float* bet, float eps,
+                                            bf16x8 (&xh)[4], float& rstd_out) {
+    f32x4 v[4][2];
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bf16x4 hx = h ? __builtin_shufflevector(x[t], x[t], 4, 5, 6, 7) : __builtin_shufflevector(x[t], x[t], 0, 1, 2, 3);
+            v[t][h] = __builtin_convertvector(hx, f32x4);
+            s += (v[t][h].x + v[t][h].y) + (v[t][h].z + v[t][h].w);
+        }
+    s += xor16(s);
+    s += xor32(s);
+    const float mu = s * (1.0f / kW);
+    float q = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v[t][h] -= mu;
+            q += (v[t][h].x * v[t][h].x + v[t][h].y * v[t][h].y) + (v[t][h].z * v[t][h].z + v[t][h].w * v[t][h].w);
+        }
+    q += xor16(q);
+    q += xor32(q);
+    const float rs = rsqrtf(q * (1.0f / kW) + eps);
+    rstd_out = rs;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (KEEP) xh[t] = pack8(v[t][0] * rs, v[t][1] * rs);
+        f32x4 y[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 32 * t + 4 * h);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 32 * t + 4 * h);
+            f32x4 n;
+            if (KEEP) {
+                const bf16x4 hn = h ? __builtin_shufflevector(xh[t], xh[t], 4, 5, 6, 7) : __builtin_shufflevector(xh[t], xh[t], 0, 1, 2, 3);
+                n = __builtin_convertvector(hn, f32x4);
+            } else {
+                n = v[t][h] * rs;
+            }
+            y[h] = __builtin_elementwise_max(n * gm + bt, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+        }
+        x[t] = pack8(y[0], y[1]);
+    }
+}
+}  // namespace
+
+// L1 = false (first_linear = 0, ver_ops.h): x is the output of the first Linear already.  The chain starts with the first
+// LayerNorm in the natural fragment layout; the image was packed with W2 in W1's place, so section kF1 holds W2 with the
+// natural k order that layout needs (and kB1, in the backward kernel, W2's dgrad with natural-order output rows).
+template <int RT, bool L1>
 __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict__ x, const __bf16* __restrict__ img,
                                                         const float* __restrict__ vec, __bf16* __restrict__ logits,
                                                         long N, float eps) {
@@ -166,8 +224,17 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
                 bf[rt][kt] = r < N ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * kt + 8 * g) : z;
             }
         }
+        if constexpr (!L1) {
+            const float* sv_n = sv + 8 * (lane_off >> 4);
 #pragma unroll
-        for (int layer = 0; layer < 2; ++layer) {
+            for (int rt = 0; rt < RT; ++rt) {
+                float rs;
+                bf16x8 unused[4];
+                ln_relu_nat<false>(bf[rt], sv_n + kW, sv_n + 2 * kW, eps, unused, rs);
+            }
+        }
+#pragma unroll
+        for (int layer = L1 ? 0 : 1; layer < 2; ++layer) {
             const float* bias = sv_g + layer * 3 * kW;
             f32x4 acc[RT][8];
 #pragma unroll
@@ -177,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
                 for (int rt = 0; rt < RT; ++rt) acc[rt][ot] = b;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    const bf16x8 a = fr[((layer ? kF2 : kF1) + ot * 4 + kt) * 64];
+                    const bf16x8 a = fr[((layer && L1 ? kF2 : kF1) + ot * 4 + kt) * 64];
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) acc[rt][ot] = mfma(a, bf[rt][kt], acc[rt][ot]);
                 }
@@ -277,6 +344,9 @@ __device__ __forceinline__ void ln_relu_keep(f32x4 (&acc)[8], const float* gam, 
 // per-lane accumulators, dz and dz*xhat (bf16) are fed back as A operands against a constant 0/1
 // selector B: D[r][n] = dz[r][feature 16ot+n], i.e. the tile comes back transposed (feature on the
 // lane, 4 rows in the registers) and 4 adds fold it into ONE accumulator per (tile, quantity).
+// NAT: the tile is in the natural fragment layout (d[2t+h][i], xh[t][4h+i] = feature 32t + 8g + 4h + i; gam / bet offset
+// by 8g; sel = the natural-layout selectors) and the Linear in front has been folded away: no d(bias).
+template <bool NAT = false>
 __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
                                             const float* bet, const bf16x8 (&sel)[2], float (&dgam)[8],
                                             float (&dbet)[8], float (&dbias)[8], bf16x8 (&out)[4]) {
@@ -289,8 +359,8 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4]
         for (int h = 0; h < 2; ++h) {
             const int ot = 2 * t + h;
             const f32x4 n = unpack_half(xh[t], h);
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * ot);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * ot);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + (NAT ? 32 * t + 4 * h : 16 * ot));
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + (NAT ? 32 * t + 4 * h : 16 * ot));
             const f32x4 y = n * gm + bt;
             dz[h].x = y.x > 0.0f ? d[ot].x : 0.0f;
             dz[h].y = y.y > 0.0f ? d[ot].y : 0.0f;
@@ -324,10 +394,12 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4]
         const f32x4 b = (d[2 * t + 1] - m1 - unpack_half(xh[t], 1) * m2) * rs;
         out[t] = pack8(a, b);
         // d(bias of the Linear in front) = column sums of d(a): same selector trick
+        if (!NAT) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 ta = mfma(out[t], sel[h], zero4);
-            dbias[2 * t + h] += (ta.x + ta.y) + (ta.z + ta.w);
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ta = mfma(out[t], sel[h], zero4);
+                dbias[2 * t + h] += (ta.x + ta.y) + (ta.z + ta.w);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -337,6 +409,9 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4]
 // One wave = 16 rows per iteration; one wave per SIMD (the chain needs ~380 registers incl. AGPRs).
 // Outputs h1, h2, da1, da2 are stored in FRAGMENT feature order: position 32t + 8g + j of a row
 // holds feature kperm(t, g, j) (16-byte stores); the caller un-permutes the small weight gradients.
+// L1 = false: see k_occ_mlp_fwd.  h1 is then stored in NATURAL feature order and grad_x is the gradient w.r.t. the
+// kernel's input = the folded Linear's output; grad_a1 is not written.
+template <bool L1>
 __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const __bf16* __restrict__ img, const float* __restrict__ vec,
                                                         __bf16* __restrict__ dx, __bf16* __restrict__ da1,
@@ -369,6 +444,12 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
     f32x4 dw3[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) dw3[ot] = zero4;
+    bf16x8 sel_nat[2];                               // natural layout: k-slot 8g+j holds feature 8g+j of the 32-block
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sel_nat[0][j] = (__bf16)((8 * g + j == c) ? 1.0f : 0.0f);
+        sel_nat[1][j] = (__bf16)((8 * g + j == c + 16) ? 1.0f : 0.0f);
+    }
     bf16x8 sel_cls;                                  // k-slot 8g'+j of the d(logits) fragment holds class 8g'+j (g' < 2)
 #pragma unroll
     for (int j = 0; j < 8; ++j) sel_cls[j] = (__bf16)((g < 2 && 8 * g + j == c) ? 1.0f : 0.0f);
@@ -386,17 +467,22 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) bf[kt] = ok ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * kt + 8 * g) : z8;
         f32x4 acc[8];
-        // ---- forward, layer 1
-        gemm8<true>(acc, fr, kF1, bf, sv_g);
-        __builtin_amdgcn_sched_barrier(0);
-        ln_relu_keep(acc, sv_g + kW, sv_g + 2 * kW, eps, bf, xh1, rs1);
+        const float* sv_n = sv + 8 * (lane_off >> 4);
+        // ---- forward, layer 1 (folded away: x is its output, LayerNorm in the natural layout)
+        if constexpr (L1) {
+            gemm8<true>(acc, fr, kF1, bf, sv_g);
+            __builtin_amdgcn_sched_barrier(0);
+            ln_relu_keep(acc, sv_g + kW, sv_g + 2 * kW, eps, bf, xh1, rs1);
+        } else {
+            ln_relu_nat<true>(bf, sv_n + kW, sv_n + 2 * kW, eps, xh1, rs1);
+        }
         if (ok) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(h1 + r * kW + 32 * t + 8 * g) = bf[t];
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- forward, layer 2
-        gemm8<true>(acc, fr, kF2, bf, sv_g + 3 * kW);
+        gemm8<true>(acc, fr, L1 ? kF2 : kF1, bf, sv_g + 3 * kW);
         __builtin_amdgcn_sched_barrier(0);
         ln_relu_keep(acc, sv_g + 4 * kW, sv_g + 5 * kW, eps, bf, xh2, rs2);
         __builtin_amdgcn_sched_barrier(0);
@@ -423,6 +509,27 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(da2 + r * kW + 32 * t + 8 * g) = bf[t];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!L1) {
+            // ---- d(h1)^T = W2^T d(a2)^T through section kB1 (natural-order output rows), LayerNorm 1 backward in the
+            // natural layout, and that is d(x)
+#pragma unroll
+            for (int mp = 0; mp < 4; ++mp) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 o = zero4;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) o = mfma(fr[(kB1 + (mp * 2 + t) * 4 + ks) * 64], bf[ks], o);
+                    acc[2 * mp + t] = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ln_relu_bwd<true>(acc, xh1, rs1, sv_n + kW, sv_n + 2 * kW, sel_nat, dgam[0], dbet[0], dbias[0], bf);
+            if (ok) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(dx + r * kW + 32 * t + 8 * g) = bf[t];
+            }
+            continue;
+        }
         // ---- d(h1)^T = W2^T d(a2)^T
         gemm8<false>(acc, fr, kB2, bf, nullptr);
         __builtin_amdgcn_sched_barrier(0);
@@ -498,7 +605,7 @@ extern "C" int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W
 }
 
 extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits, long N,
-                                   int width, int classes, float eps, void* stream) {
+                                   int width, int classes, float eps, int first_linear, void* stream) {
     int rc = check_common("ver_occ_mlp_forward", x, image, vectors, N, width, classes);
     if (rc) return rc;
     if (N == 0) return VER_OK;
@@ -506,19 +613,20 @@ extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float
     constexpr int RT = 4;
     const size_t lds = (size_t)kFwdFrags * 1024 + kVecFloats * sizeof(float);
     // (the attribute is per device: set it on every call, as ver_sca does -- it is a host-side table write)
-    hipError_t e = hipFuncSetAttribute((const void*)k_occ_mlp_fwd<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = first_linear ? k_occ_mlp_fwd<RT, true> : k_occ_mlp_fwd<RT, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 16 * RT - 1) / (16 * RT);
     long grid = (nblk + 3) / 4;
     if (grid > 512) grid = 512;                            // 2 workgroups per CU, persistent
-    hipLaunchKernelGGL(k_occ_mlp_fwd<RT>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const __bf16*)x,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const __bf16*)x,
                        (const __bf16*)image, vectors, (__bf16*)logits, N, eps);
     return ver_check_launch("ver_occ_mlp_forward");
 }
 
 extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
                                     void* grad_x, void* grad_a1, void* grad_a2, void* h1, float* param_grads, long N,
-                                    int width, int classes, float eps, void* stream) {
+                                    int width, int classes, float eps, int first_linear, void* stream) {
     int rc = check_common("ver_occ_mlp_backward", x, image, vectors, N, width, classes);
     if (rc) return rc;
     VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
@@ -526,15 +634,16 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW) * sizeof(float), st);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
-    VER_REQUIRE(grad_logits && grad_x && grad_a1 && grad_a2 && h1, VER_EINVAL,
+    VER_REQUIRE(grad_logits && grad_x && (grad_a1 || !first_linear) && grad_a2 && h1, VER_EINVAL,
                 "ver_occ_mlp_backward: null pointer argument");
     const size_t lds = (size_t)kAllFrags * 1024 + kVecFloats * sizeof(float);
-    e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = first_linear ? k_occ_mlp_bwd<true> : k_occ_mlp_bwd<false>;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 15) / 16;
     long grid = (nblk + 3) / 4;
     if (grid > 256) grid = 256;                            // one 4-wave workgroup per CU (LDS bound), persistent
-    hipLaunchKernelGGL(k_occ_mlp_bwd, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
                        (const __bf16*)grad_logits, (const __bf16*)image, vectors, (__bf16*)grad_x, (__bf16*)grad_a1,
                        (__bf16*)grad_a2, (__bf16*)h1, param_grads, N, eps);
     return ver_check_launch("ver_occ_mlp_backward");

@@ -203,13 +203,26 @@ class VoxelFormerOccupancyHead(BaseModule):
                     and 8 * self.bev_h == self.occ_xdim and 8 * self.bev_w == self.occ_ydim):
                 # lattice path: neither the dense volume nor its 3/4 constant columns are formed
                 e, b_up = upsample_lattice(x, [m.weight for m in convs], [m.bias for m in convs])
-                res = occ_proj_from_lattice(e, convs[-1].bias, self.occ_proj.weight, self.occ_proj.bias)
+                # ``occ_proj`` (:571) is followed by ``occ_branches[0]`` = Linear(128, 128) on every 128-slice of
+                # its output (:580) with nothing in between: on the fused bf16 path the two compose into ONE Linear,
+                # W' = (I_35 (x) W1) W_proj, b' = (I_35 (x) W1) b_proj + b1 (3.5 GFLOP per step, autograd maps the
+                # gradient of W' back onto both parameters), and the MLP kernels start at the first LayerNorm.
+                fold = self.fold_first_occ_linear and e.is_cuda and self._occ_mlp_runs_fused(e)
+                w_proj, b_proj = self.occ_proj.weight, self.occ_proj.bias
+                if fold:
+                    l1 = self.occ_branches[0]
+                    with torch.autocast('cuda', enabled=False):
+                        w_proj = torch.matmul(l1.weight.float(), w_proj.float().view(self.occ_zdim, self.occ_dims, -1)
+                                              ).view_as(w_proj)
+                        b_proj = torch.addmm(l1.bias.float(), b_proj.float().view(self.occ_zdim, self.occ_dims),
+                                             l1.weight.float().t()).view(-1)
+                res = occ_proj_from_lattice(e, convs[-1].bias, w_proj, b_proj)
                 if res is not None:
                     # ``occ_branches`` is row-wise: run it on the rows as the GEMMs left them
                     # (group-major) and bring only the 8x narrower logits into the reference's
                     # (Z, X, Y) voxel order (:572-579)
                     rows, plan = res
-                    logits = self._occ_mlp(rows.view(rows.shape[0], self.occ_zdim, self.occ_dims))
+                    logits = self._occ_mlp(rows.view(rows.shape[0], self.occ_zdim, self.occ_dims), first_folded=fold)
                     logits = rows_to_voxels(logits, plan, bs)                       # [bs, X*Y, Z, classes]
                     return logits.permute(0, 2, 1, 3).reshape(bs, -1, logits.shape[-1])
             x = self._upsample(x).contiguous()
@@ -241,21 +254,30 @@ class VoxelFormerOccupancyHead(BaseModule):
                 and all(tuple(m.normalized_shape) == (128,) and m.elementwise_affine and m.bias is not None
                         for m in (n1, n2)) and n1.eps == n2.eps)
 
-    def _occ_mlp(self, x):
+    fold_first_occ_linear = True      # (class switch for tests: compare against the unfolded fused path)
+
+    def _occ_mlp_runs_fused(self, x):
+        """True when ``_occ_mlp`` will take the fused MFMA kernels for this input (bf16 arithmetic)."""
+        return x.is_cuda and self._occ_mlp_is_fusable(list(self.occ_branches)) and (
+            x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
+                                          torch.get_autocast_dtype('cuda') == torch.bfloat16))
+
+    def _occ_mlp(self, x, first_folded=False):
         """``occ_branches`` (head:241-248).  On the GPU each LayerNorm(128)+ReLU pair is one fused
         HIP pass (``ver_ln_relu_*``); Linear layers are hipBLASLt GEMMs with a split-K weight
         gradient (``row_linear``).  Under bf16 autocast the vocc.py shape of the Sequential runs as
-        the fused MFMA kernels ``ver_occ_mlp_forward/backward`` instead."""
+        the fused MFMA kernels ``ver_occ_mlp_forward/backward`` instead.  ``first_folded``: x is already the
+        output of ``occ_branches[0]`` (folded into ``occ_proj`` by the caller; fused path only)."""
         mods = list(self.occ_branches)
-        if x.is_cuda and self._occ_mlp_is_fusable(mods) and (
-                x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
-                                              torch.get_autocast_dtype('cuda') == torch.bfloat16)):
+        if self._occ_mlp_runs_fused(x):
             # bf16 arithmetic (autocast): the whole Sequential is one MFMA kernel each way
             from ..hipops import occ_mlp
             l1, n1, _, l2, n2, _, l3 = mods
             with torch.autocast('cuda', enabled=False):
-                return occ_mlp(x.to(torch.bfloat16), l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias,
+                return occ_mlp(x.to(torch.bfloat16), None if first_folded else l1.weight,
+                               None if first_folded else l1.bias, n1.weight, n1.bias, l2.weight, l2.bias,
                                n2.weight, n2.bias, l3.weight, l3.bias, n1.eps)
+        assert not first_folded, 'only the fused occupancy MLP takes a folded first Linear'
         i = 0
         while i < len(mods):
             m = mods[i]

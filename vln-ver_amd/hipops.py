@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -508,8 +508,9 @@ def occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3):
     return vec.contiguous()
 
 
-def occ_mlp_forward(x, image, vectors, eps=1e-5):
-    """x bf16 [..., 128] -> logits bf16 [..., 16] (ver_occ_mlp_forward)."""
+def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True):
+    """x bf16 [..., 128] -> logits bf16 [..., 16] (ver_occ_mlp_forward).  ``first_linear=False``: x is already the
+    output of the first Linear (folded into its producer)."""
     x = _gpu(x, 'x')
     if x.dtype != torch.bfloat16 or x.shape[-1] != 128:
         raise TypeError('x must be bf16 [..., 128]')
@@ -517,7 +518,8 @@ def occ_mlp_forward(x, image, vectors, eps=1e-5):
     n = x.numel() // 128
     logits = torch.empty(x.shape[:-1] + (16,), dtype=torch.bfloat16, device=x.device)
     _launch('ver_occ_mlp_forward', lambda: lib().ver_occ_mlp_forward(
-        _p(x), _p(image), _p(vectors), _p(logits), ctypes.c_long(n), 128, 16, ctypes.c_float(eps), _stream()))
+        _p(x), _p(image), _p(vectors), _p(logits), ctypes.c_long(n), 128, 16, ctypes.c_float(eps),
+        1 if first_linear else 0, _stream()))
     return logits
 
 
@@ -566,11 +568,19 @@ class OccMLPFunction(Function):
     @staticmethod
     def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps):
         x = _gpu(x, 'x').contiguous()
+        # w1 is None: the first Linear was folded into the producer of x (two Linears in a row compose, see
+        # VoxelFormerOccupancyHead.occupancy_from_volume); the kernels then run it as the identity and its weight
+        # gradient -- a [128, N] x [N, 128] product over all rows -- is not formed here at all
+        ctx.folded = w1 is None
+        if ctx.folded:
+            # (the folded kernels read W2 from W1's image sections: natural k order forward, natural-order output rows
+            #  in the dgrad -- the layouts a chain that starts with a LayerNorm on the loaded rows needs)
+            w1, b1 = w2, torch.zeros(128, device=x.device)
         image = occ_mlp_pack(w1, w2, w3)
         vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
         ctx.save_for_backward(x, image, vec)
         ctx.eps = eps
-        return occ_mlp_forward(x, image, vec, eps)
+        return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded)
 
     @staticmethod
     @once_differentiable
@@ -580,18 +590,22 @@ class OccMLPFunction(Function):
         x2 = x.view(-1, 128)
         n = x2.shape[0]
         gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
-        gx, ga1, ga2, h1 = (torch.empty_like(x2) for _ in range(4))
+        gx, ga2, h1 = (torch.empty_like(x2) for _ in range(3))
+        ga1 = None if ctx.folded else torch.empty_like(x2)
         pg = torch.empty(6 * 128 + 16 * 128, dtype=torch.float32, device=x.device)
         _launch('ver_occ_mlp_backward', lambda: lib().ver_occ_mlp_backward(
-            _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1), _p(ga2), _p(h1), _p(pg),
-            ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _stream()))
+            _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1) if ga1 is not None else None, _p(ga2), _p(h1), _p(pg),
+            ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), 0 if ctx.folded else 1, _stream()))
         inv = _frag_order(x.device)
         vecs = pg[:768].view(6, 128)
         dw3 = pg[768:].view(16, 128)
         db3 = gl.sum(0, dtype=torch.float32)
         dw2, _ = _rows_tn(ga2, h1, with_colsum=False)
-        dw1, _ = _rows_tn(ga1, x2, with_colsum=False)
+        if ctx.folded:                               # h1 comes back in natural feature order
+            dw2 = dw2.index_select(0, inv)
+            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
         dw2 = dw2.index_select(0, inv).index_select(1, inv)
+        dw1, _ = _rows_tn(ga1, x2, with_colsum=False)
         dw1 = dw1.index_select(0, inv)
         return (gx.view(shape), dw1, vecs[2], vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
 

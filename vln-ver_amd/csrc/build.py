@@ -47,8 +47,8 @@ def build_hip(force=False, verbose=True, defines=(), lib=None):
     objs, procs = [], []
     for src in SOURCES:
         path = os.path.join(HERE, src)
-        # only the gather kernels take experiment defines
-        mytag = tag if (defines and src == 'ver_sca.hip') else ''
+        # experiment defines only rebuild the sources that mention them
+        mytag = tag if (defines and any(d.split('=')[0] in open(path).read() for d in defines)) else ''
         obj = os.path.join(OBJ_DIR, src.replace('.hip', mytag + '.o'))
         objs.append(obj)
         if force or _newer(obj, [path] + hdrs):

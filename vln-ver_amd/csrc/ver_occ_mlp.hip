@@ -411,8 +411,12 @@ __device__ __forceinline__ void ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4]
 // holds feature kperm(t, g, j) (16-byte stores); the caller un-permutes the small weight gradients.
 // L1 = false: see k_occ_mlp_fwd.  h1 is then stored in NATURAL feature order and grad_x is the gradient w.r.t. the
 // kernel's input = the folded Linear's output; grad_a1 is not written.
+#ifndef VER_MLP_BWD_WAVES
+#define VER_MLP_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = VER_MLP_BWD_WAVES;       // waves per workgroup (one workgroup per CU: the image fills the LDS)
 template <bool L1>
-__global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
+__global__ __launch_bounds__(kBwdWaves * 64) void k_occ_mlp_bwd(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const __bf16* __restrict__ img, const float* __restrict__ vec,
                                                         __bf16* __restrict__ dx, __bf16* __restrict__ da1,
                                                         __bf16* __restrict__ da2, __bf16* __restrict__ h1,
@@ -420,8 +424,8 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                       // [kAllFrags][64]
     float* sv = reinterpret_cast<float*>(smem + kAllFrags * 1024);
-    for (int i = threadIdx.x; i < kAllFrags * 64; i += 256) frag[i] = reinterpret_cast<const bf16x8*>(img)[i];
-    for (int i = threadIdx.x; i < kVecFloats; i += 256) sv[i] = vec[i];
+    for (int i = threadIdx.x; i < kAllFrags * 64; i += kBwdWaves * 64) frag[i] = reinterpret_cast<const bf16x8*>(img)[i];
+    for (int i = threadIdx.x; i < kVecFloats; i += kBwdWaves * 64) sv[i] = vec[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void k_occ_mlp_bwd(const __bf16* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) sel_cls[j] = (__bf16)((g < 2 && 8 * g + j == c) ? 1.0f : 0.0f);
     const long nblk = (N + 15) / 16;
-    for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
+    for (long blk = (long)blockIdx.x * kBwdWaves + wave; blk < nblk; blk += (long)gridDim.x * kBwdWaves) {
         int lane_off = lane;
         asm volatile("" : "+v"(lane_off));
         const bf16x8* fr = frag + lane_off;
@@ -641,9 +645,9 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 15) / 16;
-    long grid = (nblk + 3) / 4;
-    if (grid > 256) grid = 256;                            // one 4-wave workgroup per CU (LDS bound), persistent
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
+    long grid = (nblk + kBwdWaves - 1) / kBwdWaves;
+    if (grid > 256) grid = 256;                            // one workgroup per CU (LDS bound), persistent
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBwdWaves * 64), lds, st, (const __bf16*)x,
                        (const __bf16*)grad_logits, (const __bf16*)image, vectors, (__bf16*)grad_x, (__bf16*)grad_a1,
                        (__bf16*)grad_a2, (__bf16*)h1, param_grads, N, eps);
     return ver_check_launch("ver_occ_mlp_backward");

@@ -72,8 +72,9 @@ class LiftTrainer(torch.nn.Module):
             emb = self.head(feats, None, only_bev=True, world2pixel=w2p, origin=org)   # [bs,Nq,C]
             total = emb.new_zeros((), dtype=torch.float32)
             for s in range(0, bs, self.micro):
-                occ = self.head.occupancy_from_volume(emb[s:s + self.micro])
-                total = total + self.head.occupancy_loss(occ, gt[s:s + self.micro]) * occ.shape[0]
+                nb = min(self.micro, bs - s)
+                # (logits stay in the GEMMs' row order, the targets are permuted to match: same loss, same gradients)
+                total = total + self.head.occupancy_loss_from_volume(emb[s:s + nb], gt[s:s + nb]) * nb
         return total / bs
 
 

@@ -157,3 +157,32 @@ def test_vocc_head_bf16_backward_with_folded_first_linear():
         unfolded = rel_l2(grads['bf16_unfolded'][name], grads['fp32'][name])
         print(name, 'folded', folded, 'unfolded', unfolded)
         assert folded < max(1.25 * unfolded, 1e-2), (name, folded, unfolded)
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_occupancy_loss_in_row_order_equals_voxel_order(autocast):
+    """``occupancy_loss_from_volume`` (logits left in the GEMMs' row order, targets permuted to match) against
+    ``occupancy_loss(occupancy_from_volume(...))``: the same (logit row, target) pairs, so the same loss (up to the
+    order of an fp32 sum over 8 M terms) and the same gradients."""
+    syn = pkg('synthetic')
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gt = T(np.random.default_rng(5).integers(0, 17, size=(2, 504000))).to(DEV)
+    res = {}
+    for route in ('voxels', 'rows'):
+        head = _head(cases.vocc_head_cfg(), 7).train()
+        for m in head.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            emb = head(feats, None, only_bev=True, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+            if route == 'rows':
+                loss = head.occupancy_loss_from_volume(emb, gt)
+            else:
+                loss = head.occupancy_loss(head.occupancy_from_volume(emb), gt)
+        loss.backward()
+        res[route] = (float(loss), {k: p.grad.float().cpu() for k, p in head.named_parameters() if p.grad is not None})
+    assert abs(res['rows'][0] - res['voxels'][0]) <= 1e-5 * abs(res['voxels'][0]), (res['rows'][0], res['voxels'][0])
+    assert set(res['rows'][1]) == set(res['voxels'][1])
+    for k, g in res['voxels'][1].items():
+        assert rel_l2(res['rows'][1][k], g) < (2e-3 if autocast else 1e-5), k

@@ -265,3 +265,10 @@ def rows_to_voxels(x, plan, bs):
     """x [bs*Hf*Wf, ...] in the group-major row order -> [bs, Hf*Wf, ...] in (a, b) order."""
     fwd, inv = _row_index(plan, bs, x.device)
     return _SelectRows.apply(x, fwd, inv).view(bs, plan.rows, *x.shape[1:])
+
+
+def voxels_to_rows(x, plan, bs):
+    """Inverse of ``rows_to_voxels`` for tensors that need no gradient (targets): x [bs, Hf*Wf, ...] in (a, b) order ->
+    [bs*Hf*Wf, ...] in the group-major row order of the GEMM buffer."""
+    _, inv = _row_index(plan, bs, x.device)
+    return x.reshape(bs * plan.rows, *x.shape[2:]).index_select(0, inv)

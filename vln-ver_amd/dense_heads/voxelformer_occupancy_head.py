@@ -26,7 +26,7 @@ from . import coders, losses  # noqa: F401  (registers NMSFreeCoder / FocalLoss 
 from .assigner import SamplingResult, build_assigner
 from .coders import normalize_bbox
 from ..ddp import reduce_mean
-from .occ_proj_lattice import occ_proj_from_lattice, rows_to_voxels
+from .occ_proj_lattice import occ_proj_from_lattice, rows_to_voxels, voxels_to_rows
 from .row_linear import row_linear
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
@@ -190,9 +190,22 @@ class VoxelFormerOccupancyHead(BaseModule):
             return full_volume(e, b)
         return self.up_sample(x)
 
-    def occupancy_from_volume(self, voxel_embed):
+    def occupancy_loss_from_volume(self, voxel_embed, gt_occupancy):
+        """``occupancy_loss(occupancy_from_volume(voxel_embed), gt_occupancy)`` for training steps that need the loss
+        and not the logits: on the lattice path the logits stay in the row order the GEMMs left them in and the
+        TARGETS are brought into that order instead (an int64 per voxel instead of 16 logits, and no permutation in
+        the backward pass).  The loss is a sum over (logit row, target) pairs -- the same pairs, the same value."""
+        res = self.occupancy_from_volume(voxel_embed, rows_only=True)
+        if not isinstance(res, tuple):
+            return self.occupancy_loss(res, gt_occupancy)
+        logits, plan, bs = res                                           # [bs*X*Y, Z, classes], group-major rows
+        gt = gt_occupancy.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)       # (Z, X, Y) order -> [bs, X*Y, Z]
+        return self.occupancy_loss(logits, voxels_to_rows(gt, plan, bs))
+
+    def occupancy_from_volume(self, voxel_embed, rows_only=False):
         """voxel_embed [bs, Nq, C] (per-sample contiguous Nq*C buffer = the reference's
-        ``bev_embed`` at bs=1) -> occupancy logits [bs, X*Y*Z, classes]   (head:554-580)."""
+        ``bev_embed`` at bs=1) -> occupancy logits [bs, X*Y*Z, classes]   (head:554-580).
+        ``rows_only`` (lattice path): return ``(logits [bs*X*Y, Z, classes] in GEMM row order, plan, bs)`` instead."""
         bs = voxel_embed.shape[0]
         c = self.embed_dims
         voxel_embed = voxel_embed.contiguous()
@@ -223,6 +236,8 @@ class VoxelFormerOccupancyHead(BaseModule):
                     # (Z, X, Y) voxel order (:572-579)
                     rows, plan = res
                     logits = self._occ_mlp(rows.view(rows.shape[0], self.occ_zdim, self.occ_dims), first_folded=fold)
+                    if rows_only:
+                        return logits, plan, bs
                     logits = rows_to_voxels(logits, plan, bs)                       # [bs, X*Y, Z, classes]
                     return logits.permute(0, 2, 1, 3).reshape(bs, -1, logits.shape[-1])
             x = self._upsample(x).contiguous()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 17
+#define VER_ABI_VERSION 18
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -255,6 +255,23 @@ int ver_focal_loss_forward(const void* logits, const int64_t* target, float* par
                            float gamma, float alpha, int dtype, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Run copies between the channel-first even lattice and the rows of the gathered `occ_proj` operand
+ * (the reference's raw `.view(bs, Z, X, Y, C)` + `permute(0,2,3,1,4).flatten(3)` of the upsampled volume,
+ * dense_heads/voxelformer_occupancy_head.py:564-570, restricted to the columns that are not constants).
+ * A row (sample b, member i of a row group) is `runs` contiguous runs of `run_len` elements of sample b's image
+ * starting at run_start[i*runs + k], followed by n_aug single elements image[aug_idx[i*n_aug + j]]:
+ *   gather : rows[(b*n_rows + i)*row_elems + ...] <- image[b*image_stride + ...]       (forward operand)
+ *   scatter: image[b*image_stride + run_start[..] + o] <- rows[(b*n_rows + i)*row_elems + k*run_len + o]
+ *            (backward: every image element is written by exactly one row)
+ * dtype VER_F32 / VER_BF16; run_len, run starts, image_stride and row_elems multiples of 8 bytes.
+ */
+int ver_run_gather(const void* image, long image_stride, const int32_t* run_start, const int32_t* aug_idx,
+                   void* rows, int B, int n_rows, int runs, int run_len, int n_aug, int row_elems, int dtype,
+                   void* stream);
+int ver_run_scatter(const void* rows, void* image, long image_stride, const int32_t* run_start, int B,
+                    int n_rows, int runs, int run_len, int row_elems, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused occupancy MLP = the reference's `occ_branches` Sequential

@@ -738,6 +738,34 @@ def test_occ_mlp_fused_with_folded_first_linear():
                                first_linear=False).shape == (0, 16)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_run_gather_scatter_equal_index_select(dtype):
+    """ver_run_gather / ver_run_scatter (the gathered occ_proj operand as run copies) vs torch.index_select /
+    index_copy_ through the plan's index tables, bit for bit, on the vocc.py geometry."""
+    hip = pkg('hipops')
+    opl = pkg('dense_heads.occ_proj_lattice')
+    plan = opl.get_plan(768, 4, 120, 120, torch.device(DEV))
+    L, C, bs = plan.lattice_size, plan.C, 2
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    lat = torch.randn(bs, (L + C + 2 + 7) // 8 * 8, generator=gen).to(dtype).to(DEV)
+    for g in plan.groups[:3]:
+        assert g.run_len > 0
+        want = lat.index_select(1, g.gather_aug).view(bs * g.n_rows, g.k_aug)
+        got = torch.full_like(want, float('nan'))
+        hip.run_gather(lat, g.run_start, g.aug_idx, got, g.n_rows, g.run_len)
+        assert torch.equal(got, want)
+        d_data = torch.randn(bs * g.n_rows, g.n_cols, generator=gen).to(dtype).to(DEV)
+        ref = torch.zeros(bs, L, dtype=dtype, device=DEV)
+        ref.index_copy_(1, g.scatter, d_data.view(bs, -1))
+        out = torch.zeros(bs, L, dtype=dtype, device=DEV)
+        hip.run_scatter(d_data, out, g.run_start, g.n_rows, g.run_len)
+        assert torch.equal(out, ref)
+    with pytest.raises(RuntimeError):                      # run length not a multiple of 8 bytes
+        hip.run_gather(lat, plan.groups[0].run_start, plan.groups[0].aug_idx,
+                       torch.empty(bs * plan.groups[0].n_rows, plan.groups[0].k_aug, dtype=dtype, device=DEV),
+                       plan.groups[0].n_rows, 181)
+
+
 # ------------------------------------------------------------------------------- next row 2: occupancy loss
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('gamma,alpha', [(2.0, 0.25), (1.5, 0.4)])

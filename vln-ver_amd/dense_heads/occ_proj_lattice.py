@@ -106,6 +106,19 @@ def _device_plan(plan, device):
         idx[:, d.n_cols + Z] = L + C
         d.gather_aug = t(idx.reshape(-1))
         d.scatter = t(g.gather.reshape(-1))           # lattice position of every data element
+        # run structure of the data columns (R equal runs of contiguous lattice elements per row -- one per token
+        # of the raw view): the HIP run copies (ver_run_gather / ver_run_scatter) replace index_select / index_copy_
+        d.run_len = 0
+        brk = np.nonzero(np.diff(g.gather[0]) != 1)[0] + 1
+        starts = np.concatenate([[0], brk])
+        lens = np.diff(np.concatenate([starts, [d.n_cols]]))
+        if len(set(lens.tolist())) == 1 and lens[0] % 4 == 0 and d.n_cols % 4 == 0:
+            rl = int(lens[0])
+            ok = bool((g.gather.reshape(d.n_rows, -1, rl) == g.gather[:, ::rl][:, :, None] + np.arange(rl)).all())
+            if ok and bool((g.gather[:, ::rl] % 4 == 0).all()):
+                d.run_len = rl
+                d.run_start = torch.from_numpy(np.ascontiguousarray(g.gather[:, ::rl]).astype(np.int32)).to(device)
+                d.aug_idx = torch.from_numpy(np.ascontiguousarray(idx[:, d.n_cols:]).astype(np.int32)).to(device)
         d.cols = t(g.cols)
         d.ncols_by_token = [t(n) for n in g.ncols_by_token]
         d.chan = t(g.chan.reshape(-1))
@@ -159,9 +172,10 @@ class _OccProjLattice(torch.autograd.Function):
         dt = e.dtype
         out_dim = weight.shape[0]
         L = plan.lattice_size
-        lat = torch.empty(bs, L + C + 2, dtype=dt, device=e.device)
+        lat = torch.empty(bs, (L + C + 2 + 7) // 8 * 8, dtype=dt, device=e.device)       # (rows 16-byte aligned)
         lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                                # channel-first lattice
-        if e.is_cuda and dt in (torch.float32, torch.bfloat16):
+        use_hip = e.is_cuda and dt in (torch.float32, torch.bfloat16)
+        if use_hip:
             from ..hipops import lattice_transpose
             lattice_transpose(e.contiguous(), lat, (Hl, Wl), layout, True)
         else:
@@ -174,7 +188,12 @@ class _OccProjLattice(torch.autograd.Function):
         out = torch.empty(bs * plan.rows, out_dim, dtype=dt, device=e.device)
         operands, weights = [], []
         for g in plan.groups:
-            a = lat.index_select(1, g.gather_aug).view(bs * g.n_rows, g.k_aug)
+            if use_hip and g.run_len:
+                from ..hipops import run_gather
+                a = torch.empty(bs * g.n_rows, g.k_aug, dtype=dt, device=e.device)
+                run_gather(lat, g.run_start, g.aug_idx, a, g.n_rows, g.run_len)
+            else:
+                a = lat.index_select(1, g.gather_aug).view(bs * g.n_rows, g.k_aug)
             # W_aug^T [out, k_aug] = data columns | summed constant columns per token | bias | 0
             s = torch.stack([weight.index_select(1, n).sum(1) for n in g.ncols_by_token], 1)      # [out, Z] fp32
             pad = g.k_aug - g.n_cols - Z - 1
@@ -205,7 +224,11 @@ class _OccProjLattice(torch.autograd.Function):
             go = grad_out[bs * g.offset: bs * (g.offset + g.n_rows)]
             # d(operand): data columns go back to their lattice positions (each written exactly once)
             d_data = torch.mm(go, wa[:, :g.n_cols])                                  # [bs*n_rows, n_cols]
-            d_lat.index_copy_(1, g.scatter, d_data.view(bs, g.n_rows * g.n_cols))
+            if d_lat.is_cuda and g.run_len and dt in (torch.float32, torch.bfloat16):
+                from ..hipops import run_scatter
+                run_scatter(d_data, d_lat, g.run_start, g.n_rows, g.run_len)
+            else:
+                d_lat.index_copy_(1, g.scatter, d_data.view(bs, g.n_rows * g.n_cols))
             d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())         # [bs*n_rows, Z]
             d_up.index_add_(0, g.chan, d_const.view(bs, -1).sum(0, dtype=acc))
             # d(W_aug^T) = go^T a

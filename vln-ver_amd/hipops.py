@@ -13,14 +13,15 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter',
-           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose')
+           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
+           'ver_run_scatter')
 
 _lib = None
 
@@ -362,6 +363,34 @@ def lattice_transpose(channels_last, channel_first, combined_hw, layout, to_chan
     _launch('ver_lattice_transpose', lambda: lib().ver_lattice_transpose(
         _p(cl), _p(cf), ctypes.c_long(cf.shape[1]), B, Z, H, W, C, int(layout), int(to_channel_first), dt,
         _stream()))
+
+
+def run_gather(image, run_start, aug_idx, rows, n_rows, run_len):
+    """ver_run_gather (no autograd): image [B, stride] -> rows [B*n_rows, row_elems]; run_start int32 [n_rows, runs],
+    aug_idx int32 [n_rows, n_aug] (indices into a sample's image row)."""
+    img, out = _gpu(image, 'image'), _gpu(rows, 'rows')
+    if not (img.is_contiguous() and out.is_contiguous() and img.dtype == out.dtype):
+        raise ValueError('run_gather: contiguous buffers of one dtype required')
+    if img.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('run_gather: fp32 or bf16')
+    B = img.shape[0]
+    runs, n_aug = run_start.shape[1], aug_idx.shape[1]
+    _launch('ver_run_gather', lambda: lib().ver_run_gather(
+        _p(img), ctypes.c_long(img.shape[1]), _p(run_start), _p(aug_idx), _p(out), B, n_rows, runs, run_len, n_aug,
+        out.shape[1], 1 if img.dtype == torch.bfloat16 else 0, _stream()))
+
+
+def run_scatter(rows, image, run_start, n_rows, run_len):
+    """ver_run_scatter (no autograd): rows [B*n_rows, row_elems] -> the runs of image [B, stride]."""
+    src, img = _gpu(rows, 'rows'), _gpu(image, 'image')
+    if not (img.is_contiguous() and src.is_contiguous() and img.dtype == src.dtype):
+        raise ValueError('run_scatter: contiguous buffers of one dtype required')
+    if img.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('run_scatter: fp32 or bf16')
+    B = img.shape[0]
+    _launch('ver_run_scatter', lambda: lib().ver_run_scatter(
+        _p(src), _p(img), ctypes.c_long(img.shape[1]), _p(run_start), B, n_rows, run_start.shape[1], run_len,
+        src.shape[1], 1 if img.dtype == torch.bfloat16 else 0, _stream()))
 
 
 def _tap_args(taps, col_offset):

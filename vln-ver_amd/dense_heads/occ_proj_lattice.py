@@ -109,10 +109,10 @@ def _device_plan(plan, device):
         # run structure of the data columns (R equal runs of contiguous lattice elements per row -- one per token
         # of the raw view): the HIP run copies (ver_run_gather / ver_run_scatter) replace index_select / index_copy_
         d.run_len = 0
-        brk = np.nonzero(np.diff(g.gather[0]) != 1)[0] + 1
+        brk = np.nonzero(np.diff(g.gather[0]) != 1)[0] + 1 if d.n_cols and d.n_rows else np.zeros(0, dtype=np.int64)
         starts = np.concatenate([[0], brk])
         lens = np.diff(np.concatenate([starts, [d.n_cols]]))
-        if len(set(lens.tolist())) == 1 and lens[0] % 4 == 0 and d.n_cols % 4 == 0:
+        if d.n_cols and d.n_rows and len(set(lens.tolist())) == 1 and lens[0] % 4 == 0 and d.n_cols % 4 == 0:
             rl = int(lens[0])
             ok = bool((g.gather.reshape(d.n_rows, -1, rl) == g.gather[:, ::rl][:, :, None] + np.arange(rl)).all())
             if ok and bool((g.gather[:, ::rl] % 4 == 0).all()):

@@ -90,8 +90,8 @@ class FullTrainer(torch.nn.Module):
 
     def forward(self, feats, w2p, org, gt, gt_boxes, gt_labels):
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.autocast):
-            outs = self.head(feats, None, world2pixel=w2p, origin=org)
-        outs = {k: (v.float() if torch.is_tensor(v) else v) for k, v in outs.items()}
+            outs = self.head(feats, None, world2pixel=w2p, origin=org, occupancy_rows=True)
+        outs = {k: (v.float() if torch.is_tensor(v) and k != 'occupancy_preds' else v) for k, v in outs.items()}
         losses = self.head.loss(gt_boxes, gt_labels, gt, outs)
         return sum(losses.values())
 

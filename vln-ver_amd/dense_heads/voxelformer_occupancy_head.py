@@ -195,12 +195,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         and not the logits: on the lattice path the logits stay in the row order the GEMMs left them in and the
         TARGETS are brought into that order instead (an int64 per voxel instead of 16 logits, and no permutation in
         the backward pass).  The loss is a sum over (logit row, target) pairs -- the same pairs, the same value."""
-        res = self.occupancy_from_volume(voxel_embed, rows_only=True)
-        if not isinstance(res, tuple):
-            return self.occupancy_loss(res, gt_occupancy)
-        logits, plan, bs = res                                           # [bs*X*Y, Z, classes], group-major rows
-        gt = gt_occupancy.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)       # (Z, X, Y) order -> [bs, X*Y, Z]
-        return self.occupancy_loss(logits, voxels_to_rows(gt, plan, bs))
+        return self.occupancy_loss(self.occupancy_from_volume(voxel_embed, rows_only=True), gt_occupancy)
 
     def occupancy_from_volume(self, voxel_embed, rows_only=False):
         """voxel_embed [bs, Nq, C] (per-sample contiguous Nq*C buffer = the reference's
@@ -310,11 +305,13 @@ class VoxelFormerOccupancyHead(BaseModule):
         return x
 
     # ------------------------------------------------------------------ forward
-    def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, **kwargs):
+    def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, occupancy_rows=False, **kwargs):
         """mlvl_feats [Ncam, bs, Nk, C] (the detector's (6,1,196,768)); img_metas: per-sample
         meta dicts (``sample_idx`` -> camera files, or inline ``world2pixel``/``origin``).
         Extra kwargs (``world2pixel``, ``origin`` device tensors) bypass the metas.
-        Returns the reference's dict (head:615-625)."""
+        Returns the reference's dict (head:615-625).  ``occupancy_rows`` (training steps that only feed ``loss``):
+        ``occupancy_preds`` may come back as ``(logits in GEMM row order, plan, bs)``, which ``occupancy_loss`` takes
+        as it is (targets permuted instead of logits, see ``occupancy_loss_from_volume``)."""
         num_cam, bs = mlvl_feats.shape[:2]
         dtype = mlvl_feats.dtype
         voxel_queries = self.voxel_embedding.weight.to(dtype)
@@ -339,7 +336,8 @@ class VoxelFormerOccupancyHead(BaseModule):
             reg_branches=self.reg_branches if self.with_box_refine else None,
             cls_branches=None, **common)
         # bev_embed [Nq,bs,C] is a permuted view of the contiguous [bs,Nq,C] encoder output
-        occupancy = None if self.only_det else self.occupancy_from_volume(bev_embed.permute(1, 0, 2))
+        occupancy = None if self.only_det else self.occupancy_from_volume(bev_embed.permute(1, 0, 2),
+                                                                          rows_only=occupancy_rows)
         hs = hs.permute(0, 2, 1, 3)
         classes, coords = [], []
         for lvl in range(hs.shape[0]):
@@ -377,6 +375,10 @@ class VoxelFormerOccupancyHead(BaseModule):
         """Occupancy term of ``loss_single`` (head:977-989): sigmoid focal loss over
         [N, classes] logits with integer targets in [0, classes] (``classes`` = empty voxel),
         normalised by the number of occupied voxels, NaN-guarded."""
+        if isinstance(occupancy_preds, tuple):                         # (logits in GEMM row order, plan, bs)
+            occupancy_preds, plan, bs = occupancy_preds               # [bs*X*Y, Z, classes], group-major rows
+            gt = gt_occupancy.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)   # (Z, X, Y) order -> [bs, X*Y, Z]
+            gt_occupancy = voxels_to_rows(gt, plan, bs)
         preds = occupancy_preds.reshape(-1, self.occupancy_classes)
         if not (preds.is_cuda and preds.dtype == torch.bfloat16):     # the fused loss reads bf16 as is
             preds = preds.float()

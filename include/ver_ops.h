@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 18
+#define VER_ABI_VERSION 19
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -297,11 +297,11 @@ int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, 
  *     grad_x  bf16 [N,128]                      d loss / d x
  *     grad_a1, grad_a2 bf16 [N,128]             gradients w.r.t. the outputs of Linear 1 / Linear 2
  *     h1      bf16 [N,128]                      input of Linear 2 (post-ReLU activation)
- *     param_grads f32 [6*128 + 16*128]          d gamma1, d beta1, d b1, d gamma2, d beta2, d b2, then
- *                                               d W3 [16,128] (accumulated in-kernel); zeroed inside
+ *     param_grads f32 [6*128 + 16*128 + 16]     d gamma1, d beta1, d b1, d gamma2, d beta2, d b2, then
+ *                                               d W3 [16,128] and d b3 [16] (accumulated in-kernel); zeroed inside
  *   grad_a*, h1 are stored in FRAGMENT feature order: column 32t + 8g + j of a row holds feature
  *   32t + (j < 4 ? 4g + j : 16 + 4g + j - 4); the caller forms dW2 = grad_a2^T h1, dW1 = grad_a1^T x
- *   (and d b3 = column sums of grad_logits) from them and un-permutes.
+ *   from them and un-permutes.
  */
 int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* image, const float* vectors,
                          void* grad_x, void* grad_a1, void* grad_a2, void* h1,

@@ -448,6 +448,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_occ_mlp_bwd(const __bf16* __
     f32x4 dw3[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) dw3[ot] = zero4;
+    float db3 = 0.0f;                                // d(b3)[class c] = column sums of d(logits), rows 4g..4g+3 of every block
     bf16x8 sel_nat[2];                               // natural layout: k-slot 8g+j holds feature 8g+j of the 32-block
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_occ_mlp_bwd(const __bf16* __
         const bf16x8 dl = (ok && g < 2) ? *reinterpret_cast<const bf16x8*>(dlog + r * kC + 8 * g) : z8;
         {   // d(W3) += d(logits)^T h2 for this row tile
             const f32x4 tdl = mfma(dl, sel_cls, zero4);                       // [row 4g+i][class c]
+            db3 += (tdl.x + tdl.y) + (tdl.z + tdl.w);
             const bf16x8 a3 = pack8(tdl, zero4);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -575,11 +577,14 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_occ_mlp_bwd(const __bf16* __
                 atomicAdd(pgrad + (3 * l + 2) * kW + 16 * ot + c, d);
             }
         }
-    // ---- d(W3) [16][128] behind the six vectors
+    // ---- d(W3) [16][128] behind the six vectors, then d(b3) [16]
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot)
 #pragma unroll
         for (int i = 0; i < 4; ++i) atomicAdd(pgrad + 6 * kW + (4 * g + i) * kW + 16 * ot + c, dw3[ot][i]);
+    db3 += xor16(db3);
+    db3 += xor32(db3);
+    if (g == 0) atomicAdd(pgrad + 6 * kW + kC * kW + c, db3);            // (c < 16 = classes)
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -635,7 +640,7 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     if (rc) return rc;
     VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW) * sizeof(float), st);
+    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW + kC) * sizeof(float), st);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(grad_logits && grad_x && (grad_a1 || !first_linear) && grad_a2 && h1, VER_EINVAL,

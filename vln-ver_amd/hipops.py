@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -621,14 +621,14 @@ class OccMLPFunction(Function):
         gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
         gx, ga2, h1 = (torch.empty_like(x2) for _ in range(3))
         ga1 = None if ctx.folded else torch.empty_like(x2)
-        pg = torch.empty(6 * 128 + 16 * 128, dtype=torch.float32, device=x.device)
+        pg = torch.empty(6 * 128 + 16 * 128 + 16, dtype=torch.float32, device=x.device)
         _launch('ver_occ_mlp_backward', lambda: lib().ver_occ_mlp_backward(
             _p(x2), _p(gl), _p(image), _p(vec), _p(gx), _p(ga1) if ga1 is not None else None, _p(ga2), _p(h1), _p(pg),
             ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), 0 if ctx.folded else 1, _stream()))
         inv = _frag_order(x.device)
         vecs = pg[:768].view(6, 128)
-        dw3 = pg[768:].view(16, 128)
-        db3 = gl.sum(0, dtype=torch.float32)
+        dw3 = pg[768:768 + 2048].view(16, 128)
+        db3 = pg[768 + 2048:]
         dw2, _ = _rows_tn(ga2, h1, with_colsum=False)
         if ctx.folded:                               # h1 comes back in natural feature order
             dw2 = dw2.index_select(0, inv)

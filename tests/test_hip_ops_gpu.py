@@ -526,18 +526,20 @@ def test_convt_weight_taps_and_lattice_transpose(dtype):
     got.backward(g.to(DEV))
     want_g = g.float().view(3, 5, 5, 24, 40).permute(3, 4, 0, 1, 2).flip(2, 3, 4)
     assert torch.equal(wd.grad.cpu(), want_g)
-    b, z, h, wl, c = 2, 4, 6, 10, 200                      # C not a multiple of the 128-channel tile
-    plain = torch.randn(b, z, h, wl, c, generator=gen).to(dtype)
-    L = c * z * h * wl
-    for layout in (0, 1, 2, 3):                            # plain, planar, z-split, planar z-split
-        src = ups._from_plain(plain, layout)
-        cf = torch.full((b, L + 5), 3.0, dtype=dtype, device=DEV)
-        hip.lattice_transpose(src.to(DEV), cf, (h, wl), layout, True)
-        assert torch.equal(cf[:, :L].cpu().view(b, c, z, h, wl), plain.permute(0, 4, 1, 2, 3))
-        assert bool((cf[:, L:] == 3.0).all())
-        back = torch.empty_like(src, device=DEV)
-        hip.lattice_transpose(back, cf, (h, wl), layout, False)
-        assert torch.equal(back.cpu(), src)
+    # C not a multiple of the 128-channel tile; (W = 10, odd row stride): element-wise kernel,
+    # (W = 12, stride a multiple of 8): the 16-byte / 8-byte vector kernel
+    for (b, z, h, wl, c, tail) in ((2, 4, 6, 10, 200, 5), (2, 4, 6, 12, 200, 8)):
+        plain = torch.randn(b, z, h, wl, c, generator=gen).to(dtype)
+        L = c * z * h * wl
+        for layout in (0, 1, 2, 3):                        # plain, planar, z-split, planar z-split
+            src = ups._from_plain(plain, layout)
+            cf = torch.full((b, L + tail), 3.0, dtype=dtype, device=DEV)
+            hip.lattice_transpose(src.to(DEV), cf, (h, wl), layout, True)
+            assert torch.equal(cf[:, :L].cpu().view(b, c, z, h, wl), plain.permute(0, 4, 1, 2, 3))
+            assert bool((cf[:, L:] == 3.0).all())
+            back = torch.empty_like(src, device=DEV)
+            hip.lattice_transpose(back, cf, (h, wl), layout, False)
+            assert torch.equal(back.cpu(), src)
 
 
 def test_upsample_on_gpu_matches_conv_transpose():

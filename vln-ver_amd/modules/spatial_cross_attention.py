@@ -19,6 +19,7 @@ import warnings
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import hipops
 from ..registry import ATTENTION, build_attention
@@ -86,8 +87,13 @@ class SpatialCrossAttention(BaseModule):
         # [Ncam,Nk,bs,C] -> [bs,Ncam,Nk,C]; a no-copy view when the caller built it that way
         v = att.value_proj(value.permute(2, 0, 1, 3))
         v = v.reshape(bs, num_cams, nk, att.num_heads, c // att.num_heads)
-        offsets = att.sampling_offsets(query).view(bs, num_query, att.num_heads, att.num_points, 2)
-        logits = att.attention_weights(query).view(bs, num_query, att.num_heads, att.num_points)
+        # sampling_offsets and attention_weights read the same rows: one GEMM [.., C] x [C, 128 + 64] (and one cast of
+        # the query under autocast) instead of two narrow ones; the parameters stay the reference's two Linears
+        n_off = att.sampling_offsets.out_features
+        both = F.linear(query, torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0),
+                        torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
+        offsets = both[..., :n_off].reshape(bs, num_query, att.num_heads, att.num_points, 2)
+        logits = both[..., n_off:].reshape(bs, num_query, att.num_heads, att.num_points)
         slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1])
         slots = self.output_proj(slots.to(query.dtype))
         return self.dropout(slots) + inp_residual

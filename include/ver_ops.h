@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 19
+#define VER_ABI_VERSION 20
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -255,6 +255,29 @@ int ver_focal_loss_forward(const void* logits, const int64_t* target, float* par
                            float gamma, float alpha, int dtype, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * y = LayerNorm(residual + dropout(a)): how both branches of the reference's VoxelFormerLayer end
+ * (voxel_encoder.py:344-464 with operation_order cross_attn - norm - ffn - norm; SpatialCrossAttention.forward
+ * returns `dropout(output_proj(slots)) + residual`, spatial_cross_attention.py:173-176; mmcv FFN returns
+ * `identity + dropout(layers(x))`; a LayerNorm over C = embed_dims follows), one pass each way.
+ *   a [N,C] f32 or bf16 (a_dtype), residual f32 [N,C], gamma / beta f32 [C]; C in {256, 512, 768, 1024}
+ *   dropout: element i is kept iff hash(seed[0], i) < 1 - p_drop (seed: device int64; the backward pass recomputes
+ *            the decision -- no mask tensor), kept values scaled by 1 / (1 - p_drop); p_drop = 0: no dropout, seed
+ *            may be NULL.  (The reference's nn.Dropout draws from torch's generator: same distribution, different
+ *            stream; parity vectors are taken in eval mode.)
+ *   forward : y f32 [N,C], y_bf16 (optional, NULL to skip: the copy the next Linear reads under bf16 autocast),
+ *             mean, rstd f32 [N]
+ *   backward: grad_y f32 (+ grad_y_bf16, optional: the gradient that arrived through y_bf16) ->
+ *             grad_a (a's dtype), grad_residual f32, grad_gamma / grad_beta f32 [C] (zeroed inside)
+ */
+int ver_add_ln_forward(const void* a, int a_dtype, const float* residual, const float* gamma, const float* beta,
+                       const int64_t* seed, float p_drop, float eps, float* y, void* y_bf16, float* mean,
+                       float* rstd, long N, int C, void* stream);
+int ver_add_ln_backward(const float* grad_y, const void* grad_y_bf16, const void* a, int a_dtype,
+                        const float* residual, const float* gamma, const float* mean, const float* rstd,
+                        const int64_t* seed, float p_drop, void* grad_a, float* grad_residual, float* grad_gamma,
+                        float* grad_beta, long N, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Run copies between the channel-first even lattice and the rows of the gathered `occ_proj` operand

@@ -831,3 +831,46 @@ def test_voxel_msda_forward_backward(name):
     far = torch.full_like(loc, 3.0)
     assert float(hip.voxel_msda(value.detach(), T(c['shapes']).to(DEV), T(c['level_start']).to(DEV), far,
                                 w.detach()).abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------- a7: residual + dropout + LayerNorm
+@pytest.mark.parametrize('adtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_add_dropout_layer_norm_fused(adtype, p_drop):
+    """ver_add_ln_*: y = LayerNorm(residual + dropout(a)) (the tail of both branches of a VoxelFormerLayer,
+    voxel_encoder.py:344-464) vs torch.  With dropout the kept set is read off d(a) (zero exactly where an element was
+    dropped), which also checks that the backward pass recomputes the forward's decisions."""
+    hip = pkg('hipops')
+    F = torch.nn.functional
+    gen = torch.Generator(device='cpu').manual_seed(31)
+    n, c = 777, 768
+    a = torch.randn(n, c, generator=gen).to(adtype)
+    res = torch.randn(n, c, generator=gen)
+    gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.1
+    gy = torch.randn(n, c, generator=gen)
+    gy16 = (torch.randn(n, c, generator=gen) * 0.5).bfloat16()
+    ad, rd = a.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    y, y16 = hip.add_dropout_layer_norm(ad, rd, gd, bd, p_drop, 1e-5, want_bf16=True)
+    assert y.dtype == torch.float32 and y16.dtype == torch.bfloat16
+    assert torch.equal(y16, y.detach().bfloat16())
+    torch.autograd.backward([y, y16], [gy.to(DEV), gy16.to(DEV)])
+    keep = (ad.grad != 0).float().cpu() if p_drop > 0 else torch.ones(n, c)
+    if p_drop > 0:
+        assert abs(float(keep.mean()) - (1 - p_drop)) < 5e-3
+    ar, rr = a.double().requires_grad_(True), res.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    x = rr + ar * keep.double() / (1 - p_drop)
+    ref = F.layer_norm(x, (c,), gr, br, 1e-5)
+    ref.backward(gy.double() + gy16.double())
+    assert maxdiff(y.detach().cpu(), ref.detach().float()) < 2e-5
+    tol = 2e-2 if adtype == torch.bfloat16 else 1e-4
+    assert close(ad.grad.float().cpu(), ar.grad.float(), atol=tol, rtol=tol)
+    assert close(rd.grad.cpu(), rr.grad.float(), atol=1e-4, rtol=1e-4)
+    assert close(gd.grad.cpu(), gr.grad.float(), atol=2e-3, rtol=1e-4)
+    assert close(bd.grad.cpu(), br.grad.float(), atol=2e-3, rtol=1e-4)
+    # no bf16 copy requested / empty input
+    y2, none = hip.add_dropout_layer_norm(ad.detach(), rd.detach(), gd.detach(), bd.detach(), 0.0, 1e-5, want_bf16=False)
+    assert none is None and y2.shape == (n, c)
+    e, _ = hip.add_dropout_layer_norm(torch.zeros(0, c, device=DEV), torch.zeros(0, c, device=DEV), gd.detach(), bd.detach())
+    assert e.shape == (0, c)

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -21,7 +21,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
-           'ver_run_scatter')
+           'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward')
 
 _lib = None
 
@@ -641,6 +641,62 @@ class OccMLPFunction(Function):
 
 def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5):
     return OccMLPFunction.apply(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps)
+
+
+# ------------------------------------------------------------------------------------------
+class AddDropoutLayerNormFunction(Function):
+    """y = LayerNorm(residual + dropout(a)) as one pass each way (ver_add_ln_*): the tail of both branches of an
+    encoder layer.  Returns (y fp32, y_bf16 or None): the bf16 copy is what the next Linear reads under autocast."""
+
+    @staticmethod
+    def forward(ctx, a, residual, gamma, beta, p_drop, eps, want_bf16):
+        a = _gpu(a, 'a')
+        if a.dtype not in (torch.float32, torch.bfloat16):
+            a = a.float()
+        a = a.contiguous()
+        res = _gpu(residual, 'residual').float().contiguous()
+        C = a.shape[-1]
+        n = a.numel() // C
+        y = torch.empty_like(res)
+        y16 = torch.empty(res.shape, dtype=torch.bfloat16, device=res.device) if want_bf16 else None
+        mean = torch.empty(n, dtype=torch.float32, device=res.device)
+        rstd = torch.empty_like(mean)
+        seed = torch.randint(0, 2 ** 62, (1,), device=res.device, dtype=torch.int64) if p_drop > 0 else None
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        _launch('ver_add_ln_forward', lambda: lib().ver_add_ln_forward(
+            _p(a), 1 if a.dtype == torch.bfloat16 else 0, _p(res), _p(g), _p(b), _p(seed) if seed is not None else None,
+            ctypes.c_float(p_drop), ctypes.c_float(eps), _p(y), _p(y16) if y16 is not None else None, _p(mean), _p(rstd),
+            ctypes.c_long(n), C, _stream()))
+        ctx.save_for_backward(a, res, g, mean, rstd, seed if seed is not None else torch.empty(0, device=res.device))
+        ctx.p_drop, ctx.has_y16 = p_drop, want_bf16
+        if want_bf16:
+            return y, y16
+        return y, None
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y, grad_y16):
+        a, res, g, mean, rstd, seed = ctx.saved_tensors
+        C = a.shape[-1]
+        n = a.numel() // C
+        gy = (torch.zeros_like(res) if grad_y is None else _gpu(grad_y, 'grad_y').float().contiguous())
+        gy16 = None
+        if ctx.has_y16 and grad_y16 is not None:
+            gy16 = _gpu(grad_y16, 'grad_y_bf16').to(torch.bfloat16).contiguous()
+        d_a = torch.empty_like(a)
+        d_res = torch.empty_like(res)
+        dg = torch.empty(C, dtype=torch.float32, device=res.device)
+        db = torch.empty_like(dg)
+        _launch('ver_add_ln_backward', lambda: lib().ver_add_ln_backward(
+            _p(gy), _p(gy16) if gy16 is not None else None, _p(a), 1 if a.dtype == torch.bfloat16 else 0, _p(res), _p(g),
+            _p(mean), _p(rstd), _p(seed) if ctx.p_drop > 0 else None, ctypes.c_float(ctx.p_drop), _p(d_a), _p(d_res),
+            _p(dg), _p(db), ctypes.c_long(n), C, _stream()))
+        return d_a, d_res, dg, db, None, None, None
+
+
+def add_dropout_layer_norm(a, residual, gamma, beta, p_drop=0.0, eps=1e-5, want_bf16=False):
+    """(y fp32, y_bf16 | None) = LayerNorm(residual + dropout(a)); C = a.shape[-1] in {256, 512, 768, 1024}."""
+    return AddDropoutLayerNormFunction.apply(a, residual, gamma, beta, float(p_drop), float(eps), bool(want_bf16))
 
 
 # ------------------------------------------------------------------------------------------

@@ -2,7 +2,9 @@
 behaviour of mmcv-full 1.4.0; mmcv is not vendored by the
 reference).  Parameter names are the compatibility surface: ``layers.0.0.*``, ``layers.1.*``."""
 import copy
+import os
 
+import torch
 import torch.nn as nn
 
 from ..registry import FEEDFORWARD_NETWORK, USING_MMCV, build_transformer_layer
@@ -79,13 +81,64 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Dropout(drop) if drop else nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
-        out = self.layers(x)
+    def forward(self, x, identity=None, defer_residual=False):
+        """``defer_residual``: return ``PendingResidual(out, identity, p)`` instead of ``identity + dropout(out)`` when
+        the caller follows up with a LayerNorm (``residual_layer_norm`` does all three in one pass)."""
+        x_in = lowp_view(x)
+        last = self.layers[len(self.layers) - 1]
+        if (defer_residual and self.add_identity and isinstance(self.dropout_layer, nn.Identity)
+                and isinstance(last, nn.Dropout)):
+            out = x_in
+            for i in range(len(self.layers) - 1):
+                out = self.layers[i](out)
+            return PendingResidual(out, x if identity is None else identity, last.p if self.training else 0.0)
+        out = self.layers(x_in)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:
             identity = x
         return identity + self.dropout_layer(out)
+
+
+_FUSED_ADD_LN = os.environ.get('VER_FUSED_ADD_LN', '1') == '1'       # (0: plain torch ops, for A/B runs)
+
+
+class PendingResidual:
+    """``residual + dropout(branch)`` not formed yet: what an attention / FFN hands to the LayerNorm that follows it."""
+
+    def __init__(self, branch, residual, p):
+        self.branch, self.residual, self.p = branch, residual, float(p)
+
+    def materialize(self):
+        return self.residual + torch.nn.functional.dropout(self.branch, self.p, self.p > 0)
+
+
+def _autocast_bf16():
+    return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+def lowp_view(x):
+    """The bf16 copy a fused LayerNorm wrote next to its fp32 output (``residual_layer_norm``), if x carries one and
+    bf16 autocast is on: what the next Linear would cast x to anyway."""
+    x16 = getattr(x, '_ver_lowp', None)
+    return x16 if (x16 is not None and _autocast_bf16()) else x
+
+
+def residual_layer_norm(pending, norm):
+    """LayerNorm(residual + dropout(branch)).  On the GPU one fused pass each way (``ver_add_ln_*``) that also writes
+    the bf16 copy for the next Linear under bf16 autocast; elsewhere the plain sequence of torch ops."""
+    branch, res = pending.branch, pending.residual
+    c = branch.shape[-1]
+    if (_FUSED_ADD_LN and branch.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and tuple(norm.normalized_shape) == (c,) and c % 256 == 0 and c <= 1024
+            and branch.shape == res.shape and res.dtype == torch.float32):
+        from ..hipops import add_dropout_layer_norm
+        y, y16 = add_dropout_layer_norm(branch, res, norm.weight, norm.bias, pending.p, norm.eps,
+                                        want_bf16=_autocast_bf16())
+        if y16 is not None:
+            y._ver_lowp = y16
+        return y
+    return norm(pending.materialize())
 
 
 if not USING_MMCV:

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .. import hipops
 from ..registry import ATTENTION, build_attention
-from .bricks import BaseModule, constant_init, xavier_init
+from .bricks import BaseModule, PendingResidual, constant_init, lowp_view, xavier_init
 
 
 @ATTENTION.register_module(force=True)
@@ -57,7 +57,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag='encoder', hit_table=None,
-                map_hw=None, **kwargs):
+                map_hw=None, defer_residual=False, **kwargs):
         """query [bs,Nq,C]; key/value [Ncam,Nk,bs,C]; reference_points_cam [Ncam,bs,Nq,D,2];
         bev_mask [Ncam,bs,Nq,D] -> [bs,Nq,C].
 
@@ -90,12 +90,14 @@ class SpatialCrossAttention(BaseModule):
         # sampling_offsets and attention_weights read the same rows: one GEMM [.., C] x [C, 128 + 64] (and one cast of
         # the query under autocast) instead of two narrow ones; the parameters stay the reference's two Linears
         n_off = att.sampling_offsets.out_features
-        both = F.linear(query, torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0),
+        both = F.linear(lowp_view(query) if query_pos is None else query, torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0),
                         torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
         offsets = both[..., :n_off].reshape(bs, num_query, att.num_heads, att.num_points, 2)
         logits = both[..., n_off:].reshape(bs, num_query, att.num_heads, att.num_points)
         slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1])
         slots = self.output_proj(slots.to(query.dtype))
+        if defer_residual:                  # the caller's LayerNorm adds the residual (residual_layer_norm)
+            return PendingResidual(slots, inp_residual, self.dropout.p if self.training else 0.0)
         return self.dropout(slots) + inp_residual
 
 

@@ -16,8 +16,9 @@ import torch
 from .. import hipops
 from ..camera_store import CameraStore
 from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
-from .bricks import TransformerLayerSequence
+from .bricks import FFN, PendingResidual, TransformerLayerSequence, residual_layer_norm
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
+from .spatial_cross_attention import SpatialCrossAttention
 
 IMG_W = 1280.0   # hard-coded in the reference, voxel_encoder.py:179
 IMG_H = 1024.0   # voxel_encoder.py:180
@@ -132,7 +133,10 @@ class VoxelFormerLayer(MyCustomBaseTransformerLayer):
         identity = query
         if attn_masks is None:
             attn_masks = [None for _ in range(self.num_attn)]
-        for layer in self.operation_order:
+        order = list(self.operation_order)
+        for pos, layer in enumerate(order):
+            # a branch that is followed by a LayerNorm leaves its residual add (and dropout) to it: one fused pass
+            defer = (not self.pre_norm) and pos + 1 < len(order) and order[pos + 1] == 'norm'
             if layer == 'self_attn':
                 query = self.attentions[attn_index](
                     query, prev_bev, prev_bev, identity if self.pre_norm else None,
@@ -143,18 +147,29 @@ class VoxelFormerLayer(MyCustomBaseTransformerLayer):
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
-                query = self.norms[norm_index](query)
+                if isinstance(query, PendingResidual):
+                    query = residual_layer_norm(query, self.norms[norm_index])
+                else:
+                    query = self.norms[norm_index](query)
                 norm_index += 1
             elif layer == 'cross_attn':
-                query = self.attentions[attn_index](
+                attn = self.attentions[attn_index]
+                extra = dict(defer_residual=True) if (defer and isinstance(attn, SpatialCrossAttention)) else {}
+                query = attn(
                     query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=key_pos, reference_points=ref_3d,
                     reference_points_cam=reference_points_cam, mask=mask,
                     attn_mask=attn_masks[attn_index], key_padding_mask=key_padding_mask,
-                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+                    spatial_shapes=spatial_shapes, level_start_index=level_start_index, **extra, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn = self.ffns[ffn_index]
+                if defer and isinstance(ffn, FFN):
+                    query = ffn(query, identity if self.pre_norm else None, defer_residual=True)
+                else:
+                    query = ffn(query, identity if self.pre_norm else None)
                 ffn_index += 1
+        if isinstance(query, PendingResidual):
+            query = query.materialize()
         return query

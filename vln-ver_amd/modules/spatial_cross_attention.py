@@ -85,7 +85,8 @@ class SpatialCrossAttention(BaseModule):
         num_cams, nk, vbs, c = value.shape
         assert num_cams == self.num_cams and vbs == bs and nk == map_hw[0] * map_hw[1]
         # [Ncam,Nk,bs,C] -> [bs,Ncam,Nk,C]; a no-copy view when the caller built it that way
-        v = att.value_proj(value.permute(2, 0, 1, 3))
+        v16 = getattr(value, '_ver_lowp_perm', None)           # the encoder's one bf16 cast for all its layers
+        v = att.value_proj(v16 if (v16 is not None and torch.is_autocast_enabled('cuda')) else value.permute(2, 0, 1, 3))
         v = v.reshape(bs, num_cams, nk, att.num_heads, c // att.num_heads)
         # sampling_offsets and attention_weights read the same rows: one GEMM [.., C] x [C, 128 + 64] (and one cast of
         # the query under autocast) instead of two narrow ones; the parameters stay the reference's two Linears

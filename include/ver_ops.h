@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 20
+#define VER_ABI_VERSION 21
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -278,6 +278,13 @@ int ver_add_ln_backward(const float* grad_y, const void* grad_y_bf16, const void
                         const float* residual, const float* gamma, const float* mean, const float* rstd,
                         const int64_t* seed, float p_drop, void* grad_a, float* grad_residual, float* grad_gamma,
                         float* grad_beta, long N, int C, void* stream);
+/*   y = dropout(relu(x)): the hidden activation of the layer's FFN (mmcv FFN: Linear - ReLU - Dropout - Linear), the
+ *   same hash for the keep decision.  backward: grad_x = y > 0 ? grad_y / (1 - p_drop) : 0 (needs y only).
+ *   n elements (a multiple of 4), dtype VER_F32 / VER_BF16; y may alias x.
+ */
+int ver_relu_dropout_forward(const void* x, void* y, const int64_t* seed, float p_drop, long n, int dtype, void* stream);
+int ver_relu_dropout_backward(const void* y, const void* grad_y, void* grad_x, float p_drop, long n, int dtype,
+                              void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Run copies between the channel-first even lattice and the rows of the gathered `occ_proj` operand

@@ -874,3 +874,30 @@ def test_add_dropout_layer_norm_fused(adtype, p_drop):
     assert none is None and y2.shape == (n, c)
     e, _ = hip.add_dropout_layer_norm(torch.zeros(0, c, device=DEV), torch.zeros(0, c, device=DEV), gd.detach(), bd.detach())
     assert e.shape == (0, c)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_relu_dropout_fused(dtype, p_drop):
+    """ver_relu_dropout_*: y = dropout(relu(x)) (hidden activation of the layer's FFN); the kept set is read off y,
+    the backward pass must reproduce d(x) = y > 0 ? d(y) / (1 - p) : 0."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(33)
+    x = torch.randn(1000, 1536, generator=gen).to(dtype)
+    gy = torch.randn(1000, 1536, generator=gen).to(dtype)
+    xd = x.to(DEV).requires_grad_(True)
+    y = hip.relu_dropout(xd, p_drop)
+    assert y.dtype == dtype
+    y.backward(gy.to(DEV))
+    yc, pos = y.detach().float().cpu(), x.float() > 0
+    kept = (yc != 0)
+    assert not bool((kept & ~pos).any())                                  # nothing appears where relu(x) = 0
+    if p_drop > 0:
+        assert abs(float(kept[pos].float().mean()) - (1 - p_drop)) < 5e-3
+    else:
+        assert bool((kept == pos).all())
+    want = torch.where(kept, x.float() / (1 - p_drop), torch.zeros(())).to(dtype).float()
+    assert torch.equal(yc, want) if p_drop == 0 else close(yc, want, atol=1e-6, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    want_g = torch.where(kept, gy.float() / (1 - p_drop), torch.zeros(()))
+    assert close(xd.grad.float().cpu(), want_g, atol=1e-6, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    assert hip.relu_dropout(torch.zeros(0, 8, device=DEV), 0.1).shape == (0, 8)

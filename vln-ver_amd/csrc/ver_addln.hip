@@ -279,3 +279,76 @@ extern "C" int ver_add_ln_backward(const float* grad_y, const void* grad_y_bf16,
 #undef VER_BWD
     return ver_check_launch("ver_add_ln_backward");
 }
+
+// ------------------------------------------------------------------------------------------
+// y = dropout(relu(x)) of the FFN's hidden activation (mmcv FFN: Linear - ReLU - Dropout - Linear), one pass each way.
+// The backward needs no mask and no x: y > 0 exactly where x > 0 and the element was kept, so
+// d(x) = y > 0 ? d(y) / (1 - p) : 0.  Same hash as above for the keep decision.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_relu_dropout_fwd(const void* __restrict__ x, void* __restrict__ y,
+                                                          const int64_t* __restrict__ seed_p, float p_drop, long n4) {
+    const bool drop = p_drop > 0.0f;
+    const uint64_t seed = drop ? (uint64_t)seed_p[0] : 0ull;
+    const uint32_t thresh = (uint32_t)((1.0f - p_drop) * 16777216.0f);
+    const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4];
+        load_a4<BF16>(x, 4 * i, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = (v[j] > 0.0f && (!drop || keep_elem((uint64_t)(4 * i + j), seed, thresh))) ? v[j] * scale : 0.0f;
+        if (BF16)
+            store_bf4(reinterpret_cast<uint16_t*>(y), 4 * i, v);
+        else
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + 4 * i) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_relu_dropout_bwd(const void* __restrict__ y, const void* __restrict__ dy,
+                                                          void* __restrict__ dx, float scale, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4], g[4];
+        load_a4<BF16>(y, 4 * i, v);
+        load_a4<BF16>(dy, 4 * i, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.0f ? g[j] * scale : 0.0f;
+        if (BF16)
+            store_bf4(reinterpret_cast<uint16_t*>(dx), 4 * i, g);
+        else
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dx) + 4 * i) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
+extern "C" int ver_relu_dropout_forward(const void* x, void* y, const int64_t* seed, float p_drop, long n, int dtype,
+                                        void* stream) {
+    VER_REQUIRE(n >= 0 && n % 4 == 0, VER_EINVAL, "ver_relu_dropout_forward: element count must be a multiple of 4");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_relu_dropout_forward: dtype %d", dtype);
+    VER_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, VER_EINVAL, "ver_relu_dropout_forward: dropout probability %g", p_drop);
+    if (n == 0) return VER_OK;
+    VER_REQUIRE(x && y && (seed || p_drop == 0.0f), VER_EINVAL, "ver_relu_dropout_forward: null pointer argument");
+    const long n4 = n / 4;
+    const unsigned grid = (unsigned)(((n4 + 255) / 256) < 16384 ? ((n4 + 255) / 256) : 16384);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_relu_dropout_fwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, seed, p_drop, n4);
+    else
+        hipLaunchKernelGGL(k_relu_dropout_fwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, seed, p_drop, n4);
+    return ver_check_launch("ver_relu_dropout_forward");
+}
+
+extern "C" int ver_relu_dropout_backward(const void* y, const void* grad_y, void* grad_x, float p_drop, long n, int dtype,
+                                         void* stream) {
+    VER_REQUIRE(n >= 0 && n % 4 == 0, VER_EINVAL, "ver_relu_dropout_backward: element count must be a multiple of 4");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_relu_dropout_backward: dtype %d", dtype);
+    VER_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, VER_EINVAL, "ver_relu_dropout_backward: dropout probability %g", p_drop);
+    if (n == 0) return VER_OK;
+    VER_REQUIRE(y && grad_y && grad_x, VER_EINVAL, "ver_relu_dropout_backward: null pointer argument");
+    const long n4 = n / 4;
+    const unsigned grid = (unsigned)(((n4 + 255) / 256) < 16384 ? ((n4 + 255) / 256) : 16384);
+    const float scale = 1.0f / (1.0f - p_drop);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_relu_dropout_bwd<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, grad_y, grad_x, scale, n4);
+    else
+        hipLaunchKernelGGL(k_relu_dropout_bwd<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, grad_y, grad_x, scale, n4);
+    return ver_check_launch("ver_relu_dropout_backward");
+}

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 20
+ABI_VERSION = 21
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
@@ -21,7 +21,8 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
-           'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward')
+           'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
+           'ver_relu_dropout_forward', 'ver_relu_dropout_backward')
 
 _lib = None
 
@@ -692,6 +693,41 @@ class AddDropoutLayerNormFunction(Function):
             _p(mean), _p(rstd), _p(seed) if ctx.p_drop > 0 else None, ctypes.c_float(ctx.p_drop), _p(d_a), _p(d_res),
             _p(dg), _p(db), ctypes.c_long(n), C, _stream()))
         return d_a, d_res, dg, db, None, None, None
+
+
+class ReluDropoutFunction(Function):
+    """y = dropout(relu(x)) in one pass (ver_relu_dropout_*); the backward pass needs y only."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop):
+        x = _gpu(x, 'x')
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        seed = torch.randint(0, 2 ** 62, (1,), device=x.device, dtype=torch.int64) if p_drop > 0 else None
+        _launch('ver_relu_dropout_forward', lambda: lib().ver_relu_dropout_forward(
+            _p(x), _p(y), _p(seed) if seed is not None else None, ctypes.c_float(p_drop), ctypes.c_long(x.numel()),
+            1 if x.dtype == torch.bfloat16 else 0, _stream()))
+        ctx.save_for_backward(y)
+        ctx.p_drop = p_drop
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        y, = ctx.saved_tensors
+        gy = _gpu(grad_y, 'grad_y').to(y.dtype).contiguous()
+        gx = torch.empty_like(y)
+        _launch('ver_relu_dropout_backward', lambda: lib().ver_relu_dropout_backward(
+            _p(y), _p(gy), _p(gx), ctypes.c_float(ctx.p_drop), ctypes.c_long(y.numel()),
+            1 if y.dtype == torch.bfloat16 else 0, _stream()))
+        return gx, None
+
+
+def relu_dropout(x, p_drop=0.0):
+    """dropout(relu(x)), x fp32 or bf16 with a multiple of 4 elements."""
+    return ReluDropoutFunction.apply(x, float(p_drop))
 
 
 def add_dropout_layer_norm(a, residual, gamma, beta, p_drop=0.0, eps=1e-5, want_bf16=False):

@@ -81,6 +81,17 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Dropout(drop) if drop else nn.Identity()
         self.add_identity = add_identity
 
+    def _hidden(self, block, x):
+        """One hidden block ``Sequential(Linear, ReLU, Dropout)``: ReLU + Dropout as one HIP pass on the GPU."""
+        if (_FUSED_ADD_LN and isinstance(block, Sequential) and len(block) == 3 and isinstance(block[0], nn.Linear)
+                and isinstance(block[1], nn.ReLU) and isinstance(block[2], nn.Dropout) and x.is_cuda):
+            h = block[0](x)
+            if h.numel() % 4 == 0 and h.dtype in (torch.float32, torch.bfloat16):
+                from ..hipops import relu_dropout
+                return relu_dropout(h, block[2].p if self.training else 0.0)
+            return block[2](block[1](h))
+        return block(x)
+
     def forward(self, x, identity=None, defer_residual=False):
         """``defer_residual``: return ``PendingResidual(out, identity, p)`` instead of ``identity + dropout(out)`` when
         the caller follows up with a LayerNorm (``residual_layer_norm`` does all three in one pass)."""
@@ -90,7 +101,7 @@ class FFN(BaseModule):
                 and isinstance(last, nn.Dropout)):
             out = x_in
             for i in range(len(self.layers) - 1):
-                out = self.layers[i](out)
+                out = self._hidden(self.layers[i], out)
             return PendingResidual(out, x if identity is None else identity, last.p if self.training else 0.0)
         out = self.layers(x_in)
         if not self.add_identity:

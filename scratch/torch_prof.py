@@ -34,7 +34,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     step(); torch.cuda.synchronize()
 ka = prof.key_averages(group_by_input_shape=True)
 with open(a.out, 'w') as f:
-    f.write(ka.table(sort_by='self_device_time_total', row_limit=90, max_name_column_width=60, max_shapes_column_width=110))
+    f.write(ka.table(sort_by='self_device_time_total', row_limit=400, max_name_column_width=60, max_shapes_column_width=110))
     f.write('\n\n==== kernels ====\n')
     f.write(prof.key_averages().table(sort_by='self_device_time_total', row_limit=60, max_name_column_width=110))
 print('ok')

@@ -676,16 +676,52 @@ def _compute_dtype(x):
     return x.dtype
 
 
+class _ChannelsLast(torch.autograd.Function):
+    """x0 [B,C,Z,H,W] (the head's raw view of the encoder output, head:558) -> the compute dtype, channels-last
+    [B,Z,H,W,C]; one cast + one LDS-tiled transpose each way (``ver_lattice_transpose`` over the flattened Z*H*W
+    positions) instead of a cast of the permuted view and an element-wise strided copy."""
+
+    @staticmethod
+    def forward(ctx, x0, dt, split):
+        from ..hipops import lattice_transpose
+        b, c, z, h, w = x0.shape
+        cf = x0.to(dt).contiguous().view(b, c * z * h * w)
+        e = torch.empty(b, z, h, w, c, dtype=dt, device=x0.device)
+        lattice_transpose(e.view(b, 1, split[0], split[1], c), cf, split, 0, False)
+        ctx.split, ctx.in_dtype = split, x0.dtype
+        return e
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..hipops import lattice_transpose
+        b, z, h, w, c = g.shape
+        g = g.contiguous()
+        cf = torch.empty(b, c * z * h * w, dtype=g.dtype, device=g.device)
+        lattice_transpose(g.view(b, 1, ctx.split[0], ctx.split[1], c), cf, ctx.split, 0, True)
+        return cf.view(b, c, z, h, w).to(ctx.in_dtype), None, None
+
+
+def _channels_last(x0, dt):
+    b, c, z, h, w = x0.shape
+    pos = z * h * w
+    if x0.is_cuda and dt in (torch.float32, torch.bfloat16):
+        vx = 4 if dt == torch.bfloat16 else 2
+        for wd in range(min(pos, 120), 0, -1):            # rows of the flattened positions: 8-byte multiples, tile <= 64 KB
+            if pos % wd == 0 and wd % vx == 0:
+                return _ChannelsLast.apply(x0, dt, (pos // wd, wd))
+    return x0.permute(0, 2, 3, 4, 1).to(dt).contiguous()
+
+
 def upsample_lattice(x0, weights, biases):
     """x0 [B,C,Z,H,W] -> (E_3, last bias).  E_3 holds the even positions of the reference's dense
     output ``up_sample(x0)`` [B,C,Z,8H,8W], as a PLANAR lattice [4,B,Z,2H,2W,C] or, for Z = 4, planar
     z-split [4,B,2,2H,2W,2,C] (``lattice_to_plain`` gives the channels-last [B,Z,4H,4W,C] lattice)."""
     dt = _compute_dtype(x0)
-    e = x0.permute(0, 2, 3, 4, 1).to(dt)
+    e = _channels_last(x0, dt)
     ks = [_corr_weight(w, dt) for w in weights]
     bs = [b.to(dt) for b in biases]
     if e.shape[1] == 4:                                   # bev_z = 4: z-split path (a third fewer FLOPs)
-        e = _Layer0Z4.apply(e.contiguous(), ks[0], bs[0])
+        e = _Layer0Z4.apply(e, ks[0], bs[0])
         e = _LatticeLayerZ4.apply(e, ks[1], bs[1], bs[0], False)
         e = _LatticeLayerZ4.apply(e, ks[2], bs[2], bs[1], True)
         return e, bs[2]

@@ -104,12 +104,14 @@ __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict_
         const int b = (int)(r / Zr);
         uint4* dst = col + row * stride_v;
         int t = t0, v = v0;
+        // unconditional (clamped, then masked) loads, four vectors per thread in flight
+#pragma unroll 4
         for (int i = threadIdx.x; i < per_row; i += 256) {
             const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (sz >= 0 && sz < Zs && sy >= 0 && sy < H && sx >= 0 && sx < W)
-                val = src[lattice_index<LAYOUT>(b, sz, sy, sx, B, Zs, H, W) * CV + v];
-            dst[taps.off[t] + v] = val;
+            const bool ok = sz >= 0 && sz < Zs && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const int cz = min(max(sz, 0), Zs - 1), cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
+            const uint4 val = src[lattice_index<LAYOUT>(b, cz, cy, cx, B, Zs, H, W) * CV + v];
+            dst[taps.off[t] + v] = ok ? val : make_uint4(0u, 0u, 0u, 0u);
             t += dt;
             v += dv;
             if (v >= CV) {
@@ -133,22 +135,35 @@ __global__ __launch_bounds__(256) void k_lattice_scatter(const uint4* __restrict
         float acc[BF16 ? 8 : 4];
 #pragma unroll
         for (int j = 0; j < (BF16 ? 8 : 4); ++j) acc[j] = 0.0f;
-        for (int t = 0; t < taps.n; ++t) {
-            const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
-            if (oz < 0 || oz >= Zr || oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
-            const uint4 g = gcol[((((long)b * Zr + oz) * H + oy) * W + ox) * stride_v + taps.off[t] + v];
-            if (BF16) {
-                const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+        // taps in groups of three with unconditional (clamped, then masked) loads: the three requests are in flight
+        // together instead of one load per loop trip behind a data-dependent `continue`
+        for (int t0 = 0; t0 < taps.n; t0 += 3) {
+            uint4 gv[3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[2 * j] += __uint_as_float(w[j] << 16);
-                    acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+            for (int u = 0; u < 3; ++u) {
+                const int t = min(t0 + u, taps.n - 1);
+                const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
+                const bool ok = t0 + u < taps.n && oz >= 0 && oz < Zr && oy >= 0 && oy < H && ox >= 0 && ox < W;
+                const int cz = min(max(oz, 0), Zr - 1), cy = min(max(oy, 0), H - 1), cx = min(max(ox, 0), W - 1);
+                const uint4 g = gcol[((((long)b * Zr + cz) * H + cy) * W + cx) * stride_v + taps.off[t] + v];
+                gv[u] = ok ? g : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const uint4 g = gv[u];
+                if (BF16) {
+                    const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[2 * j] += __uint_as_float(w[j] << 16);
+                        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                    }
+                } else {
+                    acc[0] += __uint_as_float(g.x);
+                    acc[1] += __uint_as_float(g.y);
+                    acc[2] += __uint_as_float(g.z);
+                    acc[3] += __uint_as_float(g.w);
                 }
-            } else {
-                acc[0] += __uint_as_float(g.x);
-                acc[1] += __uint_as_float(g.y);
-                acc[2] += __uint_as_float(g.z);
-                acc[3] += __uint_as_float(g.w);
             }
         }
         uint4 o;

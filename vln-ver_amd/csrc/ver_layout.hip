@@ -263,23 +263,26 @@ __global__ __launch_bounds__(256) void k_run_copy(const E* __restrict__ src, E* 
     constexpr int VE = 8 / sizeof(E);
     const int vec_per_run = run_len / VE;
     const int n_vec = R * vec_per_run;
-    const int t = threadIdx.x;
-    for (long row = blockIdx.x; row < rows_total; row += gridDim.x) {
+    // the (row, vector) pairs as one index space: every lane busy, four copies per thread in flight
+    const int per_row = n_vec + (GATHER ? n_aug : 0);
+    const long total = rows_total * per_row;
+#pragma unroll 4
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long row = idx / per_row;
+        const int v = (int)(idx - row * per_row);
         const long b = row / n_rows;
         const int i = (int)(row - b * n_rows);
-        for (int v = t; v < n_vec + (GATHER ? n_aug : 0); v += 256) {
-            if (v < n_vec) {
-                const int k = v / vec_per_run, o = v - k * vec_per_run;
-                const long img = b * img_stride + run_start[i * R + k] + (long)o * VE;
-                const long buf = row * row_elems + (long)v * VE;
-                if (GATHER)
-                    *reinterpret_cast<uint2*>(dst + buf) = *reinterpret_cast<const uint2*>(src + img);
-                else
-                    *reinterpret_cast<uint2*>(dst + img) = *reinterpret_cast<const uint2*>(src + buf);
-            } else {
-                const int j = v - n_vec;
-                dst[row * row_elems + (long)n_vec * VE + j] = src[b * img_stride + aug_idx[i * n_aug + j]];
-            }
+        if (v < n_vec) {
+            const int k = v / vec_per_run, o = v - k * vec_per_run;
+            const long img = b * img_stride + run_start[i * R + k] + (long)o * VE;
+            const long buf = row * row_elems + (long)v * VE;
+            if (GATHER)
+                *reinterpret_cast<uint2*>(dst + buf) = *reinterpret_cast<const uint2*>(src + img);
+            else
+                *reinterpret_cast<uint2*>(dst + img) = *reinterpret_cast<const uint2*>(src + buf);
+        } else {
+            const int j = v - n_vec;
+            dst[row * row_elems + (long)n_vec * VE + j] = src[b * img_stride + aug_idx[i * n_aug + j]];
         }
     }
 }
@@ -297,7 +300,8 @@ int run_copy(bool gather, const void* src, void* dst, long img_stride, const int
     VER_REQUIRE(src && dst && run_start && (aug_idx || !gather || n_aug == 0), VER_EINVAL, "%s: null pointer argument", who);
     VER_REQUIRE(((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 7) == 0, VER_EINVAL, "%s: buffers must be 8-byte aligned", who);
     const long rows_total = (long)B * n_rows;
-    const unsigned grid = (unsigned)(rows_total < 16384 ? rows_total : 16384);
+    const long want = (rows_total * (R * (run_len / ve) + (gather ? n_aug : 0)) + 1023) / 1024;
+    const unsigned grid = (unsigned)(want < 16384 ? (want > 0 ? want : 1) : 16384);
     hipStream_t st = (hipStream_t)stream;
 #define VER_RUN(G, E)                                                                                         \
     hipLaunchKernelGGL((k_run_copy<G, E>), dim3(grid), dim3(256), 0, st, (const E*)src, (E*)dst, img_stride,   \

@@ -344,7 +344,11 @@ def main():
                        'trainable_params': n_train, 'tuned_gemm_table': tuned,
                        'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
-                                     else 'fp32'},
+                                     else 'fp32',
+                       'evaluation': ('same loss and gradients as the reference step, evaluated where the data is: '
+                                      'occupancy logits stay in the GEMM row order and the targets are permuted to match; '
+                                      'on the bf16 path occ_branches[0] is composed with occ_proj every step '
+                                      '(DESIGN.md sections 1, 3.3, 6)') if train else 'forward only'},
             'roofline': roof, 'roofline_other_kernels': others,
         }
         if world == 1 and not args.no_cpu_baseline and train and not full:

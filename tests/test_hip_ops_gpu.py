@@ -835,15 +835,15 @@ def test_voxel_msda_forward_backward(name):
 
 # ------------------------------------------------------------------------------- a7: residual + dropout + LayerNorm
 @pytest.mark.parametrize('adtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('p_drop', [0.0, 0.1])
-def test_add_dropout_layer_norm_fused(adtype, p_drop):
+@pytest.mark.parametrize('p_drop,c', [(0.0, 768), (0.1, 768), (0.1, 256), (0.0, 1024)])
+def test_add_dropout_layer_norm_fused(adtype, p_drop, c):
     """ver_add_ln_*: y = LayerNorm(residual + dropout(a)) (the tail of both branches of a VoxelFormerLayer,
     voxel_encoder.py:344-464) vs torch.  With dropout the kept set is read off d(a) (zero exactly where an element was
     dropped), which also checks that the backward pass recomputes the forward's decisions."""
     hip = pkg('hipops')
     F = torch.nn.functional
     gen = torch.Generator(device='cpu').manual_seed(31)
-    n, c = 777, 768
+    n = 777
     a = torch.randn(n, c, generator=gen).to(adtype)
     res = torch.randn(n, c, generator=gen)
     gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen) * 0.1

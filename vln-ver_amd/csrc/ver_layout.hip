@@ -118,56 +118,62 @@ __global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T
 }
 
 // The same with 16-byte accesses on the channels-last side and 8-byte accesses on the channel-first side (W a multiple of
-// 8 / sizeof(T) elements, C a multiple of 16 / sizeof(T)): the element-wise version moved 2 bytes per lane and access,
-// 4.0 ms for the 1.06-GB lattice of the vocc.py step each way.  LDS accesses stay per element (odd row pitch).
-template <typename T, int LAYOUT, bool TO_CF>
+// 8 / sizeof(T) elements, C a multiple of 16 / sizeof(T)).  A tile is CH channels x R rows of W positions: on the
+// channel-first side a channel's R W positions are ONE contiguous run (R = 10 rows of 60: 1 200 bytes), so the 8-byte
+// stores of a wave fill whole cache lines -- with single rows (120-byte runs, one per channel and workgroup) the
+// transposes of the 1.06-GB lattice of the vocc.py step took 3.6 ms / 2.1 ms; element-wise (2 bytes per lane) 4.0 / 3.6 ms.
+// LDS accesses stay per element (odd row pitch).  grid = (B * Z * H / R, C / CH).
+template <typename T, int LAYOUT, bool TO_CF, int CH>
 __global__ __launch_bounds__(256) void k_lattice_transpose_v(T* __restrict__ cl, T* __restrict__ cf, long cf_stride,
-                                                             int B, int Z, int H, int W, int C) {
+                                                             int B, int Z, int H, int W, int C, int R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VC = 16 / sizeof(T), VX = 8 / sizeof(T);
-    T* tile = reinterpret_cast<T*>(smem);                  // [kCh][W + 1]
-    const int wp = W + 1;
+    T* tile = reinterpret_cast<T*>(smem);                  // [CH][R * W + 1]
+    const int P = R * W, wp = P + 1;
     int r = blockIdx.x;
-    const int y = r % H;
-    r /= H;
+    const int hr = H / R;
+    const int y0 = (r % hr) * R;
+    r /= hr;
     const int z = r % Z;
     const int b = r / Z;
-    const int c0 = blockIdx.y * kCh;
-    const int nc = (C - c0) < kCh ? (C - c0) : kCh;        // a multiple of VC
-    const int ncv = nc / VC, nxv = W / VX;
+    const int c0 = blockIdx.y * CH;
+    const int nc = (C - c0) < CH ? (C - c0) : CH;          // a multiple of VC
+    const int ncv = nc / VC, npv = P / VX;
     union V16 { uint4 v; T e[VC]; };
     union V8 { uint2 v; T e[VX]; };
     if (TO_CF) {
-        for (int i = threadIdx.x; i < W * ncv; i += 256) {
-            const int x = i / ncv, cv = i - x * ncv;
+        for (int i = threadIdx.x; i < P * ncv; i += 256) {
+            const int p = i / ncv, cv = i - p * ncv;
+            const int yy = p / W, x = p - yy * W;
             V16 u;
-            u.v = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y, x, B, Z, H, W) * C + c0 + cv * VC);
+            u.v = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC);
 #pragma unroll
-            for (int j = 0; j < VC; ++j) tile[(cv * VC + j) * wp + x] = u.e[j];
+            for (int j = 0; j < VC; ++j) tile[(cv * VC + j) * wp + p] = u.e[j];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nc * nxv; i += 256) {
-            const int c = i / nxv, xv = i - c * nxv;
+        for (int i = threadIdx.x; i < nc * npv; i += 256) {
+            const int c = i / npv, pv = i - c * npv;
             V8 u;
 #pragma unroll
-            for (int k = 0; k < VX; ++k) u.e[k] = tile[c * wp + xv * VX + k];
-            *reinterpret_cast<uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y) * W + xv * VX) = u.v;
+            for (int k = 0; k < VX; ++k) u.e[k] = tile[c * wp + pv * VX + k];
+            *reinterpret_cast<uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX) = u.v;
         }
     } else {
-        for (int i = threadIdx.x; i < nc * nxv; i += 256) {
-            const int c = i / nxv, xv = i - c * nxv;
+        for (int i = threadIdx.x; i < nc * npv; i += 256) {
+            const int c = i / npv, pv = i - c * npv;
             V8 u;
-            u.v = *reinterpret_cast<const uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y) * W + xv * VX);
+            u.v = *reinterpret_cast<const uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
 #pragma unroll
-            for (int k = 0; k < VX; ++k) tile[c * wp + xv * VX + k] = u.e[k];
+            for (int k = 0; k < VX; ++k) tile[c * wp + pv * VX + k] = u.e[k];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < W * ncv; i += 256) {
-            const int x = i / ncv, cv = i - x * ncv;
+        for (int i = threadIdx.x; i < P * ncv; i += 256) {
+            const int p = i / ncv, cv = i - p * ncv;
+            const int yy = p / W, x = p - yy * W;
             V16 u;
 #pragma unroll
-            for (int j = 0; j < VC; ++j) u.e[j] = tile[(cv * VC + j) * wp + x];
-            *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y, x, B, Z, H, W) * C + c0 + cv * VC) = u.v;
+            for (int j = 0; j < VC; ++j) u.e[j] = tile[(cv * VC + j) * wp + p];
+            *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC) = u.v;
         }
     }
 }
@@ -211,23 +217,49 @@ extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, l
     if (B == 0) return VER_OK;
     VER_REQUIRE(channels_last && channel_first, VER_EINVAL, "ver_lattice_transpose: null pointer argument");
     const size_t esize = dtype == VER_BF16 ? 2 : 4;
-    const size_t lds = (size_t)kCh * (W + 1) * esize;
-    VER_REQUIRE(lds <= 64 * 1024, VER_EUNSUPPORTED, "ver_lattice_transpose: W = %d too wide", W);
-    const dim3 grid((unsigned)((long)B * Z * H), (unsigned)((C + kCh - 1) / kCh));
     hipStream_t st = (hipStream_t)stream;
-    // vector form: whole 16-byte channel vectors / 8-byte position vectors and buffers aligned for them
+    // vector form: whole 16-byte channel vectors / 8-byte position vectors and buffers aligned for them; tiles of
+    // 32 channels x R rows, R the largest divisor of H whose tile stays under 48 KB (and under ~1 200 positions)
+    constexpr int kChV = 32;
     const int vc = 16 / (int)esize, vx = 8 / (int)esize;
     const bool vec = W % vx == 0 && C % vc == 0 && cf_stride % vx == 0 && ((uintptr_t)channels_last & 15) == 0 &&
                      ((uintptr_t)channel_first & 7) == 0 && ((long)Z * H * W) % vx == 0;
-#define VER_TR(T, L, CF)                                                                                             \
-    do {                                                                                                             \
-        if (vec)                                                                                                     \
-            hipLaunchKernelGGL((k_lattice_transpose_v<T, L, CF>), grid, dim3(256), lds, st, (T*)channels_last,       \
-                               (T*)channel_first, cf_stride, B, Z, H, W, C);                                         \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_lattice_transpose<T, L, CF>), grid, dim3(256), lds, st, (T*)channels_last,         \
-                               (T*)channel_first, cf_stride, B, Z, H, W, C);                                         \
+    if (vec && (size_t)kCh * (W + 1) * esize <= 64 * 1024) {
+        // the WRITE side wants long runs: to channel-first 32 channels x R rows (R W contiguous positions per channel),
+        // to channels-last 128 channels x one row (256 contiguous bytes per position); measured the other way round
+        // each direction loses a third (2.7 vs 3.6 ms to channel-first, 2.1 vs 3.0 ms back)
+        int R = 1;
+        if (to_channel_first)
+            for (int cand = 1; cand <= H; ++cand)
+                if (H % cand == 0 && (size_t)kChV * ((size_t)cand * W + 1) * esize <= 48 * 1024 && cand * W <= 1200) R = cand;
+        const int chv = to_channel_first ? kChV : kCh;
+        const size_t ldsv = (size_t)chv * ((size_t)R * W + 1) * esize;
+        const dim3 gridv((unsigned)((long)B * Z * (H / R)), (unsigned)((C + chv - 1) / chv));
+#define VER_TRV(T, L, CF)                                                                                              \
+    hipLaunchKernelGGL((k_lattice_transpose_v<T, L, CF, (CF ? kChV : kCh)>), gridv, dim3(256), ldsv, st,                \
+                       (T*)channels_last, (T*)channel_first, cf_stride, B, Z, H, W, C, R)
+#define VER_TRV_L(T, CF)                          \
+    do {                                          \
+        if (layout == 0) VER_TRV(T, 0, CF);       \
+        else if (layout == 1) VER_TRV(T, 1, CF);  \
+        else if (layout == 2) VER_TRV(T, 2, CF);  \
+        else VER_TRV(T, 3, CF);                   \
     } while (0)
+        if (dtype == VER_BF16) {
+            if (to_channel_first) VER_TRV_L(uint16_t, true); else VER_TRV_L(uint16_t, false);
+        } else {
+            if (to_channel_first) VER_TRV_L(float, true); else VER_TRV_L(float, false);
+        }
+#undef VER_TRV_L
+#undef VER_TRV
+        return ver_check_launch("ver_lattice_transpose");
+    }
+    const size_t lds = (size_t)kCh * (W + 1) * esize;
+    VER_REQUIRE(lds <= 64 * 1024, VER_EUNSUPPORTED, "ver_lattice_transpose: W = %d too wide", W);
+    const dim3 grid((unsigned)((long)B * Z * H), (unsigned)((C + kCh - 1) / kCh));
+#define VER_TR(T, L, CF)                                                                                             \
+    hipLaunchKernelGGL((k_lattice_transpose<T, L, CF>), grid, dim3(256), lds, st, (T*)channels_last, (T*)channel_first, \
+                       cf_stride, B, Z, H, W, C)
 #define VER_TR_L(T, CF)                  \
     do {                                 \
         if (layout == 0) VER_TR(T, 0, CF);      \

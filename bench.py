@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the VER 2D->3D lifting path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 from a plain shell: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process -- before anything has touched the GPU -- and relays its output and exit code (the reference's
+tools/dist_train.sh:12-14 does the same with torch.distributed.launch).  Under a launcher (WORLD_SIZE in the
+environment) it is one of the N ranks: one process per GPU, RCCL gradient all-reduce.
 
 A "step" = one training pass of the hot path over one batch of synthetic viewpoints:
 6x14x14x768 ViT features -> VERFormer encoder (projection, hit table, 3x fused multi-view
@@ -17,6 +22,9 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 import warnings
@@ -26,9 +34,8 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 warnings.filterwarnings('ignore')
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -50,9 +57,34 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--workload', default='vocc_c2f_train', choices=['vocc_c2f_train', 'c2_single_scale_fwd', 'vocc_full_train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--cpu-seconds', type=float, default=30.0,
+                    help='budget of the cpu_baseline leg: 1 warm-up + up to 10 timed single-viewpoint passes (at least 5)')
     ap.add_argument('--backend', default='nccl', help='nccl (= RCCL); gloo only to exercise the N>1 path on one GPU')
+    ap.add_argument('--config', default=None, help='mmcv-style config file (default: the vocc config shipped with the '
+                                                   'package; the reference\'s projects/configs/verformer/vocc.py loads as is)')
+    ap.add_argument('--latency-batches', default='1,8',
+                    help='viewpoints per GPU and step of the untimed-by-headline config.latency records (SURVEY 8d C4: '
+                         'vocc.py runs samples_per_gpu=1); empty string: none')
+    ap.add_argument('--latency-steps', type=int, default=10)
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: become the launcher.  This process has not initialised the GPU (importing torch
+    does not) and never will: the ranks are children, their stdout/stderr are ours, their exit code is returned."""
+    n_dev = torch.cuda.device_count()           # counts devices without creating a HIP context on this image
+    if args.backend == 'nccl' and n_dev < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one GPU per rank; '
+                         '--backend gloo shares GPUs between ranks)' % (args.gpus, n_dev))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: the only mode this host driver supports
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 class LiftTrainer(torch.nn.Module):
@@ -97,15 +129,17 @@ class FullTrainer(torch.nn.Module):
 
 
 def build_model(args, dev):
-    import cases
     pkg = importlib.import_module('vln-ver_amd')
     syn = importlib.import_module('vln-ver_amd.synthetic')
-    if args.workload == 'c2_single_scale_fwd':
-        cfg = cases.vocc_head_cfg(bev=(16, 50, 50), refine_occ=False)
+    config = importlib.import_module('vln-ver_amd.config')
+    # the model dict comes from the config FILE (tools/train.py:105-135: Config.fromfile -> build_model), through the
+    # package's own loader; the head gets train_cfg.pts the way the detector passes it on
+    model_cfg = config.load_model_cfg(args.config)
+    if args.workload == 'c2_single_scale_fwd':          # BASELINE configs[1]: the same head on a 50x50x16 single-scale grid
+        cfg = config.head_cfg(model_cfg, train=False, bev_z=16, bev_h=50, bev_w=50, refine_occ=False)
+        cfg['positional_encoding'].update(row_num_embed=50, col_num_embed=50, z_num_embed=16)
     else:
-        cfg = cases.vocc_head_cfg()
-    if args.workload == 'vocc_full_train':
-        cfg = dict(cfg, train_cfg=cases.VOCC_TRAIN_CFG)
+        cfg = config.head_cfg(model_cfg, train=args.workload == 'vocc_full_train')
     torch.manual_seed(2)
     head = pkg.registry.build_head(cfg)
     head.init_weights()
@@ -173,46 +207,77 @@ def measured_traffic(kernels, B):
 
 
 def cpu_baseline(head, syn, seconds):
-    """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this
-    host's cores: vocc.py lifting path fwd+bwd for ONE viewpoint at a time."""
+    """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this host's cores: the vocc.py
+    lifting path fwd+bwd at FULL size, one viewpoint per pass (the reference's samples_per_gpu=1): 1 untimed warm-up
+    pass, then timed passes until `seconds` are spent (at least 5, at most 10); value = 1 / median pass time."""
     oracle = importlib.import_module('oracle.ver_oracle')
     # all cores of a 256-thread host oversubscribe these small CPU ops (measured 6x slower than 8
     # threads); 16 is near the knee.  `cores` reports what was actually used.
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    host_threads = os.cpu_count() or 1
+    torch.set_num_threads(min(16, host_threads))
+    cpu_model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                cpu_model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     p = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and k != 'code_weights')
          for k, v in head.state_dict().items()}
     w2p, org = syn.camera_batch(1, seed=1)
     feats = torch.from_numpy(syn.vit_features(1, seed=0))[0].unsqueeze(1)
     gt = torch.from_numpy(np.random.default_rng(3).integers(0, 17, size=504000))
-    n, t0 = 0, time.perf_counter()
-    while True:
+
+    def one_pass():
+        t = time.perf_counter()
         _, occ = oracle.lifting_forward(p, feats, torch.from_numpy(w2p[0]), torch.from_numpy(org[0]))
         loss = oracle.focal_loss(occ[0], gt, avg_factor=(gt < 16).sum() * 1.0)
         loss.backward()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 3:
-            break
-    return dict(value=n / dt, unit='viewpoints/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d viewpoint(s), vocc.py 15x15x4 -> 120x120x35x16 lifting path fwd+bwd, fp32, '
-                       'oracle/ver_oracle.py (torch-CPU), %.1f s' % (n, dt))
+        for v in p.values():
+            v.grad = None
+        return time.perf_counter() - t
+
+    t0 = time.perf_counter()
+    warm = one_pass()
+    times = []
+    while len(times) < 5 or (len(times) < 10 and time.perf_counter() - t0 + warm < seconds):
+        times.append(one_pass())
+    med = statistics.median(times)
+    return dict(value=1.0 / med, unit='viewpoints/s', cores=torch.get_num_threads(), kind='port',
+                host_threads=host_threads, cpu_model=cpu_model, passes=len(times), warmup_passes=1,
+                median_s=round(med, 3), min_s=round(min(times), 3), max_s=round(max(times), 3),
+                sample='%d timed single-viewpoint passes after 1 warm-up (median), vocc.py 15x15x4 -> 120x120x35x16 '
+                       'lifting path fwd+bwd at full size, fp32, oracle/ver_oracle.py (torch-CPU, %d threads of %d), '
+                       '%.1f s in all' % (len(times), torch.get_num_threads(), host_threads, time.perf_counter() - t0))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))             # (nothing above this line touches the GPU)
+    under_launcher = 'WORLD_SIZE' in os.environ
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        print('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d'
+              % (args.gpus, world, world), file=sys.stderr)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback of the product path)'
+    if args.backend == 'nccl' and world > torch.cuda.device_count():
+        raise SystemExit('bench.py: %d ranks but %d GPU(s): RCCL needs one GPU per rank' % (world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if under_launcher:
+        # also with ONE rank (torchrun --nproc-per-node 1): the RCCL communicator, the bf16 compression hook and the
+        # bucket views are then built and used on hardware exactly as with N ranks
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    distributed = dist.is_available() and dist.is_initialized()
     hip = importlib.import_module('vln-ver_amd.hipops')
     hip.lib()
     tuned = False
@@ -228,9 +293,12 @@ def main():
     model.train(train)
     ddp = model                                 # train(): dropout ON, as in the reference's step
     probe_unused = train and full               # the full head has parameters its forward never touches
-    if world > 1 and train and not probe_unused:
-        ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev,
-                                                                  bf16_gradients=args.backend == 'nccl')
+
+    def wrap(m):
+        return importlib.import_module('vln-ver_amd.ddp').wrap_ddp(m, device=dev, bf16_gradients=args.backend == 'nccl')
+
+    if distributed and train and not probe_unused:
+        ddp = wrap(model)
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True) if train else None
 
@@ -240,25 +308,30 @@ def main():
     w2p, org = torch.from_numpy(w2p_np).to(dev), torch.from_numpy(org_np).to(dev)
     nvox = head.voxel_num if head.refine_occ else head.bev_h * head.bev_w * head.occ_zdim
     gt = torch.from_numpy(np.random.default_rng(7 + rank).integers(0, 17, size=(B, nvox))).to(dev)
-
+    gt_boxes = gt_labels = None
     if full:
-        import cases
-        gts = [cases.detection_gt(seed=40 + rank * 1000 + i, num_gt=3 + i % 5) for i in range(B)]
+        gts = [syn.detection_gt(seed=40 + rank * 1000 + i, num_gt=3 + i % 5) for i in range(B)]
         gt_boxes = [torch.from_numpy(g[0][:, :7]).to(dev) for g in gts]
         gt_labels = [torch.from_numpy(g[1]).to(dev) for g in gts]
 
-    def step():
-        if train:
-            loss = ddp(feats, w2p, org, gt, gt_boxes, gt_labels) if full else ddp(feats, w2p, org, gt)
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:270 grad_clip max_norm
-            opt.step()
-            opt.zero_grad(set_to_none=True)
-            return loss
-        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16'):
-            emb = head(feats, None, only_bev=True, world2pixel=w2p, origin=org)
-            out = [head.occupancy_from_volume(emb[s:s + args.micro]) for s in range(0, B, args.micro)]
-            return out[-1].float().mean()
+    def make_step(nb):
+        """One step over the first `nb` viewpoints of the resident inputs."""
+        f, w, o, g = feats[:, :nb].contiguous(), w2p[:nb], org[:nb], gt[:nb]
+        gb, gl = (gt_boxes[:nb], gt_labels[:nb]) if full else (None, None)
+
+        def step():
+            if train:
+                loss = ddp(f, w, o, g, gb, gl) if full else ddp(f, w, o, g)
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:274 grad_clip max_norm
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                return loss
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16'):
+                emb = head(f, None, only_bev=True, world2pixel=w, origin=o)
+                out = [head.occupancy_from_volume(emb[s:s + args.micro]) for s in range(0, nb, args.micro)]
+                return out[-1].float().mean()
+        return step
 
     if probe_unused:
         # One un-wrapped probing step: parameters that end it without a gradient are not part of this workload's
@@ -273,18 +346,19 @@ def main():
         params = [prm for prm in model.parameters() if prm.requires_grad]
         n_train = sum(prm.numel() for prm in params)
         opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
-        if world > 1:
-            ddp = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev,
-                                                                      bf16_gradients=args.backend == 'nccl')
+        if distributed:
+            ddp = wrap(model)
+    step = make_step(B)
     # Setup: two untimed priming steps.  The first step allocates ~55 GiB through hipMalloc and creates
     # the AdamW state, so the caching allocator still grows during the second; with them here the W
     # warm-up steps the caller asks for (even W = 0) are not spent on one-time allocator / library work.
+    # (The host-side label-range check of the fused focal loss also runs here, once: dense_heads/losses.py.)
     for _ in range(2):
-        step()
+        last = step()
     for _ in range(args.warmup):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     timer = hip.KernelTimer()
     hip.KERNEL_TIMER = timer
@@ -293,15 +367,41 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     hip.KERNEL_TIMER = None
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax)
     assert torch.isfinite(last).all(), 'non-finite loss'
+    peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+
+    # config.latency: the same step at the reference's own batch points (samples_per_gpu = 1, and 8),
+    # measured AFTER the headline region and never part of `value`; every rank runs them (the gradient sum is collective)
+    latency = []
+    for nb in [int(x) for x in args.latency_batches.split(',') if x.strip()]:
+        if not train or nb > B:
+            continue
+        small = make_step(nb)
+        for _ in range(3):
+            small()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.latency_steps):
+            small()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        ms = float(dt) / args.latency_steps * 1e3
+        latency.append(dict(viewpoints_per_gpu_per_step=nb, steps=args.latency_steps, warmup=3,
+                            ms_per_step=round(ms, 3), viewpoints_per_s=round(nb * world / ms * 1e3, 2)))
 
     if rank == 0:
         kt = timer.summary()
@@ -339,16 +439,20 @@ def main():
                                    'vocc.py coarse-to-fine lifting path (15x15x4 -> 120x120x35x16): encoder + '
                                    'occupancy head + focal loss, fwd+bwd+AdamW' if train else
                                    'single-scale 50x50x16 volume, forward only',
+                       'config_file': os.path.relpath(args.config or importlib.import_module('vln-ver_amd.config').VOCC, ROOT),
                        'viewpoints_per_gpu_per_step': B, 'global_viewpoints_per_step': B * world,
                        'head_micro_batch': args.micro, 'parallelism': 'dp%d' % world,
+                       'gradient_allreduce': (('RCCL, bf16-compressed 200 MB buckets' if args.backend == 'nccl'
+                                               else args.backend) if distributed and train else None),
                        'trainable_params': n_train, 'tuned_gemm_table': tuned,
-                       'peak_hbm_gib': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       'peak_hbm_gib': peak_gib,
                        'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
                                      else 'fp32',
                        'evaluation': ('same loss and gradients as the reference step, evaluated where the data is: '
                                       'occupancy logits stay in the GEMM row order and the targets are permuted to match; '
                                       'on the bf16 path occ_branches[0] is composed with occ_proj every step '
-                                      '(DESIGN.md sections 1, 3.3, 6)') if train else 'forward only'},
+                                      '(DESIGN.md sections 1, 3.3, 6)') if train else 'forward only',
+                       'latency': latency},
             'roofline': roof, 'roofline_other_kernels': others,
         }
         if world == 1 and not args.no_cpu_baseline and train and not full:
@@ -356,7 +460,8 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -159,15 +159,18 @@ MSDA3D_CASES = {
 
 
 def detection_gt(seed=31, num_gt=5):
-    """Synthetic ground truth for the detection losses: boxes [G,9] = (cx,cy,cz,w,l,h,yaw,vx,vy)
-    inside the vocc.py range, labels in [0,17)."""
-    rng = np.random.default_rng(seed)
-    c = rng.uniform([-5, -5, -1.2], [5, 5, 1.7], (num_gt, 3))
-    d = rng.uniform(0.3, 2.0, (num_gt, 3))
-    yaw = rng.uniform(-3.1, 3.1, (num_gt, 1))
-    boxes = np.concatenate([c, d, yaw, np.zeros((num_gt, 2))], 1).astype(np.float32)
-    labels = rng.integers(0, CLASS_NUM, num_gt).astype(np.int64)
-    return boxes, labels
+    """Synthetic ground truth for the detection losses (the recipe lives with the product's synthetic inputs)."""
+    import importlib
+    return importlib.import_module('vln-ver_amd.synthetic').detection_gt(seed, num_gt, CLASS_NUM)
+
+
+def layout_gt():
+    """One room-layout box per viewpoint (the reference's layout matcher assumes exactly one: head:786-787):
+    [1,7] = (cx,cy,cz,w,l,h,yaw) of an 8.2 x 6.4 x 2.9 m room."""
+    return np.array([[0.45, -0.3, 0.2, 8.2, 6.4, 2.9, 0.3]], dtype=np.float32)
+
+
+LAYOUT_LOSS_CFG = dict(type='L1Loss', loss_weight=0.25)     # vocc.py has no loss_layout entry (add_layout is off there)
 
 
 def occupancy_loss_inputs(seed=32, n=4000, classes=16):

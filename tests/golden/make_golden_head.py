@@ -335,4 +335,94 @@ def gen_post(ref):
          recall=np.float64(st['recall']), iou_ssc=st['iou_ssc'], miou=np.float64(st['miou']))
 
 
-GENERATORS = {'head': gen_head, 'loss': gen_loss, 'post': gen_post}
+class _CudaIsHere:
+    """The layout loss of the reference calls ``.cuda()`` on freshly made index tensors (head:786-787, :1175); this
+    container has no GPU.  For the duration of the golden run ``Tensor.cuda`` returns the tensor itself -- the
+    arithmetic is untouched."""
+
+    def __enter__(self):
+        self.old = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda t, *a, **k: t
+
+    def __exit__(self, *a):
+        torch.Tensor.cuda = self.old
+
+
+class _Boxes:
+    """Stand-in for an mmdet3d box object: the two attributes head:1181-1186 read."""
+
+    def __init__(self, arr):
+        self.tensor = T(arr)
+        self.gravity_center = self.tensor[:, :3]
+
+
+def gen_layout(ref):
+    """Room-layout branch (add_layout=True; head:436-532 forward, :760-902 targets, :992-1248 losses, layout_coder.py):
+    the reference head built from vocc.py + add_layout + a loss_layout entry, same seeded weights as the C3 case."""
+    from make_golden import _CameraDir, save
+    head_mod = install_head_stubs()
+    cfg, train_cfg = reference_head_cfg()
+    c = copy.deepcopy(cfg)
+    c.pop('type')
+    head = head_mod.VoxelFormerOccupancyHead(train_cfg=train_cfg['pts'], add_layout=True,
+                                             loss_layout=dict(cases.LAYOUT_LOSS_CFG), **c).eval()
+    code_weights = head.code_weights.detach().clone()
+    syn.load_seeded(head, 7)
+    head.code_weights.data.copy_(code_weights)          # (the seeded fill also hits this non-trainable vector: keep the default)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    g = np.load(os.path.join(HERE, 'head_vocc.npz'))
+    arrays = {}
+    with _CameraDir(w2p, org) as metas:
+        outs = head(T(feats[0]).unsqueeze(1), metas[0])
+    occ = outs['occupancy_preds']
+    assert occ.shape == (1, 35 * 15 * 15, 16) and outs['all_layout_preds'].shape == (6, 1, 100, 10)
+    # same weights, same decoder: the detection outputs equal the C3 case's
+    assert float((outs['all_cls_scores'].detach() - T(g['c3_b0_cls'])).abs().max()) < 1e-5
+    arrays['layout_preds'] = outs['all_layout_preds'].detach().numpy()
+    arrays['occ'] = occ[0, ::5].detach().numpy()
+    arrays['occ_norm'] = np.float64(occ.detach().double().norm())
+    boxes, labels = cases.detection_gt()
+    lay = cases.layout_gt()
+    rng = np.random.default_rng(34)
+    nocc = 35 * 15 * 15
+    sparse_idx = np.sort(rng.choice(nocc, 2000, replace=False))
+    sparse = np.stack([sparse_idx, rng.integers(0, 16, 2000)], 1).astype(np.int64)
+    gt_occ = np.full(nocc, 16, dtype=np.int64)
+    gt_occ[sparse[:, 0]] = sparse[:, 1]
+    arrays['occ_sparse'] = sparse
+    # ---- one layer (the last), with gradients
+    cls = outs['all_cls_scores'][-1].detach().clone().requires_grad_(True)
+    box = outs['all_bbox_preds'][-1].detach().clone().requires_grad_(True)
+    lp = outs['all_layout_preds'][-1].detach().clone().requires_grad_(True)
+    oc = occ.detach().reshape(-1, 16).clone().requires_grad_(True)
+    gtb = torch.cat([T(boxes)[:, :7], torch.zeros(len(boxes), 2)], 1)
+    gtl = torch.cat([T(lay), torch.zeros(1, 2)], 1)
+    with _CudaIsHere():
+        lc, lb, ll, lo, lf = head.loss_single_layout(cls, box, lp, oc, None, [gtb], T(labels), [gtl], None,
+                                                     T(gt_occ), None)
+        (lc + lb + ll + lo).backward()
+        res = head.assigner.assign(lp[0].detach(), None, gtl, torch.zeros(1).long(), None, layout=True)
+    arrays.update(loss_cls=np.float64(lc.detach()), loss_bbox=np.float64(lb.detach()), loss_layout=np.float64(ll.detach()),
+                  loss_occ=np.float64(lo.detach()), layout_gt_inds=res.gt_inds.numpy(), grad_layout=lp.grad.numpy(),
+                  grad_cls=cls.grad.numpy(), grad_box=box.grad.numpy(), grad_occ=oc.grad[::5].numpy())
+    print('  layout: loss_cls %.6f bbox %.6f layout %.6f occ %.6f; layout query %s'
+          % (float(lc), float(lb), float(ll), float(lo), torch.nonzero(res.gt_inds > 0).squeeze(-1).tolist()))
+    # ---- the whole dict through loss_addlayout (bs = 1, box objects, sparse occupancy ground truth).  It sizes the
+    # dense target by head.voxel_num (= 504000, the refined grid), which this branch's coarse occupancy output never
+    # has: the attribute is set to the output's own size for the call
+    head.voxel_num = nocc
+    with _CudaIsHere():
+        d = head.loss_addlayout(_Boxes(boxes[:, :7]), labels, _Boxes(lay), None, [[sparse]], None,
+                                {k: (v.detach() if torch.is_tensor(v) else v) for k, v in outs.items()})
+    arrays['dict_keys'] = np.array(sorted(d))
+    arrays['dict_vals'] = np.array([float(d[k]) for k in sorted(d)], dtype=np.float64)
+    # ---- decoding (layout_coder.py)
+    with _CudaIsHere():
+        dec = head.layout_coder.decode({'all_layout_preds': outs['all_layout_preds'].detach()})
+    arrays['decoded'] = dec[0]['layouts'].numpy()
+    print('  layout: %d boxes decoded inside the range' % len(arrays['decoded']))
+    save('layout_vocc', **arrays)
+
+
+GENERATORS = {'head': gen_head, 'loss': gen_loss, 'post': gen_post, 'layout': gen_layout}

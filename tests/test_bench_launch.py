@@ -1,0 +1,79 @@
+"""bench.py as the driver runs it: `--gpus N` from a plain shell must start N ranks (reference:
+tools/dist_train.sh:12-14 -> one process per GPU; apis/mmdet_train.py:71-80 -> DDP), and the distributed leg
+(process group, DDP wrapper, bf16 compression hook, bucket views) must run on hardware for both training workloads
+(BASELINE.json configs[3] and configs[4])."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+SMALL = ['--batch', '2', '--micro', '2', '--steps', '2', '--warmup', '0', '--no-cpu-baseline',
+         '--latency-batches', '1', '--latency-steps', '2']
+
+
+def run_bench(argv, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def json_line(proc):
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, 'expected ONE json line, got %d\nstdout:\n%s\nstderr:\n%s' % (len(lines), proc.stdout[-2000:], proc.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+def test_gpus_n_spawns_n_ranks_and_relays_exit_code():
+    """No GPU needed: on a CPU-only box every spawned rank stops at bench.py's own 'needs a GPU' assertion; the
+    launcher must have started two of them and must hand their failure back as its exit code.  On a GPU box the
+    same command is the success case below."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('covered by the gpu tests on a GPU box')
+    proc = run_bench(['--gpus', '2', '--backend', 'gloo'] + SMALL)
+    assert proc.returncode != 0
+    assert proc.stderr.count('bench.py needs a GPU') >= 2, proc.stderr[-3000:]
+    # RCCL needs a GPU per rank: refused before anything is spawned
+    proc = run_bench(['--gpus', '2', '--backend', 'nccl'] + SMALL)
+    assert proc.returncode != 0 and 'only 0 GPU(s) visible' in proc.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['vocc_c2f_train', 'vocc_full_train'])
+def test_gpus_2_from_a_plain_shell_runs_two_ranks(workload):
+    """`python bench.py --gpus 2 --backend gloo` (two ranks sharing the one GPU of this box, gradient sum over gloo):
+    one JSON line, n_gpus = 2, twice the viewpoints of one rank per step."""
+    proc = run_bench(['--gpus', '2', '--backend', 'gloo', '--workload', workload] + SMALL)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    line = json_line(proc)
+    assert line['n_gpus'] == 2 and line['config']['parallelism'] == 'dp2'
+    assert line['config']['global_viewpoints_per_step'] == 4
+    assert line['config']['gradient_allreduce'] == 'gloo'
+    assert line['value'] > 0 and line['cpu_baseline'] is None
+    assert line['config']['latency'][0]['viewpoints_per_gpu_per_step'] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('workload', ['vocc_c2f_train', 'vocc_full_train'])
+def test_rccl_leg_runs_on_hardware_with_one_rank(workload):
+    """Under a launcher with WORLD_SIZE=1 the process group is RCCL ('nccl' backend): the communicator, DDP's bucket
+    views, the bf16 compression hook and the all-reduce itself execute on the GPU (with one rank the reduce is the
+    identity, the code path is the N-rank one)."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = run_bench(['--gpus', '1', '--backend', 'nccl', '--workload', workload] + SMALL, env)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    line = json_line(proc)
+    assert line['n_gpus'] == 1
+    assert line['config']['gradient_allreduce'].startswith('RCCL')
+    assert line['roofline'] is not None and line['roofline']['launches'] == 2 * 3

@@ -35,7 +35,7 @@ def test_restated_cfg_builds_variants():
     h = r.build_head(cases.vocc_head_cfg(only_occ=True))
     assert h.transformer.decoder is None and not hasattr(h, 'cls_branches')
     assert h.loss_cls is None
-    with pytest.raises(NotImplementedError, match='add_layout'):
+    with pytest.raises(TypeError, match='loss_layout'):           # the reference builds loss_layout unconditionally
         r.build_head(dict(cases.vocc_head_cfg(), add_layout=True))
 
 
@@ -187,3 +187,77 @@ def test_occupancy_postprocessing_and_metrics_match_reference(tmp_path):
     fs = vio.FeatureStore(str(os_dir))
     v = fs.viewpoint('scanA_vp0')
     assert v.shape == (6, 1, 196, 768) and float(v[3].mean()) == 3.0
+
+
+def _layout_head(device='cpu'):
+    pkg()
+    h = pkg('registry').build_head(dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG, add_layout=True,
+                                        loss_layout=dict(cases.LAYOUT_LOSS_CFG))).eval()
+    cw = h.code_weights.detach().clone()
+    pkg('synthetic').load_seeded(h, 7)
+    h.code_weights.data.copy_(cw)
+    return h.to(device)
+
+
+def layout_loss_checks(h, g, outs_layout, device='cpu'):
+    """Shared by the CPU and the GPU test: losses / gradients / dict / decoding of the layout-enabled head against
+    the reference's (tests/golden/layout_vocc.npz), from given last-layer predictions."""
+    T = torch.from_numpy
+    gh = golden('head_vocc')
+    boxes, labels = cases.detection_gt()
+    lay = cases.layout_gt()
+    nocc = 35 * 15 * 15
+    gt_occ = np.full(nocc, 16, dtype=np.int64)
+    gt_occ[g['occ_sparse'][:, 0]] = g['occ_sparse'][:, 1]
+    cls = T(gh['c3_b0_cls'][-1]).to(device).requires_grad_(True)
+    box = T(gh['c3_b0_bbox'][-1]).to(device).requires_grad_(True)
+    lp = T(g['layout_preds'][-1]).to(device).requires_grad_(True)
+    gtb = torch.cat([T(boxes)[:, :7], torch.zeros(len(boxes), 2)], 1).to(device)
+    gtl = torch.cat([T(lay), torch.zeros(1, 2)], 1).to(device)
+    res = h.assigner.assign(lp[0].detach(), None, gtl, torch.zeros(1, dtype=torch.long, device=device), None, layout=True)
+    assert res.gt_inds.tolist() == g['layout_gt_inds'].tolist()
+    lc, lb, ll, _ = h.loss_single_layout(cls, box, lp, None, [gtb], [T(labels).to(device)], [gtl])
+    assert float(lc) == pytest.approx(float(g['loss_cls']), rel=1e-5)
+    assert float(lb) == pytest.approx(float(g['loss_bbox']), rel=1e-5)
+    assert float(ll) == pytest.approx(float(g['loss_layout']), rel=1e-5)
+    (lc + lb + ll).backward()
+    assert close(lp.grad.cpu(), g['grad_layout'], atol=1e-7, rtol=1e-4)
+    assert close(cls.grad.cpu(), g['grad_cls'], atol=1e-5, rtol=1e-4)
+    assert close(box.grad.cpu(), g['grad_box'], atol=1e-6, rtol=1e-4)
+    # decoding (layout_coder.py) + get_layouts (bottom centre)
+    dec = h.layout_coder.decode({'all_layout_preds': T(g['layout_preds']).to(device)})
+    assert close(dec[0]['layouts'].cpu(), g['decoded'], atol=1e-5, rtol=1e-5)
+    got = h.get_layouts({'all_layout_preds': T(g['layout_preds']).to(device)})[0][0].cpu()
+    want = T(g['decoded']).clone()
+    want[:, 2] -= want[:, 5] * 0.5
+    assert close(got, want, atol=1e-5, rtol=1e-5)
+    return gt_occ, gtb, gtl, labels
+
+
+def test_layout_branch_losses_match_reference():
+    """Room-layout branch (BASELINE configs[4] "room layout"; head:760-902, :992-1248): Hungarian matching on the
+    layout L1 cost, the four loss terms with gradients, the loss dict, the layout coder."""
+    T = torch.from_numpy
+    g = golden('layout_vocc')
+    gh = golden('head_vocc')
+    h = _layout_head()
+    gt_occ, gtb, gtl, labels = layout_loss_checks(h, g, None)
+    # whole dict: stored cls / box / layout predictions of all six layers; the occupancy logits were stored strided,
+    # so its term is checked through the occupancy_loss function on the stored rows instead
+    preds = dict(all_cls_scores=T(gh['c3_b0_cls']), all_bbox_preds=T(gh['c3_b0_bbox']),
+                 all_layout_preds=T(g['layout_preds']), occupancy_preds=None)
+    d = h.loss_addlayout([gtb], [T(labels)], [gtl], None, preds)
+    want = dict(zip([str(k) for k in g['dict_keys']], g['dict_vals']))
+    assert sorted(d) == sorted(want)
+    for k, v in want.items():
+        if k != 'loss_occupancy':
+            assert float(d[k]) == pytest.approx(v, rel=1e-5, abs=1e-7), k
+
+    class Boxes:                                  # the reference's calling convention (bs = 1, mmdet3d box objects)
+        def __init__(self, arr):
+            self.tensor = T(arr)
+            self.gravity_center = self.tensor[:, :3]
+    boxes, _ = cases.detection_gt()
+    d2 = h.loss_addlayout(Boxes(boxes[:, :7]), labels, Boxes(cases.layout_gt()), None, preds)
+    for k in want:
+        assert float(d2[k]) == float(d[k]), k

@@ -188,3 +188,146 @@ def test_occupancy_loss_in_row_order_equals_voxel_order(autocast):
     assert set(res['rows'][1]) == set(res['voxels'][1])
     for k, g in res['voxels'][1].items():
         assert rel_l2(res['rows'][1][k], g) < (2e-3 if autocast else 1e-5), k
+
+
+def test_loss_single_on_gpu_matches_reference():
+    """BASELINE configs[4], loss side, on the device: the reference head's own ``loss_single`` vectors
+    (tests/golden/loss_vocc.npz; head:1251-1384) reproduced by OUR head living on the GPU -- Hungarian matching
+    identical, the three loss values to 1e-5, their gradients as on the CPU."""
+    g = golden('loss_vocc')
+    gh = golden('head_vocc')
+    h = _head(dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG), 7)
+    cls = T(gh['c3_b0_cls'][-1]).to(DEV).requires_grad_(True)
+    box = T(gh['c3_b0_bbox'][-1]).to(DEV).requires_grad_(True)
+    boxes, labels = cases.detection_gt()
+    logits, gt_occ = cases.occupancy_loss_inputs()
+    occ = T(logits).to(DEV).requires_grad_(True)
+    gb, gl = T(boxes).to(DEV), T(labels).to(DEV)
+    res = h.assigner.assign(box[0].detach(), cls[0].detach(), gb, gl)
+    assert res.gt_inds.tolist() == g['gt_inds'].tolist()
+    assert res.labels.tolist() == g['assigned_labels'].tolist()
+    lc, lb, lo = h.loss_single(cls, box, occ, [gb], [gl], T(gt_occ).to(DEV))
+    assert float(lc) == pytest.approx(float(g['loss_cls']), rel=1e-5)
+    assert float(lb) == pytest.approx(float(g['loss_bbox']), rel=1e-5)
+    assert float(lo) == pytest.approx(float(g['loss_occ']), rel=1e-5)
+    (lc + lb + lo).backward()
+    assert close(cls.grad.cpu(), g['grad_cls'], atol=1e-5, rtol=1e-4)
+    assert close(box.grad.cpu(), g['grad_box'], atol=1e-6, rtol=1e-4)
+    assert close(occ.grad.cpu(), g['grad_occ'], atol=1e-7, rtol=1e-4)
+
+
+def test_full_multitask_head_forward_and_loss_on_gpu():
+    """BASELINE configs[4] end to end on one GPU in fp32: ``head(...)`` + ``head.loss(...)`` (head:903-990) for the two
+    golden viewpoints.  The head outputs are pinned to the reference (test_vocc_head_forward_matches_reference); here
+    the loss dict computed on the GPU from the GPU outputs must equal the loss dict our CPU implementation (pinned by
+    loss_vocc.npz) computes from the REFERENCE's outputs, and the occupancy term must equal the oracle's focal loss of
+    the reference logits' own statistics path (fused kernel, 1 M rows)."""
+    syn = pkg('synthetic')
+    gh = golden('head_vocc')
+    cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
+    head = _head(cfg, 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gts = [cases.detection_gt(seed=40 + i, num_gt=3 + i) for i in range(2)]
+    gt_occ = T(np.random.default_rng(9).integers(0, 17, size=(2, 504000)))
+    outs = head(feats, None, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+    losses = head.loss([T(b[:, :7]).to(DEV) for b, _ in gts], [T(l).to(DEV) for _, l in gts], gt_occ.to(DEV), outs)
+    keys = sorted(['loss_cls', 'loss_bbox', 'loss_occupancy', 'loss_flow'] +
+                  ['d%d.loss_%s' % (i, k) for i in range(5) for k in ('cls', 'bbox')])
+    assert sorted(losses) == keys
+    # the same dict on the CPU from the reference's own head outputs
+    pkg()
+    cpu = pkg('registry').build_head(cfg).eval()
+    ref_outs = dict(all_cls_scores=T(np.concatenate([gh['c3_b0_cls'], gh['c3_b1_cls']], 1)),
+                    all_bbox_preds=T(np.concatenate([gh['c3_b0_bbox'], gh['c3_b1_bbox']], 1)), occupancy_preds=None)
+    want = cpu.loss([T(b[:, :7]) for b, _ in gts], [T(l) for _, l in gts], None, ref_outs)
+    for k in keys:
+        if 'cls' in k or 'bbox' in k:
+            assert float(losses[k]) == pytest.approx(float(want[k]), rel=2e-4, abs=1e-6), k
+    from util import oracle
+    occ_want = oracle().focal_loss(outs['occupancy_preds'].detach().cpu().reshape(-1, 16), gt_occ.reshape(-1),
+                                   avg_factor=float((gt_occ < 16).sum()))
+    assert float(losses['loss_occupancy']) == pytest.approx(float(occ_want), rel=1e-5)
+    total = sum(losses.values())
+    total.backward()
+    assert torch.isfinite(total)
+    grads = {k: p.grad for k, p in head.named_parameters() if p.grad is not None}
+    for k in ('cls_branches.5.6.weight', 'reg_branches.0.4.weight', 'transformer.decoder.layers.0.attentions.1.value_proj.weight',
+              'transformer.encoder.layers.0.attentions.0.deformable_attention.sampling_offsets.weight', 'occ_proj.weight',
+              'up_sample.0.weight', 'query_embedding.weight', 'voxel_embedding.weight'):
+        assert k in grads and torch.isfinite(grads[k]).all() and float(grads[k].abs().max()) > 0, k
+
+
+def test_full_multitask_training_steps_bf16():
+    """Two optimiser steps of bench.py's `--workload vocc_full_train` arithmetic (bf16 autocast, occupancy loss in row
+    order, Hungarian targets batched, grad clip, fused AdamW) on 3 viewpoints: finite and decreasing-or-equal is not
+    required, but every parameter that received a gradient in step 1 receives one in step 2 (no unused-parameter
+    drift for DDP) and the parameters move."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    syn = pkg('synthetic')
+    cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
+    torch.manual_seed(2)
+    pkg()
+    head = pkg('registry').build_head(cfg)
+    head.init_weights()
+    for k, p in head.named_parameters():
+        if k.startswith(('layout_branches.', 'query_layout_embedding.')):
+            p.requires_grad_(False)
+    model = bench.FullTrainer(head, 'bf16').to(DEV).train()
+    B = 3
+    w2p, org = syn.camera_batch(B, seed=1)
+    feats = T(syn.vit_features(B, seed=100)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gt = T(np.random.default_rng(7).integers(0, 17, size=(B, 504000))).to(DEV)
+    gts = [syn.detection_gt(seed=40 + i, num_gt=3 + i % 5) for i in range(B)]
+    gb = [T(g[0][:, :7]).to(DEV) for g in gts]
+    gl = [T(g[1]).to(DEV) for g in gts]
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    before = head.occ_proj.weight.detach().clone()
+    seen = []
+    for _ in range(2):
+        loss = model(feats, T(w2p).to(DEV), T(org).to(DEV), gt, gb, gl)
+        loss.backward()
+        assert torch.isfinite(loss)
+        seen.append({k for k, p in model.named_parameters() if p.grad is not None})
+        torch.nn.utils.clip_grad_norm_(params, 300.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    assert seen[0] == seen[1] and len(seen[0]) > 250
+    assert float((head.occ_proj.weight.detach() - before).abs().max()) > 0
+
+
+def test_layout_branch_on_gpu_matches_reference():
+    """Room-layout branch (add_layout=True) end to end on the GPU: forward (head:436-532: coarse occupancy without
+    upsampling + layout boxes from the decoder states) against the reference head's outputs, then the reference's
+    whole ``loss_addlayout`` dict from OUR outputs."""
+    from test_head_cpu import _layout_head, layout_loss_checks
+    syn = pkg('synthetic')
+    g = golden('layout_vocc')
+    gh = golden('head_vocc')
+    torch.backends.cuda.matmul.allow_tf32 = False
+    head = _layout_head(DEV)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    outs = head(T(feats[0]).to(DEV).unsqueeze(1), _metas(w2p, org, [0]))
+    assert outs['all_layout_preds'].shape == (6, 1, 100, 10) and outs['occupancy_preds'].shape == (1, 7875, 16)
+    assert close(outs['all_layout_preds'].detach().cpu(), g['layout_preds'], atol=2e-4, rtol=1e-4)
+    assert close(outs['all_cls_scores'].detach().cpu(), gh['c3_b0_cls'], atol=2e-4, rtol=1e-4)
+    assert close(outs['occupancy_preds'][0, ::5].detach().cpu(), g['occ'], atol=1e-4, rtol=1e-4)
+    norm = float(outs['occupancy_preds'].detach().double().norm())
+    assert abs(norm - float(g['occ_norm'])) < 1e-4 * float(g['occ_norm'])
+    gt_occ, gtb, gtl, labels = layout_loss_checks(head, g, None, device=DEV)
+    d = head.loss_addlayout([gtb], [T(labels).to(DEV)], [gtl], T(gt_occ).to(DEV)[None], outs)
+    want = dict(zip([str(k) for k in g['dict_keys']], g['dict_vals']))
+    assert sorted(d) == sorted(want)
+    for k, v in want.items():
+        assert float(d[k]) == pytest.approx(v, rel=1e-3, abs=1e-6), k
+    sum(d.values()).backward()
+    for name in ('layout_branches.5.4.weight', 'layout_branches.5.0.weight', 'occ_proj.weight'):
+        grad = dict(head.named_parameters())[name].grad
+        assert grad is not None and torch.isfinite(grad).all() and float(grad.abs().max()) > 0, name

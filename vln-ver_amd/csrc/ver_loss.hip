@@ -12,7 +12,8 @@
 //   t=1: d/dx = alpha (1-p)^g [ g p log p - (1-p) ]       t=0: d/dx = (1-alpha) p^g [ p - g (1-p) log(1-p) ]
 //
 // One thread owns 8 consecutive classes of a row (C % 8 == 0): one 16-byte (bf16) or two 16-byte
-// (fp32) loads.  The sum is reduced per workgroup into `partial[blockIdx]` (the caller adds the
+// (fp32) loads.  A target outside [0, C] makes the forward sum NaN (the reference raises in F.one_hot).
+// The sum is reduced per workgroup into `partial[blockIdx]` (the caller adds the
 // <= 4096 partials: deterministic, no float atomics).
 #include "ver_common.h"
 
@@ -80,11 +81,16 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logi
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
         const long row = v / vec_per_row;
         const int c0 = (int)(v - row * vec_per_row) * 8;
-        const int tgt = (int)target[row];
+        const int64_t t64 = target[row];
+        const int tgt = (int)t64;
         float x[8];
         load_x8<BF16>(logits, v, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += focal_term<G2, BF16>(x[j], tgt == c0 + j, gamma, alpha).loss;
+        // a label outside [0, C] (F.one_hot raises on it) poisons the sum: the loss comes out NaN instead of silently
+        // counting the row as background -- checked here, in the pass that reads the labels anyway, so the host needs no
+        // device->host synchronisation per step to be loud about it
+        if ((uint64_t)t64 > (uint64_t)(vec_per_row * 8)) acc = __builtin_nanf("");
     }
     acc = group_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

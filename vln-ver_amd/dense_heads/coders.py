@@ -71,4 +71,18 @@ class NMSFreeCoder(_TopKCoder):
 
 @BBOX_CODERS.register_module(force=True)
 class LayoutCoder(_TopKCoder):
-    pass
+    """core/bbox/coders/layout_coder.py: no scores -- every layout query of the last decoder layer is
+    de-normalised and kept when its centre lies inside ``post_center_range``."""
+
+    def decode_single(self, layout_preds):
+        boxes = denormalize_bbox(layout_preds, self.pc_range)
+        if self.post_center_range is None:
+            raise NotImplementedError('Need to reorganize output as a batch, only '
+                                      'support post_center_range is not None for now!')
+        rng = torch.as_tensor(self.post_center_range, device=boxes.device, dtype=boxes.dtype)
+        mask = (boxes[..., :3] >= rng[:3]).all(1) & (boxes[..., :3] <= rng[3:]).all(1)
+        return dict(layouts=boxes[mask])
+
+    def decode(self, preds_dicts):
+        last = preds_dicts['all_layout_preds'][-1]
+        return [self.decode_single(last[i]) for i in range(last.size(0))]

@@ -41,7 +41,9 @@ def sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, reducti
     return _reduce(loss, weight, reduction, avg_factor)
 
 
-_FOCAL_CHECK = os.environ.get('VER_FOCAL_CHECK', '1') != '0'
+# 0: never check the label range on the host; 1 (default): on a module's first fused call; 2: on every call.
+# Whatever the setting, the kernel itself turns the loss into NaN when a label is outside [0, C] (ver_loss.hip).
+_FOCAL_CHECK = int(os.environ.get('VER_FOCAL_CHECK', '1'))
 
 
 @LOSSES.register_module(force=True)
@@ -51,6 +53,7 @@ class FocalLoss(nn.Module):
         assert use_sigmoid is True, 'Only sigmoid focal loss supported now.'
         self.use_sigmoid, self.gamma, self.alpha = use_sigmoid, gamma, alpha
         self.reduction, self.loss_weight = reduction, loss_weight
+        self._labels_checked = False
 
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         reduction = reduction_override if reduction_override else self.reduction
@@ -59,11 +62,14 @@ class FocalLoss(nn.Module):
                 and pred.dtype in (torch.float32, torch.bfloat16)):
             # Fused path (ver_focal_loss_*): rows >= 4096 only, so the small detection-branch calls keep the torch
             # arithmetic; on bf16 logits the kernel uses the hardware log (tolerances: tests/test_hip_ops_gpu.py).
-            # The kernel compares `target == class`, so a label outside [0, C] would silently count as background
-            # where F.one_hot (and the reference) raise: check once per call.  VER_FOCAL_CHECK=0 skips the check (it
-            # costs one device->host sync).
-            if _FOCAL_CHECK and target.numel():
-                lo, hi = int(target.min()), int(target.max())
+            # A label outside [0, C] raises in F.one_hot (and in the reference).  The kernel answers it with a NaN loss
+            # (no synchronisation); the host-side range check with its readable message costs a device->host sync and
+            # a reduction over every label, so it runs on the first fused call of a module only (VER_FOCAL_CHECK=2:
+            # every call, 0: never) -- not inside every training step.
+            if target.numel() and (_FOCAL_CHECK >= 2 or (_FOCAL_CHECK == 1 and not self._labels_checked)):
+                self._labels_checked = True
+                lo, hi = torch.aminmax(target)
+                lo, hi = torch.stack((lo, hi)).tolist()
                 if lo < 0 or hi > pred.size(1):
                     raise RuntimeError('FocalLoss: target labels must be in [0, %d], got [%d, %d]' % (pred.size(1), lo, hi))
             from ..hipops import sigmoid_focal_loss_sum

@@ -55,9 +55,6 @@ class VoxelFormerOccupancyHead(BaseModule):
         super().__init__(init_cfg)
         if args:
             raise TypeError('VoxelFormerOccupancyHead takes keyword arguments only')
-        if add_layout:
-            raise NotImplementedError('add_layout=True (room-layout branch, head:436-532) is off in '
-                                      'vocc.py and not built')
         if occ_head_type != 'mlp' or with_color_render or with_occupancy_flow:
             raise NotImplementedError('only the mlp occupancy head of vocc.py is built')
         self.bev_h, self.bev_w, self.bev_z = bev_h, bev_w, bev_z
@@ -66,6 +63,10 @@ class VoxelFormerOccupancyHead(BaseModule):
         self.occ_loss_type = occ_loss_type
         self.refine_occ = refine_occ
         self.num_layout_query = num_layout_query
+        # room-layout branch (head:96-105): its own, fixed range and coder
+        self.layout_range = [-50.0, -50.0, -5.0, 50.0, 50.0, 5.0]
+        self.layout_coder = build_bbox_coder(dict(type='LayoutCoder', post_center_range=[-50, -50, -5.0, 50, 50, 5.0],
+                                                  pc_range=self.layout_range, max_num=10, num_classes=1))
         self.getbev = getbev
         self.with_box_refine, self.as_two_stage = with_box_refine, as_two_stage
         if as_two_stage:
@@ -125,6 +126,10 @@ class VoxelFormerOccupancyHead(BaseModule):
         if only_occ:
             self.loss_cls = None
             self.loss_bbox = None
+        if add_layout:                                  # head:176-177
+            if loss_layout is None:
+                raise TypeError('add_layout=True needs a loss_layout config (the reference builds it unconditionally)')
+            self.loss_layout = build_loss(loss_layout)
 
     def _init_layers(self):
         """Same module tree / names as head:180-266."""
@@ -336,10 +341,16 @@ class VoxelFormerOccupancyHead(BaseModule):
             reg_branches=self.reg_branches if self.with_box_refine else None,
             cls_branches=None, **common)
         # bev_embed [Nq,bs,C] is a permuted view of the contiguous [bs,Nq,C] encoder output
-        occupancy = None if self.only_det else self.occupancy_from_volume(bev_embed.permute(1, 0, 2),
-                                                                          rows_only=occupancy_rows)
+        if self.only_det:
+            occupancy = None
+        elif self.add_layout:
+            # head:458-474: the layout branch of the reference never upsamples -- plain [bs,Z,H,W,C] view,
+            # occ_proj, occ_branches on the coarse grid (X*Y = bev_h*bev_w cells, occ_zdim layers)
+            occupancy = self._only_occ(bev_embed.permute(1, 0, 2))
+        else:
+            occupancy = self.occupancy_from_volume(bev_embed.permute(1, 0, 2), rows_only=occupancy_rows)
         hs = hs.permute(0, 2, 1, 3)
-        classes, coords = [], []
+        classes, coords, layouts = [], [], []
         for lvl in range(hs.shape[0]):
             reference = init_reference if lvl == 0 else inter_references[lvl - 1]
             reference = inverse_sigmoid(reference)
@@ -353,8 +364,19 @@ class VoxelFormerOccupancyHead(BaseModule):
             z = zc * (self.pc_range[5] - self.pc_range[2]) + self.pc_range[2]
             coords.append(torch.cat([x, y, tmp[..., 2:4], z, tmp[..., 5:]], -1))
             classes.append(cls)
+            if self.add_layout:
+                # head:501-513: the room layout is regressed from the SAME decoder states by its own branch and
+                # de-normalised into the (fixed, 100 m) layout range
+                lay = self.layout_branches[lvl](hs[lvl])
+                lr = self.layout_range
+                lxy = (lay[..., 0:2] + reference[..., 0:2]).sigmoid()
+                lz = (lay[..., 4:5] + reference[..., 2:3]).sigmoid()
+                layouts.append(torch.cat([lxy[..., 0:1] * (lr[3] - lr[0]) + lr[0],
+                                          lxy[..., 1:2] * (lr[4] - lr[1]) + lr[1], lay[..., 2:4],
+                                          lz * (lr[5] - lr[2]) + lr[2], lay[..., 5:]], -1))
         return dict(bev_embed=bev_embed, all_cls_scores=torch.stack(classes),
-                    all_bbox_preds=torch.stack(coords), all_layout_preds=None,
+                    all_bbox_preds=torch.stack(coords),
+                    all_layout_preds=torch.stack(layouts) if self.add_layout else None,
                     occupancy_preds=occupancy, flow_preds=None, enc_cls_scores=None,
                     enc_bbox_preds=None, enc_occupancy_preds=None)
 
@@ -470,6 +492,102 @@ class VoxelFormerOccupancyHead(BaseModule):
                 losses['d%d.loss_cls' % lvl] = lc
                 losses['d%d.loss_bbox' % lvl] = lb
         return losses
+
+    # ------------------------------------------------------------------ room-layout branch (add_layout=True)
+    def _layout_targets_single(self, layout_pred, gt_layout):
+        """Layout half of ``_get_target_layout_single`` (head:760-841): Hungarian matching on the L1 cost of the
+        normalised box alone (``assign(..., layout=True)``; all layout boxes carry label 0), matched queries get
+        weight 1 and their ground-truth box as target.  -> (targets [Nq,9], weights [Nq,10], #pos, #neg)."""
+        if gt_layout.dim() == 1:
+            gt_layout = gt_layout[None]
+        zeros = torch.zeros(gt_layout.shape[0], dtype=torch.long, device=layout_pred.device)
+        res = self.assigner.assign(layout_pred, None, gt_layout, zeros, None, layout=True)
+        sr = SamplingResult(res, layout_pred, gt_layout)
+        targets = torch.zeros_like(layout_pred)[..., :gt_layout.shape[-1]]
+        weights = torch.zeros_like(layout_pred)
+        weights[sr.pos_inds] = 1.0
+        targets[sr.pos_inds] = sr.pos_gt_bboxes.to(targets.dtype)
+        return targets, weights, sr.pos_inds.numel(), sr.neg_inds.numel()
+
+    def loss_single_layout(self, cls_scores, bbox_preds, layout_preds, occupancy_preds, gt_bboxes_list,
+                           gt_labels_list, gt_layout_list, gt_occupancy=None):
+        """One decoder layer's losses with the layout term (head:992-1104): ``loss_single`` plus a code-weighted L1
+        on the layout boxes normalised like detection boxes, averaged over the (all-reduced) number of matched
+        layout queries.  -> (loss_cls, loss_bbox, loss_layout, loss_occupancy)."""
+        loss_cls, loss_bbox, loss_occ = self.loss_single(cls_scores, bbox_preds, occupancy_preds, gt_bboxes_list,
+                                                         gt_labels_list, gt_occupancy)
+        out = [self._layout_targets_single(layout_preds[i], gt_layout_list[i]) for i in range(layout_preds.size(0))]
+        layout_targets = torch.cat([o[0] for o in out], 0)
+        layout_weights = torch.cat([o[1] for o in out], 0)
+        num_layout_pos = sum(o[2] for o in out)
+        num_layout_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([float(num_layout_pos)])), min=1).item()
+        layout_preds = layout_preds.reshape(-1, layout_preds.size(-1))
+        normalized = normalize_bbox(layout_targets, self.layout_range)
+        ok = torch.isfinite(normalized).all(dim=-1)
+        layout_weights = layout_weights * self.code_weights
+        loss_layout = self.loss_layout(layout_preds[ok, :10], normalized[ok, :10], layout_weights[ok, :10],
+                                       avg_factor=num_layout_pos)
+        return loss_cls, loss_bbox, torch.nan_to_num(loss_layout), loss_occ
+
+    @staticmethod
+    def _boxes_as_tensor(b, device):
+        """mmdet3d box object (``gravity_center`` + ``tensor``, head:1181-1186) or plain [G, 7..9] tensor -> [G, 9]
+        (gravity centre, dims, yaw, zero-padded velocity)."""
+        if hasattr(b, 'gravity_center'):
+            b = torch.cat((b.gravity_center, b.tensor[:, 3:]), dim=1)
+        b = torch.as_tensor(b).to(device)
+        if b.dim() == 1:
+            b = b[None]
+        if b.shape[-1] < 9:
+            b = torch.cat([b, b.new_zeros(b.shape[0], 9 - b.shape[-1])], dim=1)
+        return b
+
+    def loss_addlayout(self, gt_bboxes_list, gt_labels_list, gt_layout_list, gt_occupancy, preds_dicts):
+        """Loss dict of the layout-enabled head (head:1106-1248): every decoder layer contributes its detection
+        terms (``d{i}.loss_cls`` / ``d{i}.loss_bbox``), the last layer additionally ``loss_layout``,
+        ``loss_occupancy`` and the zero ``loss_flow``.  Lists are per sample (the reference is bs=1 and takes the
+        single sample's box objects directly: those are accepted too)."""
+        all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
+        all_layout, occ = preds_dicts['all_layout_preds'], preds_dicts['occupancy_preds']
+        dev = all_box.device
+        if not isinstance(gt_bboxes_list, (list, tuple)):
+            gt_bboxes_list, gt_labels_list, gt_layout_list = [gt_bboxes_list], [gt_labels_list], [gt_layout_list]
+        boxes = [self._boxes_as_tensor(b, dev) for b in gt_bboxes_list]
+        layouts = [self._boxes_as_tensor(b, dev) for b in gt_layout_list]
+        labels = [torch.as_tensor(x, device=dev).long() for x in gt_labels_list]
+        nl = len(all_cls)
+        losses = {}
+        for lvl in range(nl):
+            last = lvl == nl - 1
+            lc, lb, ll, lo = self.loss_single_layout(all_cls[lvl], all_box[lvl], all_layout[lvl],
+                                                     occ if last else None, boxes, labels, layouts,
+                                                     gt_occupancy if last else None)
+            if last:
+                losses.update(loss_cls=lc, loss_bbox=lb, loss_occupancy=lo, loss_flow=torch.zeros_like(lc),
+                              loss_layout=ll)
+            else:
+                losses['d%d.loss_cls' % lvl] = lc
+                losses['d%d.loss_bbox' % lvl] = lb
+        return losses
+
+    def _to_box_type(self, boxes, img_meta):
+        """head:1466-1471: bottom centre + the dataset's box class when the meta carries one."""
+        boxes = boxes.clone()
+        boxes[:, 2] = boxes[:, 2] - boxes[:, 5] * 0.5
+        box_type = (img_meta or {}).get('box_type_3d')
+        return box_type(boxes, boxes.shape[-1]) if box_type is not None else boxes
+
+    def get_bboxes(self, preds_dicts, img_metas=None, rescale=False):
+        """head:1450-1476: NMS-free top-k decoding of the last decoder layer."""
+        preds = self.bbox_coder.decode(preds_dicts)
+        metas = img_metas or [None] * len(preds)
+        return [[self._to_box_type(p['bboxes'], m), p['scores'], p['labels']] for p, m in zip(preds, metas)]
+
+    def get_layouts(self, preds_dicts, img_metas=None):
+        """head:1478-1502: layout boxes of the last decoder layer inside the layout range."""
+        preds = self.layout_coder.decode(preds_dicts)
+        metas = img_metas or [None] * len(preds)
+        return [[self._to_box_type(p['layouts'], m)] for p, m in zip(preds, metas)]
 
     # ---- Hungarian targets of all decoder layers and samples with ONE device->host round trip
     def _batched_targets(self, all_cls, all_box, gt_boxes, gt_labels):

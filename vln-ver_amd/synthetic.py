@@ -138,3 +138,15 @@ def load_seeded(module, seed):
             if k in vals:
                 v.copy_(torch.from_numpy(vals[k]))
     return module
+
+
+def detection_gt(seed=31, num_gt=5, num_classes=17):
+    """Synthetic ground truth for the detection losses: boxes [G,9] = (cx,cy,cz,w,l,h,yaw,vx,vy)
+    inside the vocc.py range, labels in [0, num_classes)."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform([-5, -5, -1.2], [5, 5, 1.7], (num_gt, 3))
+    d = rng.uniform(0.3, 2.0, (num_gt, 3))
+    yaw = rng.uniform(-3.1, 3.1, (num_gt, 1))
+    boxes = np.concatenate([c, d, yaw, np.zeros((num_gt, 2))], 1).astype(np.float32)
+    labels = rng.integers(0, num_classes, num_gt).astype(np.int64)
+    return boxes, labels

@@ -425,4 +425,33 @@ def gen_layout(ref):
     save('layout_vocc', **arrays)
 
 
-GENERATORS = {'head': gen_head, 'loss': gen_loss, 'post': gen_post, 'layout': gen_layout}
+def gen_init(ref):
+    """a11: the reference's ``init_weights`` chain (head:269-279 -> voxel_transformer.py:99-116 ->
+    spatial_cross_attention.py:255-273) on the head built from vocc.py: the deterministic results in full (offset-bias
+    ring, zeroed projections, focal-prior biases), the random ones by their statistics, and WHICH entries the chain
+    touches at all."""
+    from make_golden import save
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import init_report                    # (shared with the test that runs it on OUR head)
+    head_mod = install_head_stubs()
+    cfg, _ = reference_head_cfg()
+    c = copy.deepcopy(cfg)
+    c.pop('type')
+    torch.manual_seed(0)
+    head = head_mod.VoxelFormerOccupancyHead(**c)
+    rep = init_report(head)
+    sd = head.state_dict()
+    pre = 'transformer.encoder.layers.0.attentions.0.deformable_attention.'
+    arrays = {'rep_' + k: v for k, v in rep.items()}
+    arrays['enc_offset_bias'] = sd[pre + 'sampling_offsets.bias'].numpy()
+    dec = 'transformer.decoder.layers.0.attentions.1.'
+    arrays['dec_offset_bias'] = sd[dec + 'sampling_offsets.bias'].numpy()      # construction-time ring (3-D); the chain skips it
+    arrays['cls_prior_bias'] = sd['cls_branches.5.6.bias'].numpy()
+    arrays['occ_prior_bias'] = sd['occ_branches.6.bias'].numpy()
+    n_changed = int(rep['changed'].sum())
+    print('  init: %d of %d float entries re-initialised; cls prior %.5f' % (n_changed, len(rep['names']),
+                                                                         float(arrays['cls_prior_bias'][0])))
+    save('init_vocc', **arrays)
+
+
+GENERATORS = {'head': gen_head, 'loss': gen_loss, 'post': gen_post, 'layout': gen_layout, 'init': gen_init}

@@ -165,3 +165,90 @@ def test_oracle_agrees_on_gpu_host():
     """The CPU oracle gives the golden answer on this host too (its BLAS may differ)."""
     from test_oracle_golden import test_get_voxel_features_full_width
     test_get_voxel_features_full_width('vocc')
+
+
+def _train_mode_encoder(dims=256, seed=33):
+    _noTF32()
+    pkg()
+    enc = pkg('registry').build_transformer_layer_sequence(
+        cases.small_encoder_cfg(dims=dims, heads=8, points=8, ffn=2 * dims, layers=1))
+    pkg('synthetic').load_seeded(enc, seed)
+    return enc.to(DEV)
+
+
+def _run_encoder(enc, q, feats, w2p, org, grid):
+    z, h, w = grid
+    return enc(q, feats, feats, bev_z=z, bev_h=h, bev_w=w, bev_pos=None,
+               spatial_shapes=torch.tensor([[14, 14]], device=DEV), level_start_index=torch.tensor([0], device=DEV),
+               prev_bev=None, world2pixel=w2p, origin=org)
+
+
+def test_encoder_layer_training_mode_dropout_fused_vs_plain():
+    """Training mode (dropout p = 0.1 in the attention tail, the FFN hidden block and the FFN tail): the fused passes
+    (``ver_add_ln_*``, ``ver_relu_dropout_*``: keep-mask = hash(seed, index)) against the plain torch sequence
+    (``VER_FUSED_ADD_LN=0``).  The masks differ by construction, so the comparison is
+    (1) statistical -- the mean output over 48 mask draws agrees with the plain path's as well as two independent
+        plain-path means agree with each other;
+    (2) the gradient THROUGH the kept mask -- with the generator re-seeded the fused step is a deterministic function,
+        and its autograd gradient matches a central finite difference along a random direction;
+    (3) a Dropout module switched to eval() inside a train()-mode parent does not drop (the unfused semantics)."""
+    bricks = pkg('modules.bricks')
+    syn = pkg('synthetic')
+    grid = (2, 6, 5)
+    nq = 60
+    rng = np.random.default_rng(5)
+    w2p_np, org_np = syn.camera_batch(2, seed=1)
+    w2p, org = T(w2p_np).to(DEV), T(org_np).to(DEV)
+    q = T(rng.standard_normal((nq, 2, 256)).astype(np.float32)).to(DEV)
+    feats = T(rng.standard_normal((6, 196, 2, 256)).astype(np.float32)).to(DEV)
+    enc = _train_mode_encoder().train()
+
+    def mean_out(fused, reps, seed0):
+        old = bricks._FUSED_ADD_LN
+        bricks._FUSED_ADD_LN = fused
+        try:
+            acc = 0
+            with torch.no_grad():
+                for r in range(reps):
+                    torch.manual_seed(seed0 + r)
+                    acc = acc + _run_encoder(enc, q, feats, w2p, org, grid).double()
+            return acc / reps
+        finally:
+            bricks._FUSED_ADD_LN = old
+
+    reps = 48
+    plain_a, plain_b = mean_out(False, reps, 1000), mean_out(False, reps, 2000)
+    fused = mean_out(True, reps, 3000)
+    noise = float((plain_a - plain_b).norm() / plain_a.norm())
+    diff = float((fused - plain_a).norm() / plain_a.norm())
+    print('dropout statistics: plain-vs-plain %.4f fused-vs-plain %.4f' % (noise, diff))
+    assert noise > 1e-3                    # dropout is really on
+    assert diff < 1.3 * noise
+    # (2) gradient through the kept mask
+    qg = q.clone().requires_grad_(True)
+    g = T(rng.standard_normal((2, nq, 256)).astype(np.float32)).to(DEV)
+    torch.manual_seed(77)
+    out = _run_encoder(enc, qg, feats, w2p, org, grid)
+    torch.manual_seed(77)
+    assert torch.equal(out.detach(), _run_encoder(enc, q, feats, w2p, org, grid).detach())     # same seed, same masks
+    (out * g).sum().backward()
+    v = T(rng.standard_normal(q.shape).astype(np.float32)).to(DEV)
+    eps = 2e-3
+    with torch.no_grad():
+        torch.manual_seed(77)
+        fp = (_run_encoder(enc, q + eps * v, feats, w2p, org, grid).double() * g).sum()
+        torch.manual_seed(77)
+        fm = (_run_encoder(enc, q - eps * v, feats, w2p, org, grid).double() * g).sum()
+    fd = float((fp - fm) / (2 * eps))
+    an = float((qg.grad.double() * v).sum())
+    print('directional derivative: autograd %.5f finite difference %.5f' % (an, fd))
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an))
+    # (3) only the Dropout modules in eval(): nothing is dropped although the parent is in train()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    with torch.no_grad():
+        a = _run_encoder(enc, q, feats, w2p, org, grid)
+        enc.eval()
+        b = _run_encoder(enc, q, feats, w2p, org, grid)
+    assert torch.equal(a, b)

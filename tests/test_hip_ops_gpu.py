@@ -901,3 +901,63 @@ def test_relu_dropout_fused(dtype, p_drop):
     want_g = torch.where(kept, gy.float() / (1 - p_drop), torch.zeros(()))
     assert close(xd.grad.float().cpu(), want_g, atol=1e-6, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
     assert hip.relu_dropout(torch.zeros(0, 8, device=DEV), 0.1).shape == (0, 8)
+
+
+def test_focal_loss_label_range_is_loud_without_a_sync_per_step():
+    """A label outside [0, C] raises in F.one_hot (and in the reference).  The fused path: (a) the first call of a
+    FocalLoss module checks the range on the host and raises with the range in the message; (b) afterwards no host
+    check runs (no device->host synchronisation inside a training step) and the kernel itself answers a bad label
+    with a NaN loss instead of silently counting the row as background."""
+    hip = pkg('hipops')
+    losses = pkg('dense_heads.losses')
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    logits = torch.randn(5000, 16, generator=gen).to(DEV)
+    good = torch.randint(0, 17, (5000,), generator=gen).to(DEV)
+    for bad_label in (17, -1, 2 ** 32 + 3):           # (2^32 + 3 would alias class 3 if the kernel truncated to 32 bits)
+        bad = good.clone()
+        bad[1234] = bad_label
+        mod = losses.FocalLoss(loss_weight=1.0)
+        with pytest.raises(RuntimeError, match='target labels must be in'):
+            mod(logits, bad, avg_factor=100.0)
+        mod = losses.FocalLoss(loss_weight=1.0)
+        assert torch.isfinite(mod(logits, good, avg_factor=100.0))        # first call: host check passes
+        assert torch.isnan(mod(logits, bad, avg_factor=100.0))            # later calls: the kernel's NaN
+        assert torch.isnan(hip.sigmoid_focal_loss_sum(logits.bfloat16(), bad))
+    assert torch.isfinite(hip.sigmoid_focal_loss_sum(logits, good))
+
+
+def test_sca_gather_three_camera_overlap_determinism_bound():
+    """The determinism contract of ``ver_sca_forward`` (include/ver_ops.h): rows seen by <= 2 cameras are bitwise
+    reproducible; rows seen by >= 3 cameras are accumulated with fp32 atomics whose order is not fixed, so they may
+    differ run to run -- by no more than the rounding of a 3-6 term fp32 sum.  A wide-angle rig (137 degree cameras
+    every 60 degrees) makes 3-camera voxels; 20 runs are compared with the first and with the oracle."""
+    hip = pkg('hipops')
+    syn = pkg('synthetic')
+    o = oracle()
+    rng = np.random.default_rng(17)
+    B, grid, heads, hd, P = 2, (4, 15, 15), 8, 96, 8
+    z, h, w = grid
+    nq = z * h * w
+    org = syn.viewpoint_origins(B, seed=1)
+    w2p = np.stack([syn.camera_rig(og, fx=250.0, fy=250.0) for og in org]).astype(np.float32)
+    hit = hip.project_points(T(w2p).to(DEV), T(org.astype(np.float32)).to(DEV), cases.PC_RANGE, z, h, w)
+    mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()           # [B, Ncam, Nq]
+    ncam = mask.sum(1)
+    assert int(ncam.max()) >= 3 and int((ncam >= 3).sum()) > 50, 'rig does not produce 3-camera voxels'
+    value = T(rng.standard_normal((B, 6, 196, heads, hd)).astype(np.float32))
+    offsets = T((rng.standard_normal((B, nq, heads, P, 2)) * 3.0).astype(np.float32))
+    logits = T(rng.standard_normal((B, nq, heads, P)).astype(np.float32))
+    for vdev in (value.to(DEV), value.to(DEV).bfloat16()):
+        first = hip.sca_gather(vdev, offsets.to(DEV), logits.to(DEV), hit, 14, 14)
+        worst = 0.0
+        for _ in range(20):
+            again = hip.sca_gather(vdev, offsets.to(DEV), logits.to(DEV), hit, 14, 14)
+            d = (again - first).abs()
+            assert float(d[ncam.to(DEV) <= 2].max()) == 0.0          # <= 2 cameras: bitwise
+            worst = max(worst, float(d.max()))
+        scale = float(first.abs().max())
+        print('3-camera rows: %d, run-to-run max |diff| %.3e (|slots| max %.2f)' % (int((ncam >= 3).sum()), worst, scale))
+        assert worst <= 8 * 2.0 ** -24 * scale                        # a few ulps of the largest partial sum
+    ref = oracle_slots(o, value, offsets, logits, hit.uv.cpu(), mask, (14, 14))
+    first = hip.sca_gather(value.to(DEV), offsets.to(DEV), logits.to(DEV), hit, 14, 14)
+    assert maxdiff(first.cpu(), ref) < 2e-5

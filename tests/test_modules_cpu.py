@@ -127,3 +127,41 @@ def test_get_reference_points_matches_oracle():
     assert ref.shape == (2, 1, 900, 3)
     assert torch.equal(ref[0, 0], oracle().reference_points_3d(4, 15, 15))
     assert torch.equal(ref[0, 0], torch.from_numpy(golden('point_sampling')['vocc_ref3d']))
+
+
+def test_init_weights_chain_matches_reference_fixture():
+    """a11 pinned: the reference's own ``init_weights`` chain on the vocc.py head (tests/golden/init_vocc.npz,
+    generated by running the reference's files) against OUR head AND the oracle's restatement -- the same entries are
+    re-initialised, constants are the same constants (zeroed projections, focal-prior biases -log 99), the offset
+    ring is identical, and the random initialisers draw from the same distributions (std within 5 %, |max| inside the
+    same xavier bound)."""
+    from util import init_report
+    g = golden('init_vocc')
+    pkg()
+    torch.manual_seed(0)
+    head = pkg('registry').build_head(cases.vocc_head_cfg())
+    rep = init_report(head)
+    assert [str(n) for n in rep['names']] == [str(n) for n in g['rep_names']]
+    names = [str(n) for n in g['rep_names']]
+    bad = [n for n, a, b in zip(names, rep['changed'], g['rep_changed']) if bool(a) != bool(b)]
+    assert not bad, 'init_weights touches a different set of entries: %s' % bad[:8]
+    bad = [n for n, a, b in zip(names, rep['const'], g['rep_const']) if bool(a) != bool(b)]
+    assert not bad, bad[:8]
+    for n, c, a, b in zip(names, g['rep_const'], rep['value'], g['rep_value']):
+        if c:
+            assert a == pytest.approx(b, abs=1e-7), n
+    for n, c, sa, sb, ma, mb in zip(names, g['rep_const'], rep['std'], g['rep_std'], rep['amax'], g['rep_amax']):
+        if not c and 'sampling_offsets.bias' not in n:
+            assert sa == pytest.approx(sb, rel=0.05), (n, sa, sb)
+            if ma < 1.0:                          # bounded (uniform) initialisers: same bound
+                assert ma == pytest.approx(mb, rel=0.02), (n, ma, mb)
+    sd = head.state_dict()
+    pre = 'transformer.encoder.layers.%d.attentions.0.deformable_attention.sampling_offsets.bias'
+    for layer in range(3):
+        assert torch.equal(sd[pre % layer], torch.from_numpy(g['enc_offset_bias']))
+    assert torch.allclose(oracle().msda3d_init(8, 1, 8), torch.from_numpy(g['enc_offset_bias']), atol=1e-7)
+    assert torch.equal(sd['transformer.decoder.layers.0.attentions.1.sampling_offsets.bias'],
+                       torch.from_numpy(g['dec_offset_bias']))
+    assert torch.allclose(sd['cls_branches.5.6.bias'], torch.from_numpy(g['cls_prior_bias']), atol=1e-7)
+    assert torch.allclose(sd['occ_branches.6.bias'], torch.from_numpy(g['occ_prior_bias']), atol=1e-7)
+    assert float(g['cls_prior_bias'][0]) == pytest.approx(-float(np.log(99.0)), abs=1e-6)

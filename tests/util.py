@@ -107,3 +107,26 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def init_report(head):
+    """What ``init_weights`` did to a freshly built head, in a form two implementations can be compared by:
+    per state-dict entry whether it was re-initialised (differs from its construction-time value), whether the
+    result is a constant, its value if so, and its std / |max| otherwise."""
+    before = {k: v.detach().clone() for k, v in head.state_dict().items()}
+    head.init_weights()
+    names, changed, const, value, std, amax = [], [], [], [], [], []
+    for k, v in head.state_dict().items():
+        if not v.dtype.is_floating_point:
+            continue
+        v = v.detach().double()
+        names.append(k)
+        changed.append(bool((v != before[k].double()).any()))
+        c = bool((v == v.flatten()[0]).all())
+        const.append(c)
+        value.append(float(v.flatten()[0]) if c else float('nan'))
+        std.append(float(v.std()) if v.numel() > 1 else 0.0)
+        amax.append(float(v.abs().max()))
+    return dict(names=np.array(names), changed=np.array(changed), const=np.array(const),
+                value=np.array(value, dtype=np.float64), std=np.array(std, dtype=np.float64),
+                amax=np.array(amax, dtype=np.float64))

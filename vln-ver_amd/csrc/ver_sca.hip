@@ -1972,7 +1972,15 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             const int nlp = (cs_nload >= 0 && cs_nload < pt / 64) ? cs_nload : 0;
             const size_t tb = (tile_bytes + 15) & ~(size_t)15;
             const size_t ldsp = (nlp > 0 ? 2 : 1) * tb + (size_t)(pt / 64) * 512;
-            if (use_cs && ldsp <= kMaxLds) {
+            // k_sca_fwd_cs addresses slots / offsets / logits / uv with 32-bit byte offsets (`__umul24` row products):
+            // every one of them must stay below 2^32 and the 24-bit multiplicands below 2^24, else the generic
+            // kernel (64-bit addressing) takes the launch
+            const size_t row_b = (size_t)heads * head_dim * 4;
+            const bool cs_addr_ok = (size_t)Nq * row_b < ((size_t)1 << 32) &&
+                                    (size_t)Nq * heads * points * 8 < ((size_t)1 << 32) &&
+                                    (size_t)Nq * D * 8 < ((size_t)1 << 32) && row_b < ((size_t)1 << 24) &&
+                                    (size_t)heads * points * 8 < ((size_t)1 << 24) && Nq < (1 << 24);
+            if (use_cs && ldsp <= kMaxLds && cs_addr_ok) {
                 int hsp = 1;
                 while (hsp < cs_hsplit && hsp < heads && heads % (hsp * 2) == 0) hsp *= 2;
                 const int units = B * Ncam * nchunks * hsp;
@@ -2014,9 +2022,14 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
 
 // dtype ver_sca_backward writes d(value) in most cheaply for this problem: VER_BF16 on the matrix-core path (bf16 value
 // tiles, 8 points, head_dim % 32 == 0, tile fits), else VER_F32.  VER_F32 is always accepted.
+static bool sca_bwd_use_mm() {       // read ONCE per process: the dtype query and the dispatch can never disagree
+    static const int v = env_int("VER_SCA_BWD_MM", 1);
+    return v != 0;
+}
+
 extern "C" int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int points, int map_h, int map_w) {
     if (value_dtype != VER_BF16 || points != 8 || head_dim % 32 != 0 || head_dim > 128) return VER_F32;
-    if (env_int("VER_SCA_BWD_MM", 1) == 0) return VER_F32;
+    if (!sca_bwd_use_mm()) return VER_F32;
     const int nk = map_h * map_w, mt = (nk + 15) / 16;
     const size_t tile_b = ((size_t)nk * head_dim * 2 + 15) & ~(size_t)15, ds_b = (size_t)nk * kMmDss * 4,
                  g_b = (size_t)2 * 32 * head_dim * 2;
@@ -2055,7 +2068,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
         if constexpr (P == 8 && HD % 32 == 0) {
             // bf16 value tiles: everything on the matrix cores, one kernel (VER_SCA_BWD_MM=0: the two-kernel path below)
-            static const int use_mm = env_int("VER_SCA_BWD_MM", 1);
+            const bool use_mm = sca_bwd_use_mm();
             const int nk = map_h * map_w, mt = (nk + 15) / 16;
             const size_t tile_b = ((size_t)nk * HD * 2 + 15) & ~(size_t)15, ds_b = (size_t)nk * kMmDss * 4, g_b = (size_t)2 * 32 * HD * 2;
             // the last tile-row tile reads (16 mt - nk) rows past the tile / past DS: they must stay inside the allocation
@@ -2082,6 +2095,9 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                 return launch_mm(k_sca_bwd_mm<HD, 0, float, kMmWaves>, (float*)nullptr);
             }
         }
+        // everything below writes d(value) as fp32 (twice the bytes of a bf16 buffer): never fall through with one
+        VER_REQUIRE(grad_value_dtype == VER_F32, VER_EUNSUPPORTED,
+                    "ver_sca_backward: bf16 d(value) is only written by the matrix-core kernel; this shape runs the fp32 paths");
         if constexpr (G == 16) {
             if (map_h * map_w <= kValMaxRows) {
                 // ---- d(offsets), d(logits): forward-shaped kernel

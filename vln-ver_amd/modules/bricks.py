@@ -88,7 +88,7 @@ class FFN(BaseModule):
             h = block[0](x)
             if h.numel() % 4 == 0 and h.dtype in (torch.float32, torch.bfloat16):
                 from ..hipops import relu_dropout
-                return relu_dropout(h, block[2].p if self.training else 0.0)
+                return relu_dropout(h, block[2].p if block[2].training else 0.0)
             return block[2](block[1](h))
         return block(x)
 
@@ -102,7 +102,7 @@ class FFN(BaseModule):
             out = x_in
             for i in range(len(self.layers) - 1):
                 out = self._hidden(self.layers[i], out)
-            return PendingResidual(out, x if identity is None else identity, last.p if self.training else 0.0)
+            return PendingResidual(out, x if identity is None else identity, last.p if last.training else 0.0)
         out = self.layers(x_in)
         if not self.add_identity:
             return self.dropout_layer(out)

@@ -57,7 +57,7 @@ class SpatialCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
                 bev_mask=None, level_start_index=None, flag='encoder', hit_table=None,
-                map_hw=None, defer_residual=False, **kwargs):
+                map_hw=None, defer_residual=False, value_lowp=None, **kwargs):
         """query [bs,Nq,C]; key/value [Ncam,Nk,bs,C]; reference_points_cam [Ncam,bs,Nq,D,2];
         bev_mask [Ncam,bs,Nq,D] -> [bs,Nq,C].
 
@@ -85,8 +85,11 @@ class SpatialCrossAttention(BaseModule):
         num_cams, nk, vbs, c = value.shape
         assert num_cams == self.num_cams and vbs == bs and nk == map_hw[0] * map_hw[1]
         # [Ncam,Nk,bs,C] -> [bs,Ncam,Nk,C]; a no-copy view when the caller built it that way
-        v16 = getattr(value, '_ver_lowp_perm', None)           # the encoder's one bf16 cast for all its layers
-        v = att.value_proj(v16 if (v16 is not None and torch.is_autocast_enabled('cuda')) else value.permute(2, 0, 1, 3))
+        # ``value_lowp``: the encoder's one bf16 cast of ``value`` ([bs,Ncam,Nk,C]) for all its layers, only meaningful
+        # under the bf16 autocast it was made for
+        use_lowp = (value_lowp is not None and torch.is_autocast_enabled('cuda')
+                    and torch.get_autocast_dtype('cuda') == value_lowp.dtype)
+        v = att.value_proj(value_lowp if use_lowp else value.permute(2, 0, 1, 3))
         v = v.reshape(bs, num_cams, nk, att.num_heads, c // att.num_heads)
         # sampling_offsets and attention_weights read the same rows: one GEMM [.., C] x [C, 128 + 64] (and one cast of
         # the query under autocast) instead of two narrow ones; the parameters stay the reference's two Linears
@@ -98,7 +101,7 @@ class SpatialCrossAttention(BaseModule):
         slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1])
         slots = self.output_proj(slots.to(query.dtype))
         if defer_residual:                  # the caller's LayerNorm adds the residual (residual_layer_norm)
-            return PendingResidual(slots, inp_residual, self.dropout.p if self.training else 0.0)
+            return PendingResidual(slots, inp_residual, self.dropout.p if self.dropout.training else 0.0)
         return self.dropout(slots) + inp_residual
 
 

@@ -100,10 +100,14 @@ class VoxelFormerEncoder(TransformerLayerSequence):
         output = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2) if bev_pos is not None else None
         intermediate = []
+        value_lowp = None
         if (torch.is_tensor(value) and value.is_cuda and value.dtype == torch.float32 and value.dim() == 4
                 and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16):
-            # every layer's value_proj would cast the same fp32 feature maps to bf16 again: cast once
-            value._ver_lowp_perm = value.permute(2, 0, 1, 3).to(torch.bfloat16)
+            # every layer's value_proj would cast the same fp32 feature maps to bf16 again: cast once and hand the
+            # copy to the layers explicitly (it lives exactly as long as this call)
+            value_lowp = value.permute(2, 0, 1, 3).to(torch.bfloat16)
+        if value_lowp is not None:
+            kwargs['value_lowp'] = value_lowp
         for layer in self.layers:
             output = layer(output, key, value, *args, bev_pos=bev_pos, bev_z=bev_z, bev_h=bev_h,
                            bev_w=bev_w, spatial_shapes=spatial_shapes,

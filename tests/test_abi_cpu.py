@@ -96,3 +96,25 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(hip.HipLibraryError, match='no CPU/PyTorch fallback'):
         hip.lib()
+
+
+def test_host_launchers_under_address_sanitizer():
+    """SURVEY section 5 (sanitizers): the HOST side of the C ABI -- argument checks, error formatting, launch-shape
+    arithmetic up to the first device call -- built with -fsanitize=address (device code untouched: GPU ASan is not
+    available on this pool) and driven through the same calls as the validation tests above, in a child python with
+    the ASan runtime preloaded.  Any heap / stack / global overflow or use-after-free in those paths aborts the child."""
+    import subprocess
+    import sys
+    build = pkg('csrc.build')
+    rt = build.asan_runtime()
+    if rt is None:
+        pytest.skip('no libclang_rt.asan in this ROCm install')
+    lib = build.build_hip(verbose=False, asan=True)
+    env = dict(os.environ, LD_PRELOAD=rt, VER_HIP_LIB=lib,
+               ASAN_OPTIONS='detect_leaks=0:abort_on_error=0:exitcode=66:verify_asan_link_order=0')
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider', os.path.abspath(__file__), '-k',
+           'argument_validation or exports_every or missing_library']
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert 'AddressSanitizer' not in proc.stderr and 'AddressSanitizer' not in proc.stdout, proc.stderr[-3000:]
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert '4 passed' in proc.stdout, proc.stdout[-500:]

@@ -34,12 +34,29 @@ def stale():
     return _newer(LIB, deps)
 
 
-def build_hip(force=False, verbose=True, defines=(), lib=None):
+ASAN_LIB = os.path.join(PKG, 'libver_hip_asan.so')
+ASAN_FLAGS = ['-O1', '-g', '-fsanitize=address', '-fno-gpu-sanitize', '-shared-libsan', '-fno-omit-frame-pointer']
+
+
+def asan_runtime():
+    """libclang_rt.asan of the ROCm clang (to LD_PRELOAD into the python that loads the ASan build)."""
+    import glob
+    hits = sorted(glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so'))
+    return hits[-1] if hits else None
+
+
+def build_hip(force=False, verbose=True, defines=(), lib=None, asan=False):
     """Compile each source to csrc/build/<name>.o (only the stale ones) and link libver_hip.so.
-    ``defines`` / ``lib``: experiment builds (scratch/) with extra -D flags into another .so."""
+    ``defines`` / ``lib``: experiment builds (scratch/) with extra -D flags into another .so.
+    ``asan``: AddressSanitizer build of the HOST side (launchers, argument checks, error paths) into
+    libver_hip_asan.so -- device code is compiled as usual (GPU ASan is not available on this pool)."""
+    if asan:
+        lib = lib or ASAN_LIB
     lib = lib or LIB
     if not force and not defines and lib == LIB and not stale():
         return LIB
+    if asan and not force and not _newer(lib, [os.path.join(HERE, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]):
+        return lib
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tag = ''.join('_' + d.replace('=', '-') for d in defines)
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -49,17 +66,20 @@ def build_hip(force=False, verbose=True, defines=(), lib=None):
         path = os.path.join(HERE, src)
         # experiment defines only rebuild the sources that mention them
         mytag = tag if (defines and any(d.split('=')[0] in open(path).read() for d in defines)) else ''
+        if asan:
+            mytag += '_asan'
         obj = os.path.join(OBJ_DIR, src.replace('.hip', mytag + '.o'))
         objs.append(obj)
         if force or _newer(obj, [path] + hdrs):
-            cmd = [hipcc] + CFLAGS + (['-D' + d for d in defines] if mytag else []) + ['-c', path, '-o', obj]
+            cflags = [f for f in CFLAGS if f != '-O3'] + ASAN_FLAGS if asan else CFLAGS
+            cmd = [hipcc] + cflags + (['-D' + d for d in defines] if mytag.replace('_asan', '') else []) + ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', lib]
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + (['-fsanitize=address', '-shared-libsan'] if asan else []) + objs + ['-o', lib]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -69,4 +89,4 @@ def build_hip(force=False, verbose=True, defines=(), lib=None):
 if __name__ == '__main__':
     defs = tuple(a[2:] for a in sys.argv[1:] if a.startswith('-D'))
     out = [a[6:] for a in sys.argv[1:] if a.startswith('--lib=')]
-    build_hip(force='--force' in sys.argv, defines=defs, lib=out[0] if out else None)
+    build_hip(force='--force' in sys.argv, defines=defs, lib=out[0] if out else None, asan='--asan' in sys.argv)

@@ -12,7 +12,8 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libver_hip.so')
+# (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
+LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
 ABI_VERSION = 21
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',

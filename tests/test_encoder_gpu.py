@@ -224,25 +224,38 @@ def test_encoder_layer_training_mode_dropout_fused_vs_plain():
     print('dropout statistics: plain-vs-plain %.4f fused-vs-plain %.4f' % (noise, diff))
     assert noise > 1e-3                    # dropout is really on
     assert diff < 1.3 * noise
-    # (2) gradient through the kept mask
-    qg = q.clone().requires_grad_(True)
+    # (2) gradient through the kept mask: with the generator re-seeded the step is a deterministic function; its autograd
+    #     gradient against central finite differences along 8 random directions.  (A finite difference of this layer
+    #     carries ~1.5 % noise of its own from bilinear / ReLU kinks -- the same with dropout off, where the gradients
+    #     are pinned by the golden vectors -- hence a vector comparison; a backward pass that ignored the mask would be
+    #     off by ~30 %.  The exact op-level checks are test_add_dropout_layer_norm_fused / test_relu_dropout_fused.)
     g = T(rng.standard_normal((2, nq, 256)).astype(np.float32)).to(DEV)
-    torch.manual_seed(77)
-    out = _run_encoder(enc, qg, feats, w2p, org, grid)
-    torch.manual_seed(77)
-    assert torch.equal(out.detach(), _run_encoder(enc, q, feats, w2p, org, grid).detach())     # same seed, same masks
-    (out * g).sum().backward()
-    v = T(rng.standard_normal(q.shape).astype(np.float32)).to(DEV)
-    eps = 2e-3
-    with torch.no_grad():
-        torch.manual_seed(77)
-        fp = (_run_encoder(enc, q + eps * v, feats, w2p, org, grid).double() * g).sum()
-        torch.manual_seed(77)
-        fm = (_run_encoder(enc, q - eps * v, feats, w2p, org, grid).double() * g).sum()
-    fd = float((fp - fm) / (2 * eps))
-    an = float((qg.grad.double() * v).sum())
-    print('directional derivative: autograd %.5f finite difference %.5f' % (an, fd))
-    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an))
+    eps = 5e-4
+    for fused_path in (False, True):
+        old = bricks._FUSED_ADD_LN
+        bricks._FUSED_ADD_LN = fused_path
+        try:
+            qg = q.clone().requires_grad_(True)
+            torch.manual_seed(77)
+            out = _run_encoder(enc, qg, feats, w2p, org, grid)
+            torch.manual_seed(77)
+            assert torch.equal(out.detach(), _run_encoder(enc, q, feats, w2p, org, grid).detach())   # same seed, same masks
+            (out * g).sum().backward()
+            an, fd = [], []
+            for k in range(8):
+                v = T(np.random.default_rng(100 + k).standard_normal(q.shape).astype(np.float32)).to(DEV)
+                torch.manual_seed(77)
+                fp = (_run_encoder(enc, q + eps * v, feats, w2p, org, grid).detach().double() * g).sum()
+                torch.manual_seed(77)
+                fm = (_run_encoder(enc, q - eps * v, feats, w2p, org, grid).detach().double() * g).sum()
+                fd.append(float((fp - fm) / (2 * eps)))
+                an.append(float((qg.grad.double() * v).sum()))
+        finally:
+            bricks._FUSED_ADD_LN = old
+        an, fd = np.array(an), np.array(fd)
+        rel = float(np.linalg.norm(fd - an) / np.linalg.norm(an))
+        print('directional derivatives (%s): rel. L2 of finite differences vs autograd %.4f' % ('fused' if fused_path else 'plain', rel))
+        assert rel < 5e-2, (an, fd)
     # (3) only the Dropout modules in eval(): nothing is dropped although the parent is in train()
     for m in enc.modules():
         if isinstance(m, torch.nn.Dropout):

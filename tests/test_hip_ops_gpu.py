@@ -230,9 +230,11 @@ def test_sca_gather_forward_backward_vs_oracle(heads, hd, P, grid, mhw):
 @pytest.mark.parametrize('heads,hd,P,grid', [(8, 96, 8, (4, 15, 15)), (2, 32, 4, (2, 6, 5)), (4, 8, 8, (2, 6, 5)),
                                              (4, 64, 8, (2, 6, 5)), (2, 32, 8, (3, 7, 6))])
 def test_sca_gather_bf16_value(heads, hd, P, grid):
-    """value stored as bf16 (what value_proj emits under bf16 autocast): the kernel reads bf16 and
-    computes in fp32, so against the oracle evaluated on the SAME bf16-rounded values the fp32
-    tolerances still hold."""
+    """value stored as bf16 (what value_proj emits under bf16 autocast).  Against the oracle evaluated on the SAME
+    bf16-rounded values: the generic kernels compute in fp32 and keep the fp32 tolerance; the corner-slot kernel
+    (8 points, head_dim % 32 == 0) accumulates the <= 8 points of a (voxel, head, corner) in packed fp16 by default
+    (VER_SCA_FWD_MATH=2) -- inside the north star's 1e-2 for bf16 arithmetic; its exact modes
+    (0 / 1) are held to 2e-5 by test_sca_gather_launch_modes."""
     hip = pkg('hipops')
     o = oracle()
     hit, value, offsets, logits, gslots = _random_sca_case(17, 2, grid, heads, hd, P)
@@ -248,7 +250,12 @@ def test_sca_gather_bf16_value(heads, hd, P, grid):
     oc, lc = T(offsets).requires_grad_(True), T(logits).requires_grad_(True)
     ref = oracle_slots(o, vc, oc, lc, hit.uv.cpu(), mask, (14, 14))
     ref.backward(T(gslots))
-    assert maxdiff(slots.detach().cpu(), ref.detach()) < 2e-5
+    if P == 8 and hd % 32 == 0:
+        from util import rel_l2
+        assert maxdiff(slots.detach().cpu(), ref.detach()) < 1e-2
+        assert rel_l2(slots.detach().cpu(), ref.detach()) < 2e-3
+    else:
+        assert maxdiff(slots.detach().cpu(), ref.detach()) < 2e-5
     assert close(of.grad.cpu(), oc.grad)
     assert close(lg.grad.cpu(), lc.grad)
     assert close(vb.grad.float().cpu(), vc.grad, atol=2e-2, rtol=1e-2)      # grad rounded to bf16
@@ -321,16 +328,17 @@ def test_sca_gather_samples_outside_the_map():
     _, hit, value, offsets, logits = H.case(6, 2, (4, 15, 15), 8, 96, True)
     mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()
     for vt in (value, value.bfloat16()):
+        tol = 2e-5 if vt.dtype == torch.float32 else 1e-2         # bf16 tiles: packed fp16 accumulation (bf16 bound)
         got = hip.sca_gather(vt, offsets, logits, hit, 14, 14)
         ref = oracle_slots(o, vt.float().cpu(), offsets.cpu(), logits.cpu(), hit.uv.cpu(), mask, (14, 14))
-        assert maxdiff(got.cpu(), ref) < 2e-5
+        assert maxdiff(got.cpu(), ref) < tol
         far = hip.sca_gather(vt, offsets + 40.0, logits, hit, 14, 14)
         assert float(far.abs().max()) == 0.0
         one = offsets + 40.0
         one[:, :, :, 3] = offsets[:, :, :, 3] * 0.25                   # only point 3 can land inside
         got1 = hip.sca_gather(vt, one, logits, hit, 14, 14)
         ref1 = oracle_slots(o, vt.float().cpu(), one.cpu(), logits.cpu(), hit.uv.cpu(), mask, (14, 14))
-        assert maxdiff(got1.cpu(), ref1) < 2e-5
+        assert maxdiff(got1.cpu(), ref1) < tol
 
 
 def test_sca_gather_launch_modes(tmp_path):
@@ -340,13 +348,15 @@ def test_sca_gather_launch_modes(tmp_path):
     import subprocess
     helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'sca_modes_helper.py')
     modes = {
-        'default': {},
+        'default': {'VER_SCA_FWD_MATH': '0'},         # bf16 tile unpacked to fp32 per use: the exact reference mode
+        'f16_acc': {},                                # the shipped default: packed fp16 accumulation on bf16 tiles
+        'odd_threads': {'VER_SCA_FWD_MATH': '0', 'VER_SCA_CS_THREADS_BF16': '320', 'VER_SCA_CS_THREADS_F32': '384'},
         'generic': {'VER_SCA_FWD_CS': '0'},
-        'loaders': {'VER_SCA_CS_NLOAD': '1', 'VER_SCA_CS_THREADS_BF16': '1024', 'VER_SCA_CS_THREADS_F32': '1024',
+        'loaders': {'VER_SCA_FWD_MATH': '0', 'VER_SCA_CS_NLOAD': '1', 'VER_SCA_CS_THREADS_BF16': '1024', 'VER_SCA_CS_THREADS_F32': '1024',
                     'VER_SCA_CS_HSPLIT': '2', 'VER_SCA_CS_UNITS_PER_WG': '0'},
-        'loaders2': {'VER_SCA_CS_NLOAD': '2', 'VER_SCA_CS_THREADS_BF16': '512', 'VER_SCA_CS_THREADS_F32': '1024',
+        'loaders2': {'VER_SCA_FWD_MATH': '2', 'VER_SCA_CS_NLOAD': '2', 'VER_SCA_CS_THREADS_BF16': '512', 'VER_SCA_CS_THREADS_F32': '1024',
                      'VER_SCA_CS_HSPLIT': '1', 'VER_SCA_CS_UNITS_PER_WG': '3'},
-        'multi_unit': {'VER_SCA_CS_HSPLIT': '4', 'VER_SCA_CS_UNITS_PER_WG': '5', 'VER_SCA_CS_THREADS_BF16': '512'},
+        'multi_unit': {'VER_SCA_FWD_MATH': '0', 'VER_SCA_CS_HSPLIT': '4', 'VER_SCA_CS_UNITS_PER_WG': '5', 'VER_SCA_CS_THREADS_BF16': '512'},
     }
     res = {}
     for name, env in modes.items():
@@ -356,7 +366,12 @@ def test_sca_gather_launch_modes(tmp_path):
     for name in modes:
         for key in res['default'].files:
             d = float(np.abs(res[name][key] - res['default'][key]).max())
-            assert d < 2e-5, (name, key, d)
+            if name in ('f16_acc', 'loaders2') and key.endswith('_bf16'):
+                # packed fp16 accumulation: inside the bf16 bound of the north star, and only on bf16 tiles
+                rel = float(np.linalg.norm(res[name][key] - res['default'][key]) / np.linalg.norm(res['default'][key]))
+                assert d < 1e-2 and rel < 2e-3, (name, key, d, rel)
+            else:
+                assert d < 2e-5, (name, key, d)
 
 
 def test_sca_gather_multi_camera_and_anchors():

@@ -678,7 +678,16 @@ __device__ float g_sca_dummy_row[256 * 256];        // one 1-KiB slice per (bloc
 // COMPACTS the live samples of a voxel to the front of its record row, and a pair only walks
 // max(live samples of its two voxels) points -- with the reference's initial ring of offsets (1..8 px on a 14-px
 // map, spatial_cross_attention.py:255-270) more than a third of the samples are outside.
-template <int HD, typename VT, int NKT>
+// MATH (bf16 tiles only): how the gather multiplies a tile row by its weight.
+//   0  the tile stays bf16 in LDS; every use unpacks to fp32 (v_and / v_lshlrev) and accumulates with v_pk_fma_f32
+//   2  each wave converts the chunks it staged to fp16 IN PLACE (exact for bf16 values with |x| in [6.1e-5, 65504]:
+//      8 mantissa bits fit in 11; RTZ saturates above and truncates into the subnormals below, abs. error < 6e-8),
+//      weights travel as packed fp16 pairs, and the <= 8 points of a (voxel, head, corner) are accumulated with
+//      v_pk_fma_f16 -- two channels per instruction, no unpack; the corner fold runs on the packed sums, everything
+//      after it (camera sum, division) in fp32.  Error ~5e-4 of the partial sums (bf16 bound of the north star: 1e-2).
+//   (1 = fp16 tile with fp32 accumulation: the compiler turns it into v_cvt_f32_f16 + v_pk_fma_f32, as many
+//    instructions as mode 0 -- measured 3 % slower, 437 vs 424 us per launch; not dispatched.)
+template <int HD, typename VT, int NKT, int MATH = 0>
 __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
@@ -691,6 +700,8 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     constexpr unsigned RB = 32 * sizeof(VT);
     constexpr int CPR = 32 * sizeof(VT) / 16, EPC = 16 / sizeof(VT);
     static_assert(HD % 32 == 0, "8 lanes x vectors of 4 channels");
+    static_assert(MATH == 0 || !F32, "the fp16 modes are for bf16 tiles");
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const int nwaves = (int)(blockDim.x >> 6);
     const int ncons = nwaves - nload;
     const int nbuf = nload > 0 ? 2 : 1;
@@ -743,11 +754,35 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         }
     };
 
+    // bf16 -> fp16 in place, by the wave that staged the chunk (its own s_waitcnt covers the DMA): no extra barrier
+    auto to_f16 = [&](int i) {
+        if constexpr (MATH != 0) {
+            const unsigned dst = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(smem) +
+                                 (nbuf == 2 ? (unsigned)(i & 1) : 0u) * tile_bytes;
+            for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
+                if (q0 + lane < total_chunks) {
+                    const unsigned a = dst + (unsigned)(q0 + lane) * 16u;
+                    u32x4_t w = *lds_ptr<u32x4_t>(a);
+                    u32x4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned x = e == 0 ? w.x : e == 1 ? w.y : e == 2 ? w.z : w.w;
+                        const auto hh = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u));
+                        const unsigned r = __builtin_bit_cast(unsigned, hh);
+                        if (e == 0) o.x = r; else if (e == 1) o.y = r; else if (e == 2) o.z = r; else o.w = r;
+                    }
+                    *lds_ptr_mut<u32x4_t>(a) = o;
+                }
+            }
+        }
+    };
+
     if (nload > 0 && wave >= ncons) {
         // ------------------------------------------------------------ loader waves: stream the tiles
         stage(0);
         for (int i = 0; i < ntiles; ++i) {
             __builtin_amdgcn_s_waitcnt(0);            // this wave's share of tile i has landed
+            to_f16(i);
             VER_TL(1 + i);
             __syncthreads();                          // tile i complete; the consumers are done with tile i - 1
             if (i + 1 < ntiles) stage(i + 1);
@@ -834,7 +869,10 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
             int n0 = un0, n1 = un1, n2 = un2;
             Sample s0 = {};
             if (iters > 0) s0 = load_sample(n0);      // requested before the tile barrier: the latency hides behind it
-            if (nload == 0) __builtin_amdgcn_s_waitcnt(0);         // this wave's share of the tile has landed
+            if (nload == 0) {
+                __builtin_amdgcn_s_waitcnt(0);        // this wave's share of the tile has landed
+                to_f16(ti);
+            }
             __syncthreads();                          // tile ti is complete
             VER_TL(1 + ti);
             const unsigned base4 = smem_lds + (nbuf == 2 ? (unsigned)(ti & 1) * tile_bytes : 0u) + lane_off;
@@ -877,11 +915,22 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 // but the compiler must know (without the fence it forwarded the previous pair's loads to the lanes that
                 // did not store -- legal for a single thread, wrong here).
                 u32x4_t recs[P / 2];
+                // the record {weight word, row offset}: the weight is fp32, or (w, w) as packed fp16 in mode 2
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                u32x2_t rec[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (MATH == 2) {
+                        const _Float16 hw = (_Float16)w[t];
+                        rec[t].x = __builtin_bit_cast(unsigned, h2_t{hw, hw});
+                    } else {
+                        rec[t].x = __float_as_uint(w[t]);
+                    }
+                    rec[t].y = k[t];
+                }
                 if (s4 == 0) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        *lds_ptr_mut<unsigned long long>(rec_wr + (unsigned)t * 64u) =
-                            (unsigned long long)__float_as_uint(w[t]) | ((unsigned long long)k[t] << 32);
+                    for (int t = 0; t < 4; ++t) *lds_ptr_mut<u32x2_t>(rec_wr + (unsigned)t * 64u) = rec[t];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -898,20 +947,20 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     // when they were).
                     if (j + 1 < nsub && s4 == j + 1) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            *lds_ptr_mut<unsigned long long>(rec_wr + (unsigned)t * 64u) =
-                                (unsigned long long)__float_as_uint(w[t]) | ((unsigned long long)k[t] << 32);
+                        for (int t = 0; t < 4; ++t) *lds_ptr_mut<u32x2_t>(rec_wr + (unsigned)t * 64u) = rec[t];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     float acc[4 * NV];
+                    h2_t acc2[2 * NV];                             // mode 2: the same 4 * NV channels as packed fp16 pairs
 #pragma unroll
                     for (int i = 0; i < 4 * NV; ++i) acc[i] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 2 * NV; ++i) acc2[i] = h2_t{(_Float16)0.0f, (_Float16)0.0f};
                     // tile vectors of a point are requested one point ahead of their FMAs (explicitly: left to itself the
                     // compiler, short of registers, funnelled every read through one register pair with a full
                     // lgkmcnt(0) wait in front of each group of FMAs)
-                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                     typedef typename std::conditional<F32, f32x4_t, u32x2_t>::type tv_t;
-                    auto rec_w = [&](int pt) { return __uint_as_float((pt & 1) ? recs[pt / 2].z : recs[pt / 2].x); };
+                    auto rec_wbits = [&](int pt) { return (pt & 1) ? recs[pt / 2].z : recs[pt / 2].x; };
                     auto rec_a = [&](int pt) { return base4 + ((pt & 1) ? recs[pt / 2].w : recs[pt / 2].y); };
                     // (volatile: an ordinary load whose only use is in the next point's block gets sunk into it)
                     auto tile_ld = [&](unsigned addr) -> tv_t {
@@ -923,7 +972,8 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #pragma unroll
                     for (int pt = 0; pt < P; ++pt) {
                         if (pt >= npts) break;                     // wave-uniform: the pair has no more live samples
-                        const float wb = rec_w(pt);
+                        const unsigned wbit = rec_wbits(pt);
+                        const float wb = __uint_as_float(wbit);
                         if (pt + 1 < P) {
 #pragma unroll
                             for (int i = 0; i < NV; ++i) tb[(pt + 1) & 1][i] = tile_ld(rec_a(pt + 1) + (unsigned)i * plane);
@@ -931,15 +981,24 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #pragma unroll
                         for (int i = 0; i < NV; ++i) {
                             const tv_t tc = tb[pt & 1][i];
-                            float v[4];
-                            if constexpr (F32) {
-                                v[0] = tc.x; v[1] = tc.y; v[2] = tc.z; v[3] = tc.w;
+                            if constexpr (MATH == 2) {
+                                const h2_t w2 = __builtin_bit_cast(h2_t, wbit);
+                                acc2[2 * i] = __builtin_elementwise_fma(__builtin_bit_cast(h2_t, (unsigned)tc.x), w2, acc2[2 * i]);
+                                acc2[2 * i + 1] = __builtin_elementwise_fma(__builtin_bit_cast(h2_t, (unsigned)tc.y), w2, acc2[2 * i + 1]);
                             } else {
-                                v[0] = __uint_as_float(tc.x << 16); v[1] = __uint_as_float(tc.x & 0xffff0000u);
-                                v[2] = __uint_as_float(tc.y << 16); v[3] = __uint_as_float(tc.y & 0xffff0000u);
-                            }
+                                float v[4];
+                                if constexpr (F32) {
+                                    v[0] = tc.x; v[1] = tc.y; v[2] = tc.z; v[3] = tc.w;
+                                } else if constexpr (MATH == 1) {
+                                    const h2_t a = __builtin_bit_cast(h2_t, (unsigned)tc.x), b2 = __builtin_bit_cast(h2_t, (unsigned)tc.y);
+                                    v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b2.x; v[3] = (float)b2.y;
+                                } else {
+                                    v[0] = __uint_as_float(tc.x << 16); v[1] = __uint_as_float(tc.x & 0xffff0000u);
+                                    v[2] = __uint_as_float(tc.y << 16); v[3] = __uint_as_float(tc.y & 0xffff0000u);
+                                }
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[i * 4 + q] = __builtin_fmaf(wb, v[q], acc[i * 4 + q]);
+                                for (int q = 0; q < 4; ++q) acc[i * 4 + q] = __builtin_fmaf(wb, v[q], acc[i * 4 + q]);
+                            }
                         }
                     }
                     if (j + 1 < nsub) {                            // next pair's records: the latency hides behind the epilogue
@@ -950,15 +1009,28 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     // fold the four corner slots: rows of 16 lanes first (transposing: even rows keep channels {0,1}
                     // of each vector, odd rows {2,3}), then the two slots of a row
                     float out[2 * NV];
+                    if constexpr (MATH == 2) {
+                        // the same fold on the packed pairs: (ch0, ch1) and (ch2, ch3) of a vector are one register each
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        permlane16_swap(acc[i * 4 + 0], acc[i * 4 + 2]);
-                        permlane16_swap(acc[i * 4 + 1], acc[i * 4 + 3]);
-                        out[2 * i + 0] = acc[i * 4 + 0] + acc[i * 4 + 2];
-                        out[2 * i + 1] = acc[i * 4 + 1] + acc[i * 4 + 3];
+                        for (int i = 0; i < NV; ++i) {
+                            float a = __builtin_bit_cast(float, acc2[2 * i]), b2 = __builtin_bit_cast(float, acc2[2 * i + 1]);
+                            permlane16_swap(a, b2);
+                            h2_t sum = __builtin_bit_cast(h2_t, a) + __builtin_bit_cast(h2_t, b2);
+                            sum = sum + __builtin_bit_cast(h2_t, dpp_mov<0x128>(__builtin_bit_cast(float, sum)));      // row_ror:8
+                            out[2 * i + 0] = (float)sum.x;
+                            out[2 * i + 1] = (float)sum.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            permlane16_swap(acc[i * 4 + 0], acc[i * 4 + 2]);
+                            permlane16_swap(acc[i * 4 + 1], acc[i * 4 + 3]);
+                            out[2 * i + 0] = acc[i * 4 + 0] + acc[i * 4 + 2];
+                            out[2 * i + 1] = acc[i * 4 + 1] + acc[i * 4 + 3];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2 * NV; ++i) out[i] += dpp_mov<0x128>(out[i]);      // row_ror:8
                     }
-#pragma unroll
-                    for (int i = 0; i < 2 * NV; ++i) out[i] += dpp_mov<0x128>(out[i]);      // row_ror:8
                     const int na = __builtin_amdgcn_readlane(n0, 16 * j), nb = __builtin_amdgcn_readlane(n0, 16 * j + 8);
                     const int n = half ? nb : na;
                     const unsigned rowoff = __umul24((unsigned)(n < 0 ? -n - 1 : n), hhd4) + (unsigned)(l8 * 4 + rho * 2) * 4u;
@@ -1968,7 +2040,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             static const int cs_upw = env_int("VER_SCA_CS_UNITS_PER_WG", 1);
             static const int cs_wgs_per_cu = env_int("VER_SCA_CS_WGS_PER_CU", 1);
             int pt = f32 ? cs_threads_f32 : cs_threads_bf16;
-            if (pt != 256 && pt != 512 && pt != 1024) pt = f32 ? 512 : 256;
+            if (pt % 64 != 0 || pt < 128 || pt > 1024) pt = f32 ? 512 : 256;
             const int nlp = (cs_nload >= 0 && cs_nload < pt / 64) ? cs_nload : 0;
             const size_t tb = (tile_bytes + 15) & ~(size_t)15;
             const size_t ldsp = (nlp > 0 ? 2 : 1) * tb + (size_t)(pt / 64) * 512;
@@ -2009,7 +2081,12 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                     if (k196) return launch_cs(k_sca_fwd_cs<HD, float, 196>, (const float*)value);
                     return launch_cs(k_sca_fwd_cs<HD, float, 0>, (const float*)value);
                 }
+                // VER_SCA_FWD_MATH: 0 bf16 tile + fp32 unpack and accumulation (exact), 2 fp16 tile + packed fp16
+                // accumulation over a voxel's points (default: DESIGN.md section 3.1)
+                static const int cs_math = env_int("VER_SCA_FWD_MATH", 2);
+                if (k196 && cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2>, (const uint16_t*)value);
                 if (k196) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196>, (const uint16_t*)value);
+                if (cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0, 2>, (const uint16_t*)value);
                 return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0>, (const uint16_t*)value);
             }
         }

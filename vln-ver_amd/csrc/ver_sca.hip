@@ -740,6 +740,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         const VT* src = value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD + jc * EPC;
         VT* dst = reinterpret_cast<VT*>(smem + (nbuf == 2 ? (i & 1) : 0) * tile_bytes);
         int pi = i_first, pk = k_first;
+#ifdef VER_ABL_NODMA
+        if (i >= 0) return;
+#endif
         for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
             if (q0 + lane < total_chunks) {
                 const VT* g = src + (size_t)pk * rstride + pi * 32;
@@ -756,6 +759,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 
     // bf16 -> fp16 in place, by the wave that staged the chunk (its own s_waitcnt covers the DMA): no extra barrier
     auto to_f16 = [&](int i) {
+#ifdef VER_ABL_NOCONV
+        return;
+#endif
         if constexpr (MATH != 0) {
             const unsigned dst = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(smem) +
                                  (nbuf == 2 ? (unsigned)(i & 1) : 0u) * tile_bytes;
@@ -938,8 +944,16 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (j >= nsub) break;                          // wave-uniform
+#ifdef VER_ABL_NOATOMIC
+                    const bool atomic = false;
+#else
                     const bool atomic = p_lo + 4 * it + j >= s_pairs;   // wave-uniform: the pair is in the shared region
+#endif
+#ifdef VER_ABL_NOPOINTS
+                    const int npts = min(1, max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8)));
+#else
                     const int npts = max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8));
+#endif
                     // `recs` holds this pair's records (requested during the previous pair's epilogue).  Publish the next
                     // pair's now -- LDS serves the wave's requests in order, so the reads of this pair's records are
                     // already done -- and request them after the FMA loop, when `recs` is free again: neither the
@@ -1037,6 +1051,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     float* live_row = reinterpret_cast<float*>(out_base + rowoff);
                     // the only dead voxel of the plain-store region is the pad entry of an odd single count: last pair
                     const bool has_pad = !atomic && (s_n & 1) && p_lo + 4 * it + j == s_pairs - 1;     // wave-uniform
+#ifdef VER_ABL_NOSTORE
+                    if (out[0] == 12345.678f)
+#endif
                     if (!atomic) {
                         // both slots of a row hold the sums and share the stores
                         float* row = live_row;
@@ -1051,12 +1068,24 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                                 o2[0] = sigma ? b0 : a0;
                                 o2[1] = sigma ? b1 : a1;
                                 dst = row + (2 * kk + sigma) * 32;
-                            } else {                               // odd plane count: both slots write the last vector
-                                o2[0] = out[4 * kk];
-                                o2[1] = out[4 * kk + 1];
-                                dst = row + 2 * kk * 32;
+                            } else {
+                                // odd plane count: both slots of a row hold the last vector's two sums -- each writes ONE
+                                // of them (4-byte stores, 32 lanes = one 128-byte line) instead of both writing both
+                                float a0 = out[4 * kk], a1 = out[4 * kk + 1];
+                                asm("" : "+v"(a1));
+                                const float one = sigma ? a1 : a0;
+#ifdef VER_ABL_TEMPORAL
+                                row[2 * kk * 32 + sigma] = one;
+#else
+                                __builtin_nontemporal_store(one, row + 2 * kk * 32 + sigma);
+#endif
+                                continue;
                             }
+#ifdef VER_ABL_TEMPORAL
+                            store_vec<2, false>(dst, o2);
+#else
                             store_vec<2, true>(dst, o2);
+#endif
                         }
                     } else {
                         float* row = live_row;                     // dead voxel (odd tail): adds zeros to a live shared row

@@ -1074,18 +1074,10 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                                 float a0 = out[4 * kk], a1 = out[4 * kk + 1];
                                 asm("" : "+v"(a1));
                                 const float one = sigma ? a1 : a0;
-#ifdef VER_ABL_TEMPORAL
-                                row[2 * kk * 32 + sigma] = one;
-#else
                                 __builtin_nontemporal_store(one, row + 2 * kk * 32 + sigma);
-#endif
                                 continue;
                             }
-#ifdef VER_ABL_TEMPORAL
-                            store_vec<2, false>(dst, o2);
-#else
                             store_vec<2, true>(dst, o2);
-#endif
                         }
                     } else {
                         float* row = live_row;                     // dead voxel (odd tail): adds zeros to a live shared row

@@ -333,3 +333,26 @@ def test_layout_branch_on_gpu_matches_reference():
     for name in ('layout_branches.5.4.weight', 'layout_branches.5.0.weight', 'occ_proj.weight'):
         grad = dict(head.named_parameters())[name].grad
         assert grad is not None and torch.isfinite(grad).all() and float(grad.abs().max()) > 0, name
+
+
+def test_gpu_path_fails_loudly_without_the_hip_library(monkeypatch):
+    """The dense head keeps torch formulations of its lattice algebra for CPU tensors (the fp64 algebra checks of
+    tests/test_head_cpu.py run the product code on the CPU); a GPU tensor never takes them: with libver_hip.so gone the
+    encoder AND the occupancy branch raise instead of computing anything with torch ops (fp32 and bf16 autocast)."""
+    hip = pkg('hipops')
+    syn = pkg('synthetic')
+    head = _head(cases.vocc_head_cfg(), 7)
+    w2p, org = syn.camera_batch(1, seed=1)
+    feats = T(syn.vit_features(1, seed=0)[0]).to(DEV).unsqueeze(1)
+    emb = torch.randn(1, 900, 768, device=DEV)
+    monkeypatch.setattr(hip, '_lib', None)
+    monkeypatch.setattr(hip, 'LIB_PATH', '/nonexistent/libver_hip.so')
+    with torch.no_grad():
+        with pytest.raises(hip.HipLibraryError, match='no CPU/PyTorch fallback'):
+            head.lift(feats, _metas(w2p, org, [0]))
+        with pytest.raises(hip.HipLibraryError):
+            head.occupancy_from_volume(emb)
+        with pytest.raises(hip.HipLibraryError), torch.autocast('cuda', dtype=torch.bfloat16):
+            head.occupancy_from_volume(emb)
+        with pytest.raises(hip.HipLibraryError):
+            head.occupancy_loss(torch.randn(8192, 16, device=DEV), torch.zeros(8192, dtype=torch.long, device=DEV))

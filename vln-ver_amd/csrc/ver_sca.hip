@@ -15,10 +15,20 @@
 // bitwise run-to-run reproducible as long as no voxel is seen by more than two cameras (two addends commute);
 // with three or more the last bit may vary with the order of the adds.  Voxels seen by no camera get exact zeros.
 //
-// Backward (ver_sca_backward): k_sca_bwd_off (d offsets, d logits; the forward's structure) + k_sca_bwd_val
-// (d value by a counting sort of the sampling events per tile row, no floating-point atomics in LDS); a single
-// LDS-atomic kernel (k_sca_bwd) remains for head_dim < 32.  d(value) may differ in the last bit run to run (the
-// order of a tile row's events inside the sort is not fixed), as the reference's CUDA backward does.
+// On bf16 tiles k_sca_fwd_cs converts the staged tile to fp16 in LDS and accumulates the <= 8 points of a (voxel, head,
+// corner) with v_pk_fma_f16 (VER_SCA_FWD_MATH=0: bf16 tile unpacked to fp32 per use, exact fp32 accumulation).
+//
+// Backward (ver_sca_backward), by shape:
+//   * bf16 tiles, 8 points, head_dim % 32 == 0, tile + buffers <= 160 KB  ->  k_sca_bwd_mm: ONE kernel on the matrix
+//     cores.  Per 32-voxel chunk D^T = V x G^T (all tile-row x voxel dots, bf16 hi + lo split of the grad rows) gives
+//     d(offsets) / d(logits); the sampling events are added into a dense S^T in LDS as 2^-30 fixed point (integer LDS
+//     atomics: exact in any order) and d(value) = S^T x G accumulates in registers over all chunks: d(value) is bitwise
+//     reproducible and is written in bf16 (ver_sca_backward_grad_dtype tells the caller);
+//   * fp32 tiles / other shapes with 16 lanes per voxel  ->  k_sca_bwd_off (d offsets, d logits; the forward's
+//     structure) + k_sca_bwd_val (d value by a counting sort of the sampling events per tile row, no floating-point
+//     atomics in LDS; the order of a row's events inside the sort is not fixed, so d(value) may differ in the last
+//     bit run to run, as the reference's CUDA backward does);
+//   * head_dim < 32 or large maps  ->  k_sca_bwd, a single LDS-atomic kernel.
 #include <cstdlib>
 #include <type_traits>
 #include "ver_common.h"

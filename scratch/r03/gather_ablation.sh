@@ -1,6 +1,6 @@
 #!/bin/bash
 # where the forward gather's time goes: timing-only ablation builds (results are wrong by construction)
-for abl in NONE NOATOMIC NOSTORE NOCONV NOPOINTS NODMA; do
+for abl in NONE NOATOMIC NOSTORE NOCONV NOPOINTS NODMA DUMMYOUT; do
   lib=vln-ver_amd/libver_abl_$abl.so
   [ -f $lib ] || continue
   echo "== $abl"

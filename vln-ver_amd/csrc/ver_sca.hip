@@ -1067,7 +1067,11 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     if (!atomic) {
                         // both slots of a row hold the sums and share the stores
                         float* row = live_row;
+#ifdef VER_ABL_DUMMYOUT
+                        row = g_sca_dummy_row + (blockIdx.x & 255) * 256 + l8 * 4 + rho * 2;      // timing: no HBM write stream
+#else
                         if (has_pad && n < 0) row = g_sca_dummy_row + (blockIdx.x & 255) * 256 + l8 * 4 + rho * 2;
+#endif
 #pragma unroll
                         for (int kk = 0; kk < (NV + 1) / 2; ++kk) {
                             float o2[2];

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 21
+#define VER_ABI_VERSION 22
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -337,6 +337,15 @@ int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* ima
                          void* grad_x, void* grad_a1, void* grad_a2, void* h1,
                          float* param_grads, long N, int width, int classes, float eps, int first_linear,
                          void* stream);
+/*   backward, folded first Linear (first_linear = 0), EVERYTHING accumulated in the kernel (ABI 22): reads x and
+ *   grad_logits, writes grad_x; no side tensors.  W2 f32 [128,128], W3 f32 [16,128] are the raw nn.Linear weights
+ *   (no image), `vectors` as above (b1 is ignored).
+ *     param_grads f32 [6*128 + 16*128 + 16 + 128*128]   d gamma1, d beta1, (unused), d gamma2, d beta2, d b2, then
+ *                                               d W3 [16,128], d b3 [16], d W2 [128,128] -- natural order; zeroed inside
+ */
+int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
+                               const float* vectors, void* grad_x, float* param_grads, long N, int width,
+                               int classes, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@
 //     the chain never leaves the registers (no LDS transposes, no barriers).
 // Weight fragments live in LDS in fragment order (one conflict-free ds_read_b128 per fragment),
 // built once per step by `ver_occ_mlp_pack` from the fp32 parameters.
+#include <cstdlib>
 #include "ver_common.h"
 
 namespace {
@@ -656,4 +657,369 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
                        (const __bf16*)grad_logits, (const __bf16*)image, vectors, (__bf16*)grad_x, (__bf16*)grad_a1,
                        (__bf16*)grad_a2, (__bf16*)h1, param_grads, N, eps);
     return ver_check_launch("ver_occ_mlp_backward");
+}
+
+// ============================================================================================
+// Backward, folded first Linear, N-SPLIT form (ver_occ_mlp_backward_fused): every parameter gradient -- d(W2)
+// included -- is accumulated in the kernel; x and d(logits) are read, d(x) is written, nothing else touches HBM.
+//
+// The row-split kernel above gives a wave 16 rows and ALL 128 features of every layer: d(W2) would be 64 accumulator
+// tiles (256 registers) per wave on top of a chain that already fills the register file, so it writes h1 and d(a2)
+// for a host GEMM instead.  Here a workgroup of four waves takes a block of 64 rows and alternates between two views
+// of it, with LDS tiles (bf16, row-major, 272-byte rows) as the transposer in between:
+//   * ROW view (LayerNorm forward / backward, elementwise): wave w owns rows 16w..16w+15 with all 128 features in the
+//     natural fragment layout (lane (row c, g) holds features 32t + 8g + j) -- statistics are in-lane sums + two
+//     cross-lane adds, exactly the code of the row-split kernel;
+//   * FEATURE view (everything that is a matrix product): wave w owns output features 32w..32w+31 of ALL 64 rows.
+//     Its slices of W2 (as A operand of the forward and of the dgrad) and of W3 live in registers for the whole
+//     kernel: no weight traffic at all.  Activation operands are 16-byte row reads of the LDS tiles; the operands of
+//     the weight gradients and of the row sums need rows on the K axis and come out of the same row-major tiles
+//     transposed by ds_read_b64_tr_b16.  d(W2)[o][k] = sum_r d(a2)[r][o] h1[r][k] is then 2 x 8 tiles x 2 FULL k-steps
+//     per 64 rows (64 accumulator registers per wave), the LayerNorm parameter gradients are the same A fragments
+//     against an all-ones B fragment.
+// Per 64 rows and wave: 128 MFMAs (516 in the row-split kernel), no register shuffling through AGPRs, 7 barriers.
+// Between the views the activations are rounded to bf16 (a2, d(h2), d(h1)) -- what the layer-by-layer bf16 autocast
+// path does between its kernels as well.
+namespace {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int kNsLd = kW + 8;               // LDS row stride in elements (272 B: 16-byte aligned, off the 256-B bank period)
+constexpr int kNsTiles = 4;
+constexpr int kNsDlLd = kC;                 // d(logits) tile [rows][16]
+constexpr size_t ns_lds_bytes(int nw) {
+    return (size_t)kNsTiles * (16 * nw) * kNsLd * 2 + (size_t)(16 * nw) * kNsDlLd * 2 + kVecFloats * sizeof(float);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// B (or A) fragment with ROWS on the K axis from a row-major LDS tile: rows row0 + 8g .. + 7 of column col0 + c.
+__device__ __forceinline__ bf16x8 ns_tr_frag(const __bf16* tile, int ld, int row0, int col0, int c, int g) {
+    const __bf16* p = tile + (row0 + 8 * g + (c >> 2)) * ld + col0 + 4 * (c & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ld));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// LayerNorm + ReLU backward for one row tile in the natural layout (d[2t+h][i], xh[t][4h+i] = feature 32t + 8g + 4h + i;
+// gam / bet offset by 8g).  Writes, for this lane's row, d(pre-LayerNorm) to `out` and the two tiles whose row sums are
+// d(beta) / d(gamma) to `pz` / `pn` (pointers to the lane's 8-feature chunk of k-step 0; + 32 elements per k-step) --
+// each as soon as it exists, so that no more than one k-step of them is ever live in registers.
+template <bool OUT_OK = true>
+__device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
+                                               const float* bet, __bf16* out, __bf16* pz, __bf16* pn, bool out_ok) {
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 dz[2], dzn[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ot = 2 * t + h;
+            const f32x4 n = unpack_half(xh[t], h);
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 32 * t + 4 * h);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 32 * t + 4 * h);
+            const f32x4 y = n * gm + bt;
+            dz[h].x = y.x > 0.0f ? d[ot].x : 0.0f;
+            dz[h].y = y.y > 0.0f ? d[ot].y : 0.0f;
+            dz[h].z = y.z > 0.0f ? d[ot].z : 0.0f;
+            dz[h].w = y.w > 0.0f ? d[ot].w : 0.0f;
+            dzn[h] = dz[h] * n;
+            const f32x4 dg = dz[h] * gm;
+            d[ot] = dg;
+            s1 += (dg.x + dg.y) + (dg.z + dg.w);
+            const f32x4 dn = dg * n;
+            s2 += (dn.x + dn.y) + (dn.z + dn.w);
+        }
+        *reinterpret_cast<bf16x8*>(pz + 32 * t) = pack8(dz[0], dz[1]);
+        *reinterpret_cast<bf16x8*>(pn + 32 * t) = pack8(dzn[0], dzn[1]);
+    }
+    s1 += xor16(s1);
+    s1 += xor32(s1);
+    s2 += xor16(s2);
+    s2 += xor32(s2);
+    const float m1 = s1 * (1.0f / kW), m2 = s2 * (1.0f / kW);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 a = (d[2 * t] - m1 - unpack_half(xh[t], 0) * m2) * rs;
+        const f32x4 b = (d[2 * t + 1] - m1 - unpack_half(xh[t], 1) * m2) * rs;
+        if (out_ok) *reinterpret_cast<bf16x8*>(out + 32 * t) = pack8(a, b);
+    }
+}
+}  // namespace
+
+// NW waves per workgroup: a block is 16 NW rows, a wave owns rows 16w.. (row view) and the 128 / NW output features
+// from 128 w / NW (feature view).  NW = 8: two waves per SIMD, 128-row blocks, one 16-feature tile per wave.
+// LDS tiles: T0 = h1;  T1 = a2 -> d(h2) -> d(z2) n2 -> d(h1);  T2 = h2 -> d(z2) -> d(z1);  T3 = d(a2) -> d(z1) n1.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
+                                                            const float* __restrict__ W2, const float* __restrict__ W3,
+                                                            const float* __restrict__ vec, __bf16* __restrict__ dx,
+                                                            float* __restrict__ pgrad, long N, float eps) {
+    constexpr int RB = 16 * NW;             // rows per block
+    constexpr int OT = kW / NW / 16;        // 16-feature output tiles per wave
+    constexpr int RT = NW;                  // 16-row tiles per block
+    constexpr int KS = RB / 32;             // k-steps when ROWS are the K axis
+    constexpr int TILE = RB * kNsLd;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* T0 = reinterpret_cast<__bf16*>(smem);
+    __bf16* T1 = T0 + TILE;
+    __bf16* T2 = T1 + TILE;
+    __bf16* T3 = T2 + TILE;
+    __bf16* DL = T3 + TILE;                            // d(logits) [RB][16]
+    float* sv = reinterpret_cast<float*>(DL + RB * kNsDlLd);
+    for (int i = threadIdx.x; i < kVecFloats; i += NW * 64) sv[i] = vec[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int f0 = (kW / NW) * w;                      // first output feature of this wave
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- this wave's weight slices, as MFMA A operands, for the whole kernel
+    bf16x8 wa2[OT][4];     // forward:  A[m = o][k]      = W2[f0 + 16ot + m][k]
+    bf16x8 wb2[OT][4];     // dgrad:    A[m = k_in][k=o] = W2[o][f0 + 16kt + m]
+    bf16x8 wa3[OT];        // d(h2):    A[m = f][k = class] = W3[class][f0 + 16ot + m]   (classes >= 16: zero)
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* p = W2 + (size_t)(f0 + 16 * ot + c) * kW + 32 * ks + 8 * g;
+            wa2[ot][ks] = pack8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+            f32x4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = W2[(size_t)(32 * ks + 8 * g + j) * kW + f0 + 16 * ot + c];
+                hi[j] = W2[(size_t)(32 * ks + 8 * g + 4 + j) * kW + f0 + 16 * ot + c];
+            }
+            wb2[ot][ks] = pack8(lo, hi);
+        }
+        f32x4 lo = zero4, hi = zero4;
+        if (g < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = W3[(size_t)(8 * g + j) * kW + f0 + 16 * ot + c];
+                hi[j] = W3[(size_t)(8 * g + 4 + j) * kW + f0 + 16 * ot + c];
+            }
+        }
+        wa3[ot] = pack8(lo, hi);
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    // ---- accumulators (feature view).  D[m][n]: lane (n = c, g) holds m = 4g .. 4g+3.
+    f32x4 dw2[OT][8];                    // [o tile][k tile]: d(W2)[f0 + 16ot + 4g + i][16kt + c]
+    f32x4 dw3[OT];                       // d(W3)[class 4g + i][f0 + 16ft + c]
+    f32x4 sdb3 = zero4;                  // d(b3)[class 4g + i]            (every column n holds the same sum)
+    f32x4 sbet1[OT], sgam1[OT], sbet2[OT], sgam2[OT], sb2[OT];      // [o tile]: feature f0 + 16ot + 4g + i
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        dw3[ot] = sbet1[ot] = sgam1[ot] = sbet2[ot] = sgam2[ot] = sb2[ot] = zero4;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) dw2[ot][kt] = zero4;
+    }
+    __syncthreads();
+    const float* sv_n = sv + 8 * g;      // natural layout: features 32t + 8g + ...
+    const int myrow = 16 * w + c;        // this lane's row of the block (row view)
+    const long nblk = (N + RB - 1) / RB;
+    bool pending = false;                // the previous block's LayerNorm-1 row sums are still to be taken
+    auto ln1_sums = [&]() {              // step 7 (features): d(beta1), d(gamma1) += row sums of the d(z1), d(z1) n1 tiles
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                sbet1[ot] = mfma(ns_tr_frag(T2, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet1[ot]);
+                sgam1[ot] = mfma(ns_tr_frag(T3, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam1[ot]);
+            }
+    };
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const long r = blk * RB + myrow;
+        const bool ok = r < N;
+        // ---------------- step 0 (rows): x -> LayerNorm 1 + ReLU -> h1; stage d(logits)
+        bf16x8 xr[4], xh1[4], xh2[4];
+        float rs1, rs2;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[t] = ok ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * t + 8 * g) : z8;
+        if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = ok ? *reinterpret_cast<const bf16x8*>(dlog + r * kC + 8 * g) : z8;
+        ln_relu_nat<true>(xr, sv_n + kW, sv_n + 2 * kW, eps, xh1, rs1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T0 + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
+        __syncthreads();
+        if (pending) ln1_sums();
+        // ---------------- step 1 (features): a2 = W2 h1 + b2 for this wave's output features, all rows
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 acc[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = *reinterpret_cast<const f32x4*>(sv + 3 * kW + f0 + 16 * ot + 4 * g);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T0 + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma(wa2[ot][ks], b, acc[ot]);
+            }
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(acc[ot], bf16x4);
+            __builtin_amdgcn_sched_barrier(0);         // (keeps the operand reads of the next row tiles from piling up in registers)
+        }
+        __syncthreads();
+        // ---------------- step 2 (rows): LayerNorm 2 + ReLU -> h2
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x8*>(T1 + myrow * kNsLd + 32 * t + 8 * g);
+        ln_relu_nat<true>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, xh2, rs2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T2 + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
+        __syncthreads();
+        // ---------------- step 3 (features): d(h2) = W3^T d(logits); d(W3), d(b3)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8 b = g < 2 ? *reinterpret_cast<const bf16x8*>(DL + (16 * rt + c) * kNsDlLd + 8 * g) : z8;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                const f32x4 d = mfma(wa3[ot], b, zero4);
+                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(d, bf16x4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = ns_tr_frag(DL, kNsDlLd, 32 * ks, 0, c, g);           // A[m = class][k = row]
+            if (w == 0) sdb3 = mfma(a, ones, sdb3);
+#pragma unroll
+            for (int ft = 0; ft < OT; ++ft)
+                dw3[ft] = mfma(a, ns_tr_frag(T2, kNsLd, 32 * ks, f0 + 16 * ft, c, g), dw3[ft]);
+        }
+        __syncthreads();
+        // ---------------- step 4 (rows): LayerNorm 2 backward -> d(a2); the tiles of d(beta2), d(gamma2)
+        {
+            f32x4 d[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(T1 + myrow * kNsLd + 32 * t + 8 * g);
+                d[2 * t] = unpack_half(v, 0);
+                d[2 * t + 1] = unpack_half(v, 1);
+            }
+            // (T1: d(z2) n2 overwrites this lane's own d(h2) chunks, all read above)
+            ns_ln_relu_bwd(d, xh2, rs2, sv_n + 4 * kW, sv_n + 5 * kW, T3 + myrow * kNsLd + 8 * g, T2 + myrow * kNsLd + 8 * g,
+                           T1 + myrow * kNsLd + 8 * g, true);
+        }
+        __syncthreads();
+        // ---------------- step 5 (features): row sums, d(W2), d(h1) = W2^T d(a2)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 ada[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                ada[ot] = ns_tr_frag(T3, kNsLd, 32 * ks, f0 + 16 * ot, c, g);             // A[m = o][k = row] of d(a2)
+                sb2[ot] = mfma(ada[ot], ones, sb2[ot]);
+                sbet2[ot] = mfma(ns_tr_frag(T2, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet2[ot]);
+                sgam2[ot] = mfma(ns_tr_frag(T1, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam2[ot]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const bf16x8 b = ns_tr_frag(T0, kNsLd, 32 * ks, 16 * kt, c, g);           // B[k = row][n = input feature] of h1
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) dw2[ot][kt] = mfma(ada[ot], b, dw2[ot][kt]);
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        bf16x4 dh1[RT][OT];                                   // held over the barrier: T1 is still being read (d(z2) n2)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 acc[OT];
+#pragma unroll
+            for (int kt = 0; kt < OT; ++kt) acc[kt] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T3 + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
+#pragma unroll
+                for (int kt = 0; kt < OT; ++kt) acc[kt] = mfma(wb2[kt][ks], b, acc[kt]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < OT; ++kt) dh1[rt][kt] = __builtin_convertvector(acc[kt], bf16x4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int kt = 0; kt < OT; ++kt)
+                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * kt + 4 * g) = dh1[rt][kt];
+        __syncthreads();
+        // ---------------- step 6 (rows): LayerNorm 1 backward -> d(x); the tiles of d(beta1), d(gamma1)
+        {
+            f32x4 d[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(T1 + myrow * kNsLd + 32 * t + 8 * g);
+                d[2 * t] = unpack_half(v, 0);
+                d[2 * t + 1] = unpack_half(v, 1);
+            }
+            ns_ln_relu_bwd(d, xh1, rs1, sv_n + kW, sv_n + 2 * kW, dx + r * kW + 8 * g, T2 + myrow * kNsLd + 8 * g,
+                           T3 + myrow * kNsLd + 8 * g, ok);
+        }
+        pending = true;
+        // (step 7 -- the row sums of LayerNorm 1 from T2 / T3 -- runs after the NEXT barrier: the next block's step 0
+        //  only writes T0 and DL, both last read before the barrier above step 6; T2 / T3 are not written again before
+        //  the next block's second / fourth barrier)
+    }
+    if (pending) {
+        __syncthreads();
+        ln1_sums();
+    }
+    // ---- parameter gradients: one atomic per element and workgroup
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + 16 * ot + 4 * g + i;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) atomicAdd(pgrad + 6 * kW + kC * kW + kC + (size_t)f * kW + 16 * kt + c, dw2[ot][kt][i]);
+            atomicAdd(pgrad + 6 * kW + (4 * g + i) * kW + f0 + 16 * ot + c, dw3[ot][i]);
+            if (c == 0) {
+                atomicAdd(pgrad + 0 * kW + f, sgam1[ot][i]);
+                atomicAdd(pgrad + 1 * kW + f, sbet1[ot][i]);
+                atomicAdd(pgrad + 3 * kW + f, sgam2[ot][i]);
+                atomicAdd(pgrad + 4 * kW + f, sbet2[ot][i]);
+                atomicAdd(pgrad + 5 * kW + f, sb2[ot][i]);
+            }
+        }
+    }
+    if (w == 0 && c == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(pgrad + 6 * kW + kC * kW + 4 * g + i, sdb3[i]);
+    }
+}
+
+extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
+                                          const float* vectors, void* grad_x, float* param_grads, long N, int width,
+                                          int classes, float eps, void* stream) {
+    VER_REQUIRE(N >= 0, VER_EINVAL, "ver_occ_mlp_backward_fused: negative row count");
+    VER_REQUIRE(width == kW && classes == kC, VER_EUNSUPPORTED,
+                "ver_occ_mlp_backward_fused: built for width %d / %d classes (got %d / %d)", kW, kC, width, classes);
+    VER_REQUIRE(W2 && W3 && vectors && param_grads, VER_EINVAL, "ver_occ_mlp_backward_fused: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW + kC + kW * kW) * sizeof(float), st);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: memset: %s", hipGetErrorString(e));
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(x && grad_logits && grad_x, VER_EINVAL, "ver_occ_mlp_backward_fused: null pointer argument");
+    VER_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)grad_x & 15) == 0 && ((uintptr_t)grad_logits & 15) == 0 &&
+                    ((uintptr_t)W2 & 15) == 0,
+                VER_EINVAL, "ver_occ_mlp_backward_fused: buffers must be 16-byte aligned");
+    static const int nw = [] {
+        const char* ev = getenv("VER_OCC_MLP_NS_WAVES");       // 8: 128-row blocks, two waves per SIMD; 4: 64-row blocks
+        const int v = ev ? atoi(ev) : 8;
+        return v == 4 ? 4 : 8;
+    }();
+    const size_t lds = ns_lds_bytes(nw);
+    const void* kern = nw == 8 ? (const void*)k_occ_mlp_bwd_ns<8> : (const void*)k_occ_mlp_bwd_ns<4>;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: LDS attribute: %s", hipGetErrorString(e));
+    const long nblk = (N + 16 * nw - 1) / (16 * nw);
+    const long per_cu = nw == 4 ? 2 : 1;                   // 4 waves: 75 KB of LDS, two workgroups per CU
+    const long grid = nblk < 256 * per_cu ? nblk : 256 * per_cu;          // persistent
+    if (nw == 8)
+        hipLaunchKernelGGL(k_occ_mlp_bwd_ns<8>, dim3((unsigned)grid), dim3(512), lds, st, (const __bf16*)x,
+                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps);
+    else
+        hipLaunchKernelGGL(k_occ_mlp_bwd_ns<4>, dim3((unsigned)grid), dim3(256), lds, st, (const __bf16*)x,
+                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps);
+    return ver_check_launch("ver_occ_mlp_backward_fused");
 }

@@ -14,13 +14,13 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
-           'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_lattice_gather', 'ver_lattice_scatter',
+           'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward')
@@ -592,6 +592,9 @@ def _frag_order(device):
     return _FRAG_ORDER[key]
 
 
+_OCC_MLP_BWD_FUSED = os.environ.get('VER_OCC_MLP_BWD_FUSED', '1') == '1'      # (0: row-split kernel + host GEMM for d(W2))
+
+
 class OccMLPFunction(Function):
     """``occ_branches`` (head:241-248) as one fused kernel each way (ver_occ_mlp_*): x bf16 [N,128]
     -> logits bf16 [N,16].  Nothing but x is kept for the backward pass (the chain is re-computed)."""
@@ -609,18 +612,30 @@ class OccMLPFunction(Function):
             w1, b1 = w2, torch.zeros(128, device=x.device)
         image = occ_mlp_pack(w1, w2, w3)
         vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
-        ctx.save_for_backward(x, image, vec)
+        ctx.save_for_backward(x, image, vec, w2.detach(), w3.detach())
         ctx.eps = eps
         return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_logits):
-        x, image, vec = ctx.saved_tensors
+        x, image, vec, w2, w3 = ctx.saved_tensors
         shape = x.shape
         x2 = x.view(-1, 128)
         n = x2.shape[0]
         gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
+        if ctx.folded and _OCC_MLP_BWD_FUSED:
+            # N-split kernel: d(W2) and every other parameter gradient accumulated in the kernel, no side tensors
+            gx = torch.empty_like(x2)
+            pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
+            _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
+                _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
+                ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _stream()))
+            vecs = pg[:768].view(6, 128)
+            dw3 = pg[768:768 + 2048].view(16, 128)
+            db3 = pg[768 + 2048:768 + 2048 + 16]
+            dw2 = pg[768 + 2048 + 16:].view(128, 128)
+            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
         gx, ga2, h1 = (torch.empty_like(x2) for _ in range(3))
         ga1 = None if ctx.folded else torch.empty_like(x2)
         pg = torch.empty(6 * 128 + 16 * 128 + 16, dtype=torch.float32, device=x.device)

@@ -988,6 +988,291 @@ __global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __rest
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// The same arithmetic, WAVE SPECIALISED (k_occ_mlp_bwd_ws): in the kernel above all eight waves are in the row view or all in
+// the feature view, so a SIMD's two waves always want the same unit -- VALU in the LayerNorm steps, LDS + matrix cores in the
+// product steps -- and the two kinds of work add up (measured: 8.7 ms + 9.5 ms of a 17.5-ms launch over 32 M rows).  Here
+// waves 0-3 are the ROW team (LayerNorm forward / backward of 16 rows each, nothing else: no weights, no accumulators) and
+// waves 4-7 the FEATURE team (32 output features each: weights, d(W2) and the row sums in registers, nothing else), one wave
+// of each team per SIMD, and TWO 64-row blocks A and B are in flight, three steps apart: in every slot the row team runs a
+// row step of one block while the feature team runs a product step of the other.
+//     slot     0      1      2      3      4      5      6      7          (one workgroup barrier after each)
+//     rows     A.0    B.6    A.2    B.0    A.4    B.2    A.6    B.4
+//     features B.5    A.1    B.7    A.3    B.1    A.5    B.3    A.7
+// Steps of a block: 0 LN1 fwd | 1 a2 = W2 h1 | 2 LN2 fwd | 3 d(h2), d(W3) | 4 LN2 bwd | 5 sums, d(W2), d(h1) | 6 LN1 bwd | 7 LN1 sums.
+// LDS: per block set T0 h1, T1 a2 -> d(h2) -> d(z2)n2, T2 h2 -> d(z2) -> d(z1), T3 d(a2) -> d(z1)n1, DL; ONE shared tile for
+// d(h1) (A writes it in slot 5 and reads it in slot 6, B in slots 0 and 1): 9 x 17 KB + 4 KB + vectors = 159.6 KB.
+namespace {
+constexpr int kWsRows = 64;
+constexpr int kWsTile = kWsRows * kNsLd;
+constexpr int kWsVec0 = kW;                                      // b1 is not staged (folded mode)
+constexpr size_t kWsLds = (size_t)9 * kWsTile * 2 + (size_t)2 * kWsRows * kNsDlLd * 2 + (kVecFloats - kWsVec0) * sizeof(float);
+}  // namespace
+
+__global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
+                                                        const float* __restrict__ W2, const float* __restrict__ W3,
+                                                        const float* __restrict__ vec, __bf16* __restrict__ dx,
+                                                        float* __restrict__ pgrad, long N, float eps) {
+    constexpr int OT = 2, RT = 4, KS = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __bf16* const tiles = reinterpret_cast<__bf16*>(smem);              // [set][4] tiles, then the shared d(h1) tile
+    __bf16* const T4 = tiles + 8 * kWsTile;
+    __bf16* const DLs = T4 + kWsTile;                                    // [set][64][16]
+    float* const sv = reinterpret_cast<float*>(DLs + 2 * kWsRows * kNsDlLd) - kWsVec0;   // sv[i] valid for i >= 128
+    for (int i = kWsVec0 + threadIdx.x; i < kVecFloats; i += 512) sv[i] = vec[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int team = wv >> 2, q = wv & 3;
+    const int c = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // this workgroup's blocks: blockIdx.x, + gridDim.x, ...; round k works on block 2k (A) and 2k + 1 (B)
+    const long nblk = (N + kWsRows - 1) / kWsRows;
+    const long nmine = blockIdx.x < nblk ? (nblk - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const long rounds = nmine / 2 + 1;
+    __syncthreads();
+    if (team == 0) {
+        // =================================================================== ROW team
+        const float* sv_n = sv + 8 * g;
+        const int myrow = 16 * q + c;
+        struct RowState {
+            bf16x8 xh1[4], xh2[4];
+            float rs1, rs2;
+            long r;
+            bool ok;
+        };
+        RowState sa, sb;
+        auto r0 = [&](RowState& st, __bf16* T, __bf16* DL, long blk) {          // x -> LN1 + ReLU -> h1 (T0); stage d(logits)
+            st.r = blk * kWsRows + myrow;
+            st.ok = st.r < N;
+            bf16x8 xr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xr[t] = st.ok ? *reinterpret_cast<const bf16x8*>(x + st.r * kW + 32 * t + 8 * g) : z8;
+            if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = st.ok ? *reinterpret_cast<const bf16x8*>(dlog + st.r * kC + 8 * g) : z8;
+            ln_relu_nat<true>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
+        };
+        auto r2 = [&](RowState& st, __bf16* T) {                                  // a2 (T1) -> LN2 + ReLU -> h2 (T2)
+            bf16x8 xr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x8*>(T + kWsTile + myrow * kNsLd + 32 * t + 8 * g);
+            ln_relu_nat<true>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + 2 * kWsTile + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
+        };
+        auto r4 = [&](RowState& st, __bf16* T) {                                  // d(h2) (T1) -> LN2 bwd -> d(a2) T3, d(z2) T2, d(z2)n2 T1
+            f32x4 d[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(T + kWsTile + myrow * kNsLd + 32 * t + 8 * g);
+                d[2 * t] = unpack_half(v, 0);
+                d[2 * t + 1] = unpack_half(v, 1);
+            }
+            ns_ln_relu_bwd(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
+                           T + 2 * kWsTile + myrow * kNsLd + 8 * g, T + kWsTile + myrow * kNsLd + 8 * g, true);
+        };
+        auto r6 = [&](RowState& st, __bf16* T) {                                  // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
+            f32x4 d[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(T4 + myrow * kNsLd + 32 * t + 8 * g);
+                d[2 * t] = unpack_half(v, 0);
+                d[2 * t + 1] = unpack_half(v, 1);
+            }
+            ns_ln_relu_bwd(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
+                           T + 3 * kWsTile + myrow * kNsLd + 8 * g, st.ok);
+        };
+        __bf16* const TA = tiles;
+        __bf16* const TB = tiles + 4 * kWsTile;
+        for (long k = 0; k < rounds; ++k) {
+            const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
+            const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
+            if (va) r0(sa, TA, DLs, blk_a);
+            __syncthreads();
+            if (vp) r6(sb, TB);
+            __syncthreads();
+            if (va) r2(sa, TA);
+            __syncthreads();
+            if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
+            __syncthreads();
+            if (va) r4(sa, TA);
+            __syncthreads();
+            if (vb) r2(sb, TB);
+            __syncthreads();
+            if (va) r6(sa, TA);
+            __syncthreads();
+            if (vb) r4(sb, TB);
+            __syncthreads();
+        }
+        return;
+    }
+    // ======================================================================= FEATURE team
+    const int f0 = 32 * q;
+    bf16x8 wa2[OT][4], wb2[OT][4], wa3[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float* p = W2 + (size_t)(f0 + 16 * ot + c) * kW + 32 * ks + 8 * g;
+            wa2[ot][ks] = pack8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+            f32x4 lo, hi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = W2[(size_t)(32 * ks + 8 * g + j) * kW + f0 + 16 * ot + c];
+                hi[j] = W2[(size_t)(32 * ks + 8 * g + 4 + j) * kW + f0 + 16 * ot + c];
+            }
+            wb2[ot][ks] = pack8(lo, hi);
+        }
+        f32x4 lo = zero4, hi = zero4;
+        if (g < 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = W3[(size_t)(8 * g + j) * kW + f0 + 16 * ot + c];
+                hi[j] = W3[(size_t)(8 * g + 4 + j) * kW + f0 + 16 * ot + c];
+            }
+        }
+        wa3[ot] = pack8(lo, hi);
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    f32x4 dw2[OT][8], dw3[OT], sdb3 = zero4, sbet1[OT], sgam1[OT], sbet2[OT], sgam2[OT], sb2[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        dw3[ot] = sbet1[ot] = sgam1[ot] = sbet2[ot] = sgam2[ot] = sb2[ot] = zero4;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) dw2[ot][kt] = zero4;
+    }
+    auto f1 = [&](__bf16* T) {                                            // a2 = W2 h1 + b2: T0 -> T1
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 acc[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = *reinterpret_cast<const f32x4*>(sv + 3 * kW + f0 + 16 * ot + 4 * g);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma(wa2[ot][ks], b, acc[ot]);
+            }
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(acc[ot], bf16x4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto f3 = [&](__bf16* T, __bf16* DL) {                                 // d(h2) = W3^T d(logits) -> T1; d(W3), d(b3) from DL, T2
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const bf16x8 b = g < 2 ? *reinterpret_cast<const bf16x8*>(DL + (16 * rt + c) * kNsDlLd + 8 * g) : z8;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                const f32x4 d = mfma(wa3[ot], b, zero4);
+                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(d, bf16x4);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = ns_tr_frag(DL, kNsDlLd, 32 * ks, 0, c, g);
+            if (q == 0) sdb3 = mfma(a, ones, sdb3);
+#pragma unroll
+            for (int ft = 0; ft < OT; ++ft) dw3[ft] = mfma(a, ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ft, c, g), dw3[ft]);
+        }
+    };
+    auto f5 = [&](__bf16* T) {                                            // LN2 row sums, d(W2), d(h1) = W2^T d(a2) -> T4
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 ada[OT];
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                ada[ot] = ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
+                sb2[ot] = mfma(ada[ot], ones, sb2[ot]);
+                sbet2[ot] = mfma(ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet2[ot]);
+                sgam2[ot] = mfma(ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam2[ot]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) {
+                const bf16x8 b = ns_tr_frag(T, kNsLd, 32 * ks, 16 * kt, c, g);
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) dw2[ot][kt] = mfma(ada[ot], b, dw2[ot][kt]);
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            f32x4 acc[OT];
+#pragma unroll
+            for (int kt = 0; kt < OT; ++kt) acc[kt] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T + 3 * kWsTile + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
+#pragma unroll
+                for (int kt = 0; kt < OT; ++kt) acc[kt] = mfma(wb2[kt][ks], b, acc[kt]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < OT; ++kt)
+                *reinterpret_cast<bf16x4*>(T4 + (16 * rt + c) * kNsLd + f0 + 16 * kt + 4 * g) = __builtin_convertvector(acc[kt], bf16x4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto f7 = [&](__bf16* T) {                                            // LN1 row sums from T2, T3
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                sbet1[ot] = mfma(ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet1[ot]);
+                sgam1[ot] = mfma(ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam1[ot]);
+            }
+    };
+    {
+        __bf16* const TA = tiles;
+        __bf16* const TB = tiles + 4 * kWsTile;
+        __bf16* const DLA = DLs;
+        __bf16* const DLB = DLs + kWsRows * kNsDlLd;
+        for (long k = 0; k < rounds; ++k) {
+            const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
+            if (vp) f5(TB);
+            __syncthreads();
+            if (va) f1(TA);
+            __syncthreads();
+            if (vp) f7(TB);
+            __syncthreads();
+            if (va) f3(TA, DLA);
+            __syncthreads();
+            if (vb) f1(TB);
+            __syncthreads();
+            if (va) f5(TA);
+            __syncthreads();
+            if (vb) f3(TB, DLB);
+            __syncthreads();
+            if (va) f7(TA);
+            __syncthreads();
+        }
+    }
+    // ---- parameter gradients: one atomic per element and workgroup
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + 16 * ot + 4 * g + i;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt) atomicAdd(pgrad + 6 * kW + kC * kW + kC + (size_t)f * kW + 16 * kt + c, dw2[ot][kt][i]);
+            atomicAdd(pgrad + 6 * kW + (4 * g + i) * kW + f0 + 16 * ot + c, dw3[ot][i]);
+            if (c == 0) {
+                atomicAdd(pgrad + 0 * kW + f, sgam1[ot][i]);
+                atomicAdd(pgrad + 1 * kW + f, sbet1[ot][i]);
+                atomicAdd(pgrad + 3 * kW + f, sgam2[ot][i]);
+                atomicAdd(pgrad + 4 * kW + f, sbet2[ot][i]);
+                atomicAdd(pgrad + 5 * kW + f, sb2[ot][i]);
+            }
+        }
+    }
+    if (q == 0 && c == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(pgrad + 6 * kW + kC * kW + 4 * g + i, sdb3[i]);
+    }
+}
+
 extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                           const float* vectors, void* grad_x, float* param_grads, long N, int width,
                                           int classes, float eps, void* stream) {
@@ -1003,6 +1288,19 @@ extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits
     VER_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)grad_x & 15) == 0 && ((uintptr_t)grad_logits & 15) == 0 &&
                     ((uintptr_t)W2 & 15) == 0,
                 VER_EINVAL, "ver_occ_mlp_backward_fused: buffers must be 16-byte aligned");
+    static const int ws = [] {
+        const char* ev = getenv("VER_OCC_MLP_WS");              // 1 (default): wave-specialised kernel; 0: phase-locked N-split
+        return ev ? atoi(ev) : 1;
+    }();
+    if (ws) {
+        e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: LDS attribute: %s", hipGetErrorString(e));
+        const long nb = (N + kWsRows - 1) / kWsRows;
+        const long gridw = nb < 256 ? nb : 256;               // one workgroup per CU (LDS bound), persistent
+        hipLaunchKernelGGL(k_occ_mlp_bwd_ws, dim3((unsigned)gridw), dim3(512), kWsLds, st, (const __bf16*)x,
+                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps);
+        return ver_check_launch("ver_occ_mlp_backward_fused");
+    }
     static const int nw = [] {
         const char* ev = getenv("VER_OCC_MLP_NS_WAVES");       // 8: 128-row blocks, two waves per SIMD; 4: 64-row blocks
         const int v = ev ? atoi(ev) : 8;

@@ -141,7 +141,9 @@ namespace {
 // 32t + 8g + j of the row in x[t][j]).  Used when the first Linear has been folded into the producer of x
 // (first_linear = 0): x is the pre-LayerNorm activation itself.  gam / bet already offset by 8g.
 // KEEP: also return the normalised values (bf16) and form the output from those rounded values (backward pass).
-template <bool KEEP>
+// QUAD: the four lanes that share a row are a quad (lane = 4 row + chunk) instead of the same column of the four 16-lane rows
+// (lane = row + 16 chunk): the row statistics are then two DPP quad permutes instead of two ds_bpermute round trips.
+template <bool KEEP, bool QUAD = false>
 __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, const float* bet, float eps,
                                             bf16x8 (&xh)[4], float& rstd_out) {
     f32x4 v[4][2];
@@ -154,8 +156,12 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
             v[t][h] = __builtin_convertvector(hx, f32x4);
             s += (v[t][h].x + v[t][h].y) + (v[t][h].z + v[t][h].w);
         }
-    s += xor16(s);
-    s += xor32(s);
+    if constexpr (QUAD) {
+        s = group_sum<4>(s);
+    } else {
+        s += xor16(s);
+        s += xor32(s);
+    }
     const float mu = s * (1.0f / kW);
     float q = 0.0f;
 #pragma unroll
@@ -165,8 +171,12 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
             v[t][h] -= mu;
             q += (v[t][h].x * v[t][h].x + v[t][h].y * v[t][h].y) + (v[t][h].z * v[t][h].z + v[t][h].w * v[t][h].w);
         }
-    q += xor16(q);
-    q += xor32(q);
+    if constexpr (QUAD) {
+        q = group_sum<4>(q);
+    } else {
+        q += xor16(q);
+        q += xor32(q);
+    }
     const float rs = rsqrtf(q * (1.0f / kW) + eps);
     rstd_out = rs;
 #pragma unroll
@@ -704,7 +714,7 @@ __device__ __forceinline__ bf16x8 ns_tr_frag(const __bf16* tile, int ld, int row
 // gam / bet offset by 8g).  Writes, for this lane's row, d(pre-LayerNorm) to `out` and the two tiles whose row sums are
 // d(beta) / d(gamma) to `pz` / `pn` (pointers to the lane's 8-feature chunk of k-step 0; + 32 elements per k-step) --
 // each as soon as it exists, so that no more than one k-step of them is ever live in registers.
-template <bool OUT_OK = true>
+template <bool QUAD = false>
 __device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
                                                const float* bet, __bf16* out, __bf16* pz, __bf16* pn, bool out_ok) {
     float s1 = 0.0f, s2 = 0.0f;
@@ -732,10 +742,15 @@ __device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)
         *reinterpret_cast<bf16x8*>(pz + 32 * t) = pack8(dz[0], dz[1]);
         *reinterpret_cast<bf16x8*>(pn + 32 * t) = pack8(dzn[0], dzn[1]);
     }
-    s1 += xor16(s1);
-    s1 += xor32(s1);
-    s2 += xor16(s2);
-    s2 += xor32(s2);
+    if constexpr (QUAD) {
+        s1 = group_sum<4>(s1);
+        s2 = group_sum<4>(s2);
+    } else {
+        s1 += xor16(s1);
+        s1 += xor32(s1);
+        s2 += xor16(s2);
+        s2 += xor32(s2);
+    }
     const float m1 = s1 * (1.0f / kW), m2 = s2 * (1.0f / kW);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1009,6 +1024,12 @@ constexpr int kWsVec0 = kW;                                      // b1 is not st
 constexpr size_t kWsLds = (size_t)9 * kWsTile * 2 + (size_t)2 * kWsRows * kNsDlLd * 2 + (kVecFloats - kWsVec0) * sizeof(float);
 }  // namespace
 
+namespace {
+// Workgroup barrier that orders LDS traffic only: this wave's LDS operations are complete, global loads may stay in flight
+// across it (__syncthreads() also waits for vmcnt(0), which would serialise the row team's prefetch of the next block's x).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace
+
 __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ vec, __bf16* __restrict__ dx,
@@ -1022,7 +1043,9 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
     for (int i = kWsVec0 + threadIdx.x; i < kVecFloats; i += 512) sv[i] = vec[i];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int team = wv >> 2, q = wv & 3;
-    const int c = lane & 15, g = lane >> 4;
+    // feature team: MFMA operand coordinates (c = lane & 15, g = lane >> 4); row team: row = lane >> 2, chunk = lane & 3
+    // (a row's four 8-feature chunks of a k-step sit on one quad: DPP reductions)
+    const int c = team ? (lane & 15) : (lane >> 2), g = team ? (lane >> 4) : (lane & 3);
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // this workgroup's blocks: blockIdx.x, + gridDim.x, ...; round k works on block 2k (A) and 2k + 1 (B)
@@ -1039,16 +1062,30 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             float rs1, rs2;
             long r;
             bool ok;
+            bf16x8 xn[4], dln;            // the NEXT block's x / d(logits) chunks of this lane, requested a round ahead
+            bool okn;
         };
         RowState sa, sb;
+        // a lone wave per SIMD has nothing to hide an HBM round trip behind: the operands of a block's step 0 are
+        // requested one round (eight slots) earlier
+        // (unconditional loads from a clamped row: loads under a branch make the compiler wait for vmcnt(0) everywhere)
+        auto prefetch = [&](RowState& st, long blk, bool valid) {
+            const long rn = blk * kWsRows + myrow;
+            st.okn = valid && rn < N;
+            const long rc = st.okn ? rn : N - 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) st.xn[t] = *reinterpret_cast<const bf16x8*>(x + rc * kW + 32 * t + 8 * g);
+            st.dln = *reinterpret_cast<const bf16x8*>(dlog + rc * kC + 8 * (g & 1));
+        };
         auto r0 = [&](RowState& st, __bf16* T, __bf16* DL, long blk) {          // x -> LN1 + ReLU -> h1 (T0); stage d(logits)
             st.r = blk * kWsRows + myrow;
             st.ok = st.r < N;
             bf16x8 xr[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xr[t] = st.ok ? *reinterpret_cast<const bf16x8*>(x + st.r * kW + 32 * t + 8 * g) : z8;
-            if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = st.ok ? *reinterpret_cast<const bf16x8*>(dlog + st.r * kC + 8 * g) : z8;
-            ln_relu_nat<true>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
+            for (int t = 0; t < 4; ++t) xr[t] = st.okn ? st.xn[t] : z8;
+            if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = st.okn ? st.dln : z8;
+            prefetch(st, blk + 2 * (long)gridDim.x, blk + 2 * (long)gridDim.x < nblk);
+            ln_relu_nat<true, true>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1056,7 +1093,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             bf16x8 xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x8*>(T + kWsTile + myrow * kNsLd + 32 * t + 8 * g);
-            ln_relu_nat<true>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
+            ln_relu_nat<true, true>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + 2 * kWsTile + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1068,7 +1105,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 d[2 * t] = unpack_half(v, 0);
                 d[2 * t + 1] = unpack_half(v, 1);
             }
-            ns_ln_relu_bwd(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
+            ns_ln_relu_bwd<true>(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 2 * kWsTile + myrow * kNsLd + 8 * g, T + kWsTile + myrow * kNsLd + 8 * g, true);
         };
         auto r6 = [&](RowState& st, __bf16* T) {                                  // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
@@ -1079,30 +1116,37 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 d[2 * t] = unpack_half(v, 0);
                 d[2 * t + 1] = unpack_half(v, 1);
             }
-            ns_ln_relu_bwd(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
+            ns_ln_relu_bwd<true>(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 3 * kWsTile + myrow * kNsLd + 8 * g, st.ok);
         };
         __bf16* const TA = tiles;
         __bf16* const TB = tiles + 4 * kWsTile;
+        prefetch(sa, blockIdx.x, blockIdx.x < nblk);
+        prefetch(sb, blockIdx.x + (long)gridDim.x, blockIdx.x + (long)gridDim.x < nblk);
         for (long k = 0; k < rounds; ++k) {
             const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
             const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
+#ifdef VER_WS_ABL_NOROW
+            (void)blk_a; (void)blk_b; (void)va; (void)vb; (void)vp;
+            for (int sl = 0; sl < 8; ++sl) lds_barrier();
+#else
             if (va) r0(sa, TA, DLs, blk_a);
-            __syncthreads();
+            lds_barrier();
             if (vp) r6(sb, TB);
-            __syncthreads();
+            lds_barrier();
             if (va) r2(sa, TA);
-            __syncthreads();
+            lds_barrier();
             if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
-            __syncthreads();
+            lds_barrier();
             if (va) r4(sa, TA);
-            __syncthreads();
+            lds_barrier();
             if (vb) r2(sb, TB);
-            __syncthreads();
+            lds_barrier();
             if (va) r6(sa, TA);
-            __syncthreads();
+            lds_barrier();
             if (vb) r4(sb, TB);
-            __syncthreads();
+            lds_barrier();
+#endif
         }
         return;
     }
@@ -1231,22 +1275,27 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
         __bf16* const DLB = DLs + kWsRows * kNsDlLd;
         for (long k = 0; k < rounds; ++k) {
             const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
+#ifdef VER_WS_ABL_NOFEAT
+            (void)va; (void)vb; (void)vp; (void)DLA; (void)DLB;
+            for (int sl = 0; sl < 8; ++sl) lds_barrier();
+#else
             if (vp) f5(TB);
-            __syncthreads();
+            lds_barrier();
             if (va) f1(TA);
-            __syncthreads();
+            lds_barrier();
             if (vp) f7(TB);
-            __syncthreads();
+            lds_barrier();
             if (va) f3(TA, DLA);
-            __syncthreads();
+            lds_barrier();
             if (vb) f1(TB);
-            __syncthreads();
+            lds_barrier();
             if (va) f5(TA);
-            __syncthreads();
+            lds_barrier();
             if (vb) f3(TB, DLB);
-            __syncthreads();
+            lds_barrier();
             if (va) f7(TA);
-            __syncthreads();
+            lds_barrier();
+#endif
         }
     }
     // ---- parameter gradients: one atomic per element and workgroup

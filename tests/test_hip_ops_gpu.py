@@ -717,11 +717,15 @@ def test_occ_mlp_fused_backward():
         assert rel(pd[k].grad, pr[k].grad) < 8e-2, (k, rel(pd[k].grad, pr[k].grad))
 
 
-def test_occ_mlp_fused_with_folded_first_linear():
+@pytest.mark.parametrize('fused', [True, False])
+def test_occ_mlp_fused_with_folded_first_linear(fused, monkeypatch):
     """first_linear = 0 (the first Linear folded into the producer of x): the kernels start at the first LayerNorm.
+    ``fused``: the wave-specialised N-split backward kernel that accumulates d(W2) itself (ver_occ_mlp_backward_fused, the
+    default) / the row-split kernel + host GEMM over its side tensors.
     x := bf16(Linear1(x0)); forward and every gradient (d x = gradient w.r.t. that output) vs autograd through the
     fp64 chain LayerNorm -> ReLU -> Linear2 -> LayerNorm -> ReLU -> Linear3 on the same x."""
     hip = pkg('hipops')
+    monkeypatch.setattr(hip, '_OCC_MLP_BWD_FUSED', fused)
     gen = torch.Generator(device='cpu').manual_seed(13)
     p = _occ_mlp_params(gen)
     n = 8000 + 16 * 7 + 3
@@ -753,6 +757,42 @@ def test_occ_mlp_fused_with_folded_first_linear():
                                hip.occ_mlp_pack(p['w1'].to(DEV), p['w2'].to(DEV), p['w3'].to(DEV)),
                                hip.occ_mlp_vectors(*(p[k].to(DEV) for k in ('b1', 'g1', 'be1', 'b2', 'g2', 'be2', 'b3'))),
                                first_linear=False).shape == (0, 16)
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 128, 191, 64 * 256 + 1, 64 * 513 + 7])
+def test_occ_mlp_backward_kernels_on_ragged_sizes(n, monkeypatch):
+    """Both backward kernels of the folded MLP on row counts around the block / pipeline edges of the wave-specialised
+    kernel (64-row blocks, two in flight per workgroup, 256 persistent workgroups: one row, one block, one block + a row,
+    an odd number of blocks, more blocks than workgroups, more than two rounds): d(x) and every parameter gradient
+    against autograd through the fp64 chain, and the two kernels within the same distance of each other (what separates
+    any two bf16 evaluations of this chain is a handful of ReLU gates that flip with the rounding of the pre-activations:
+    3-5 % relative L2 at these sizes, for either kernel)."""
+    hip = pkg('hipops')
+    F = torch.nn.functional
+    gen = torch.Generator(device='cpu').manual_seed(100 + n % 97)
+    p = _occ_mlp_params(gen)
+    a1 = (torch.randn(n, 128, generator=gen) * 1.5).bfloat16()
+    gy = (torch.randn(n, 16, generator=gen) * 0.1).bfloat16()
+    keys = ('g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+    pr = {k: (v.bfloat16().double() if k.startswith('w') else v.double()).requires_grad_(True) for k, v in p.items()}
+    xr = a1.double().requires_grad_(True)
+    h = F.relu(F.layer_norm(xr, (128,), pr['g1'], pr['be1'], 1e-5))
+    h = F.relu(F.layer_norm(h @ pr['w2'].t() + pr['b2'], (128,), pr['g2'], pr['be2'], 1e-5))
+    ((h @ pr['w3'].t() + pr['b3']) * gy.double()).sum().backward()
+    from util import rel_l2
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(hip, '_OCC_MLP_BWD_FUSED', fused)
+        pd = {k: p[k].to(DEV).requires_grad_(True) for k in keys}
+        xd = a1.to(DEV).requires_grad_(True)
+        hip.occ_mlp(xd, None, None, *(pd[k] for k in keys)).backward(gy.to(DEV))
+        res[fused] = dict(x=xd.grad.float().cpu(), **{k: pd[k].grad.float().cpu() for k in keys})
+        assert torch.isfinite(res[fused]['x']).all()
+        assert rel_l2(res[fused]['x'], xr.grad) < 7e-2, (fused, rel_l2(res[fused]['x'], xr.grad))
+        for k in keys:
+            assert rel_l2(res[fused][k], pr[k].grad) < 8e-2, (fused, k, rel_l2(res[fused][k], pr[k].grad))
+    for k in ('x',) + keys:
+        assert rel_l2(res[True][k], res[False][k]) < 8e-2, (k, rel_l2(res[True][k], res[False][k]))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

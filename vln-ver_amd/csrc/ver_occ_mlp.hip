@@ -181,7 +181,16 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
     rstd_out = rs;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        if (KEEP) xh[t] = pack8(v[t][0] * rs, v[t][1] * rs);
+        if (KEEP) {
+            xh[t] = pack8(v[t][0] * rs, v[t][1] * rs);
+            // (opaque: seeing through pack + unpack the compiler rounds every element on its own -- one single-value
+            //  v_cvt_pk_bf16_f32 and one shift each -- and packs the pairs AGAIN for xh: 2.5 instructions per element
+            //  instead of 1.5)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 raw = __builtin_bit_cast(u32x4, xh[t]);
+            asm("" : "+v"(raw));
+            xh[t] = __builtin_bit_cast(bf16x8, raw);
+        }
         f32x4 y[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -714,7 +723,8 @@ __device__ __forceinline__ bf16x8 ns_tr_frag(const __bf16* tile, int ld, int row
 // gam / bet offset by 8g).  Writes, for this lane's row, d(pre-LayerNorm) to `out` and the two tiles whose row sums are
 // d(beta) / d(gamma) to `pz` / `pn` (pointers to the lane's 8-feature chunk of k-step 0; + 32 elements per k-step) --
 // each as soon as it exists, so that no more than one k-step of them is ever live in registers.
-template <bool QUAD = false>
+// XH: `pn` receives the normalised values n themselves instead of d(z) n (the consumer forms sum_r d(z) n as a matrix product).
+template <bool QUAD = false, bool XH = false>
 __device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)[4], float rs, const float* gam,
                                                const float* bet, __bf16* out, __bf16* pz, __bf16* pn, bool out_ok) {
     float s1 = 0.0f, s2 = 0.0f;
@@ -732,7 +742,7 @@ __device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)
             dz[h].y = y.y > 0.0f ? d[ot].y : 0.0f;
             dz[h].z = y.z > 0.0f ? d[ot].z : 0.0f;
             dz[h].w = y.w > 0.0f ? d[ot].w : 0.0f;
-            dzn[h] = dz[h] * n;
+            if constexpr (!XH) dzn[h] = dz[h] * n;
             const f32x4 dg = dz[h] * gm;
             d[ot] = dg;
             s1 += (dg.x + dg.y) + (dg.z + dg.w);
@@ -740,7 +750,7 @@ __device__ __forceinline__ void ns_ln_relu_bwd(f32x4 (&d)[8], const bf16x8 (&xh)
             s2 += (dn.x + dn.y) + (dn.z + dn.w);
         }
         *reinterpret_cast<bf16x8*>(pz + 32 * t) = pack8(dz[0], dz[1]);
-        *reinterpret_cast<bf16x8*>(pn + 32 * t) = pack8(dzn[0], dzn[1]);
+        *reinterpret_cast<bf16x8*>(pn + 32 * t) = XH ? xh[t] : pack8(dzn[0], dzn[1]);
     }
     if constexpr (QUAD) {
         s1 = group_sum<4>(s1);
@@ -1105,7 +1115,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 d[2 * t] = unpack_half(v, 0);
                 d[2 * t + 1] = unpack_half(v, 1);
             }
-            ns_ln_relu_bwd<true>(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
+            ns_ln_relu_bwd<true, true>(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 2 * kWsTile + myrow * kNsLd + 8 * g, T + kWsTile + myrow * kNsLd + 8 * g, true);
         };
         auto r6 = [&](RowState& st, __bf16* T) {                                  // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
@@ -1116,7 +1126,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 d[2 * t] = unpack_half(v, 0);
                 d[2 * t + 1] = unpack_half(v, 1);
             }
-            ns_ln_relu_bwd<true>(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
+            ns_ln_relu_bwd<true, true>(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 3 * kWsTile + myrow * kNsLd + 8 * g, st.ok);
         };
         __bf16* const TA = tiles;
@@ -1231,8 +1241,10 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int ot = 0; ot < OT; ++ot) {
                 ada[ot] = ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
                 sb2[ot] = mfma(ada[ot], ones, sb2[ot]);
-                sbet2[ot] = mfma(ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet2[ot]);
-                sgam2[ot] = mfma(ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam2[ot]);
+                const bf16x8 adz = ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
+                sbet2[ot] = mfma(adz, ones, sbet2[ot]);
+                // d(gamma2)[f] = sum_r d(z2)[r][f] n2[r][f] = the DIAGONAL of d(z2)^T n2 (T1 holds n2 itself)
+                sgam2[ot] = mfma(adz, ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam2[ot]);
             }
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) {
@@ -1264,8 +1276,9 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
-                sbet1[ot] = mfma(ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sbet1[ot]);
-                sgam1[ot] = mfma(ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), ones, sgam1[ot]);
+                const bf16x8 adz = ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
+                sbet1[ot] = mfma(adz, ones, sbet1[ot]);
+                sgam1[ot] = mfma(adz, ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam1[ot]);      // diagonal, as above
             }
     };
     {
@@ -1308,11 +1321,13 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int kt = 0; kt < 8; ++kt) atomicAdd(pgrad + 6 * kW + kC * kW + kC + (size_t)f * kW + 16 * kt + c, dw2[ot][kt][i]);
             atomicAdd(pgrad + 6 * kW + (4 * g + i) * kW + f0 + 16 * ot + c, dw3[ot][i]);
             if (c == 0) {
-                atomicAdd(pgrad + 0 * kW + f, sgam1[ot][i]);
                 atomicAdd(pgrad + 1 * kW + f, sbet1[ot][i]);
-                atomicAdd(pgrad + 3 * kW + f, sgam2[ot][i]);
                 atomicAdd(pgrad + 4 * kW + f, sbet2[ot][i]);
                 atomicAdd(pgrad + 5 * kW + f, sb2[ot][i]);
+            }
+            if (c == 4 * g + i) {               // D[m][n] with m == n: feature f0 + 16ot + c
+                atomicAdd(pgrad + 0 * kW + f, sgam1[ot][i]);
+                atomicAdd(pgrad + 3 * kW + f, sgam2[ot][i]);
             }
         }
     }

@@ -11,7 +11,7 @@ ap.add_argument('--batch', type=int, default=8)
 ap.add_argument('--micro', type=int, default=8)
 ap.add_argument('--out', default='gpurun_out/torch_prof.txt')
 a = ap.parse_args()
-args = argparse.Namespace(workload='vocc_c2f_train', dtype='bf16', micro=a.micro, batch=a.batch)
+args = argparse.Namespace(workload="vocc_c2f_train", dtype="bf16", micro=a.micro, batch=a.batch, config=None)
 dev = torch.device('cuda', 0)
 hip = importlib.import_module('vln-ver_amd.hipops'); hip.lib()
 pkg, syn, head, n_train = bench.build_model(args, dev)

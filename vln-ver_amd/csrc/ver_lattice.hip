@@ -90,28 +90,46 @@ template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict__ src, uint4* __restrict__ col,
                                                         TapListEx taps, long stride_v, int B, int Zr, int Zs, int H,
                                                         int W, int CV) {
+    // per row: the source vector index of every tap (clamped into the lattice) and whether the tap is inside, computed
+    // once by the first taps.n threads into LDS (two tables, by row parity: one barrier per row); the copy loop is then
+    // a table look-up, a 16-byte load and a nontemporal 16-byte store per vector -- the tap matrix is written once and
+    // read by GEMMs much later, it should not displace the lattice (which every row re-reads 18-27 times) from the L2.
+    __shared__ long s_src[2][64];
+    __shared__ int s_off[2][64];
     const long rows = (long)B * Zr * H * W;
     const int per_row = taps.n * CV;
     const int t0 = (int)threadIdx.x / CV, v0 = (int)threadIdx.x % CV;
     const int dt = 256 / CV, dv = 256 % CV;
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        long r = row;
-        const int x = (int)(r % W);
-        r /= W;
-        const int y = (int)(r % H);
-        r /= H;
-        const int z = (int)(r % Zr);
-        const int b = (int)(r / Zr);
+    int par = 0;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+        if ((int)threadIdx.x < taps.n) {
+            long r = row;
+            const int x = (int)(r % W);
+            r /= W;
+            const int y = (int)(r % H);
+            r /= H;
+            const int z = (int)(r % Zr);
+            const int b = (int)(r / Zr);
+            const int t = threadIdx.x;
+            const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
+            const bool ok = sz >= 0 && sz < Zs && sy >= 0 && sy < H && sx >= 0 && sx < W;
+            const int cz = min(max(sz, 0), Zs - 1), cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
+            const long idx = lattice_index<LAYOUT>(b, cz, cy, cx, B, Zs, H, W) * CV;
+            s_src[par][t] = ok ? idx : ~idx;          // negative: outside (the clamped index is still loaded, then masked)
+            s_off[par][t] = taps.off[t];
+        }
+        __syncthreads();
         uint4* dst = col + row * stride_v;
         int t = t0, v = v0;
         // unconditional (clamped, then masked) loads, four vectors per thread in flight
 #pragma unroll 4
         for (int i = threadIdx.x; i < per_row; i += 256) {
-            const int sz = z + taps.dz[t], sy = y + taps.dy[t], sx = x + taps.dx[t];
-            const bool ok = sz >= 0 && sz < Zs && sy >= 0 && sy < H && sx >= 0 && sx < W;
-            const int cz = min(max(sz, 0), Zs - 1), cy = min(max(sy, 0), H - 1), cx = min(max(sx, 0), W - 1);
-            const uint4 val = src[lattice_index<LAYOUT>(b, cz, cy, cx, B, Zs, H, W) * CV + v];
-            dst[taps.off[t] + v] = ok ? val : make_uint4(0u, 0u, 0u, 0u);
+            const long sidx = s_src[par][t];
+            const bool ok = sidx >= 0;
+            const uint4 val = src[(ok ? sidx : ~sidx) + v];
+            const uint4 outv = ok ? val : make_uint4(0u, 0u, 0u, 0u);
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4_t{outv.x, outv.y, outv.z, outv.w}, reinterpret_cast<u32x4_t*>(dst + s_off[par][t] + v));
             t += dt;
             v += dv;
             if (v >= CV) {
@@ -126,62 +144,79 @@ template <bool BF16, int LAYOUT>
 __global__ __launch_bounds__(256) void k_lattice_scatter(const uint4* __restrict__ gcol, uint4* __restrict__ gsrc,
                                                          TapListEx taps, long stride_v, int B, int Zr, int Zs, int H,
                                                          int W, int CV) {
-    // one thread = one 16-byte vector of the source gradient, enumerated in STORAGE order
-    const long total = (long)B * Zs * H * W * CV;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int v = (int)(i % CV);
-        int b, z, y, x;
-        lattice_decode<LAYOUT>(i / CV, B, Zs, H, W, b, z, y, x);
-        float acc[BF16 ? 8 : 4];
+    // A workgroup folds G = 256 / CV source-lattice positions at a time (enumerated in STORAGE order): for each of them the
+    // tap-matrix vector index of every tap block (or "outside") is computed once into LDS by G * taps.n threads -- two
+    // tables by parity, one barrier per group -- and a thread then owns one 16-byte vector of one position: taps.n
+    // look-ups, masked loads (six in flight) and fp32 adds.
+    __shared__ long s_idx[2][4][64];
+    const int G = min(256 / CV, 4);
+    const long npos = (long)B * Zs * H * W;
+    const int g = (int)threadIdx.x / CV, v = (int)threadIdx.x % CV;
+    const bool worker = g < G;
+    int par = 0;
+    for (long p0 = (long)blockIdx.x * G; p0 < npos; p0 += (long)gridDim.x * G, par ^= 1) {
+        if ((int)threadIdx.x < G * taps.n) {
+            const int gg = (int)threadIdx.x / taps.n, t = (int)threadIdx.x % taps.n;
+            const long pos = min(p0 + gg, npos - 1);
+            int b, z, y, x;
+            lattice_decode<LAYOUT>(pos, B, Zs, H, W, b, z, y, x);
+            const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
+            const bool ok = oz >= 0 && oz < Zr && oy >= 0 && oy < H && ox >= 0 && ox < W;
+            const int cz = min(max(oz, 0), Zr - 1), cy = min(max(oy, 0), H - 1), cx = min(max(ox, 0), W - 1);
+            const long idx = ((((long)b * Zr + cz) * H + cy) * W + cx) * stride_v + taps.off[t];
+            s_idx[par][gg][t] = ok ? idx : ~idx;
+        }
+        __syncthreads();
+        const long pos = p0 + g;
+        if (worker && pos < npos) {
+            float acc[BF16 ? 8 : 4];
 #pragma unroll
-        for (int j = 0; j < (BF16 ? 8 : 4); ++j) acc[j] = 0.0f;
-        // taps in groups of three with unconditional (clamped, then masked) loads: the three requests are in flight
-        // together instead of one load per loop trip behind a data-dependent `continue`
-        for (int t0 = 0; t0 < taps.n; t0 += 3) {
-            uint4 gv[3];
+            for (int j = 0; j < (BF16 ? 8 : 4); ++j) acc[j] = 0.0f;
+            for (int tb = 0; tb < taps.n; tb += 6) {
+                uint4 gv[6];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int t = min(t0 + u, taps.n - 1);
-                const int oz = z - taps.dz[t], oy = y - taps.dy[t], ox = x - taps.dx[t];
-                const bool ok = t0 + u < taps.n && oz >= 0 && oz < Zr && oy >= 0 && oy < H && ox >= 0 && ox < W;
-                const int cz = min(max(oz, 0), Zr - 1), cy = min(max(oy, 0), H - 1), cx = min(max(ox, 0), W - 1);
-                const uint4 g = gcol[((((long)b * Zr + cz) * H + cy) * W + cx) * stride_v + taps.off[t] + v];
-                gv[u] = ok ? g : make_uint4(0u, 0u, 0u, 0u);
-            }
+                for (int u = 0; u < 6; ++u) {
+                    const int t = min(tb + u, taps.n - 1);
+                    const long sidx = s_idx[par][g][t];
+                    const bool ok = tb + u < taps.n && sidx >= 0;
+                    const uint4 q = gcol[(sidx >= 0 ? sidx : ~sidx) + v];
+                    gv[u] = ok ? q : make_uint4(0u, 0u, 0u, 0u);
+                }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const uint4 g = gv[u];
-                if (BF16) {
-                    const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+                for (int u = 0; u < 6; ++u) {
+                    const uint4 q = gv[u];
+                    if (BF16) {
+                        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[2 * j] += __uint_as_float(w[j] << 16);
-                        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                        for (int j = 0; j < 4; ++j) {
+                            acc[2 * j] += __uint_as_float(w[j] << 16);
+                            acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                        }
+                    } else {
+                        acc[0] += __uint_as_float(q.x);
+                        acc[1] += __uint_as_float(q.y);
+                        acc[2] += __uint_as_float(q.z);
+                        acc[3] += __uint_as_float(q.w);
                     }
-                } else {
-                    acc[0] += __uint_as_float(g.x);
-                    acc[1] += __uint_as_float(g.y);
-                    acc[2] += __uint_as_float(g.z);
-                    acc[3] += __uint_as_float(g.w);
                 }
             }
+            uint4 o;
+            if (BF16) {
+                auto rne = [](float f) -> uint32_t {
+                    uint32_t u = __float_as_uint(f);
+                    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+                    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+                };
+                o.x = rne(acc[0]) | (rne(acc[1]) << 16);
+                o.y = rne(acc[2]) | (rne(acc[3]) << 16);
+                o.z = rne(acc[4]) | (rne(acc[5]) << 16);
+                o.w = rne(acc[6]) | (rne(acc[7]) << 16);
+            } else {
+                o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                               __float_as_uint(acc[3]));
+            }
+            gsrc[pos * CV + v] = o;
         }
-        uint4 o;
-        if (BF16) {
-            auto rne = [](float f) -> uint32_t {
-                uint32_t u = __float_as_uint(f);
-                if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-                return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-            };
-            o.x = rne(acc[0]) | (rne(acc[1]) << 16);
-            o.y = rne(acc[2]) | (rne(acc[3]) << 16);
-            o.z = rne(acc[4]) | (rne(acc[5]) << 16);
-            o.w = rne(acc[6]) | (rne(acc[7]) << 16);
-        } else {
-            o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
-                           __float_as_uint(acc[3]));
-        }
-        gsrc[i] = o;
     }
 }
 
@@ -394,9 +429,13 @@ extern "C" int ver_lattice_scatter(const void* gcol, void* gsrc, const int* taps
     const int CV = C * esize / 16;
     const long total = (long)B * Zs * H * W * CV;
     const long stride_v = col_stride * esize / 16;
+    VER_REQUIRE(CV <= 256, VER_EUNSUPPORTED, "ver_lattice_scatter: more than 256 16-byte vectors per lattice position");
+    const long sc_groups = ((long)B * Zs * H * W + (256 / CV < 4 ? 256 / CV : 4) - 1) / (256 / CV < 4 ? 256 / CV : 4);
+    const unsigned sc_blocks = (unsigned)(sc_groups < 256L * 32 ? sc_groups : 256L * 32);
+    (void)total;
     hipStream_t st = (hipStream_t)stream;
 #define VER_SCATTER(BF, L)                                                                                         \
-    hipLaunchKernelGGL((k_lattice_scatter<BF, L>), dim3(lattice_blocks(total)), dim3(256), 0, st, (const uint4*)gcol, \
+    hipLaunchKernelGGL((k_lattice_scatter<BF, L>), dim3(sc_blocks), dim3(256), 0, st, (const uint4*)gcol, \
                        (uint4*)gsrc, tl, stride_v, B, Zr, Zs, H, W, CV)
     if (dtype == VER_BF16) {
         if (layout == 0) VER_SCATTER(true, 0);

@@ -122,23 +122,82 @@ __global__ __launch_bounds__(256) void k_lattice_transpose(T* __restrict__ cl, T
 // channel-first side a channel's R W positions are ONE contiguous run (R = 10 rows of 60: 1 200 bytes), so the 8-byte
 // stores of a wave fill whole cache lines -- with single rows (120-byte runs, one per channel and workgroup) the
 // transposes of the 1.06-GB lattice of the vocc.py step took 3.6 ms / 2.1 ms; element-wise (2 bytes per lane) 4.0 / 3.6 ms.
-// LDS accesses stay per element (odd row pitch).  grid = (B * Z * H / R, C / CH).
+// Round 3: 16-bit tiles hold dwords of two neighbouring positions (v_perm_b32 instead of 2-byte LDS accesses) and the
+// grid runs the channel blocks of one spatial tile next to each other: 2.73 -> 1.90 ms to channel-first, 2.25 -> 1.79 back.
+// grid = B * Z * H / R spatial tiles x C / CH channel blocks, channel block fastest.
 template <typename T, int LAYOUT, bool TO_CF, int CH>
 __global__ __launch_bounds__(256) void k_lattice_transpose_v(T* __restrict__ cl, T* __restrict__ cf, long cf_stride,
                                                              int B, int Z, int H, int W, int C, int R) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int VC = 16 / sizeof(T), VX = 8 / sizeof(T);
-    T* tile = reinterpret_cast<T*>(smem);                  // [CH][R * W + 1]
-    const int P = R * W, wp = P + 1;
-    int r = blockIdx.x;
+    const int P = R * W;
+    // channel block fastest: the workgroups that read (write) the pieces of one 128-byte line of a position run next to
+    // each other -- with the spatial tile fastest every line of the lattice was fetched from HBM once per piece
+    const int ncb = (C + CH - 1) / CH;
+    int r = (int)(blockIdx.x / ncb);
     const int hr = H / R;
     const int y0 = (r % hr) * R;
     r /= hr;
     const int z = r % Z;
     const int b = r / Z;
-    const int c0 = blockIdx.y * CH;
+    const int c0 = (int)(blockIdx.x % ncb) * CH;
     const int nc = (C - c0) < CH ? (C - c0) : CH;          // a multiple of VC
     const int ncv = nc / VC, npv = P / VX;
+    if constexpr (sizeof(T) == 2) {
+        // 16-bit elements, W even: the tile holds DWORDS of two neighbouring positions of one channel, [CH][P / 2 (+ pad)].
+        // A thread on the channels-last side handles a PAIR of positions: two 16-byte vectors, eight v_perm_b32, eight
+        // 4-byte LDS accesses; the channel-first side moves 8 bytes (four positions) per LDS access.  (Element-wise --
+        // one 2-byte LDS access per element, two lanes per bank word -- the 1.06-GB lattice of the vocc.py step took
+        // 2.7 ms / 2.25 ms per direction, 0.8-0.9 TB/s.)
+        unsigned* tile32 = reinterpret_cast<unsigned*>(smem);
+        const int P2 = P >> 1, wp32 = (P2 + 2) & ~1;             // even row pitch: 8-byte aligned rows
+        if (TO_CF) {
+            for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
+                const int p2 = i / ncv, cv = i - p2 * ncv;
+                const int p = 2 * p2, yy = p / W, x = p - yy * W;
+                const uint4 a = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC);
+                const uint4 q = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x + 1, B, Z, H, W) * C + c0 + cv * VC);
+                const unsigned aw[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.x, q.y, q.z, q.w};
+                unsigned* dst = tile32 + (cv * VC) * wp32 + p2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dst[(2 * k) * wp32] = __builtin_amdgcn_perm(qw[k], aw[k], 0x05040100u);        // channel 2k:   (pos p, pos p + 1)
+                    dst[(2 * k + 1) * wp32] = __builtin_amdgcn_perm(qw[k], aw[k], 0x07060302u);    // channel 2k+1
+                }
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < nc * npv; i += 256) {
+                const int c = i / npv, pv = i - c * npv;
+                const uint2 u = *reinterpret_cast<const uint2*>(tile32 + c * wp32 + 2 * pv);
+                *reinterpret_cast<uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX) = u;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nc * npv; i += 256) {
+                const int c = i / npv, pv = i - c * npv;
+                *reinterpret_cast<uint2*>(tile32 + c * wp32 + 2 * pv) =
+                    *reinterpret_cast<const uint2*>(cf + (long)b * cf_stride + (((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
+                const int p2 = i / ncv, cv = i - p2 * ncv;
+                const int p = 2 * p2, yy = p / W, x = p - yy * W;
+                const unsigned* srcw = tile32 + (cv * VC) * wp32 + p2;
+                unsigned d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = srcw[j * wp32];
+                uint4 a, q;
+                a.x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100u); q.x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302u);
+                a.y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100u); q.y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302u);
+                a.z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100u); q.z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302u);
+                a.w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100u); q.w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302u);
+                *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC) = a;
+                *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x + 1, B, Z, H, W) * C + c0 + cv * VC) = q;
+            }
+        }
+        return;
+    }
+    T* tile = reinterpret_cast<T*>(smem);                  // [CH][R * W + 1]
+    const int wp = P + 1;
     union V16 { uint4 v; T e[VC]; };
     union V8 { uint2 v; T e[VX]; };
     if (TO_CF) {
@@ -228,13 +287,13 @@ extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, l
         // the WRITE side wants long runs: to channel-first 32 channels x R rows (R W contiguous positions per channel),
         // to channels-last 128 channels x one row (256 contiguous bytes per position); measured the other way round
         // each direction loses a third (2.7 vs 3.6 ms to channel-first, 2.1 vs 3.0 ms back)
-        int R = 1;
+        int R = 1;       // (to channels-last with 3 rows of 128 channels: 2.64 ms against 1.79 -- fewer workgroups per CU)
         if (to_channel_first)
             for (int cand = 1; cand <= H; ++cand)
-                if (H % cand == 0 && (size_t)kChV * ((size_t)cand * W + 1) * esize <= 48 * 1024 && cand * W <= 1200) R = cand;
+                if (H % cand == 0 && (size_t)kChV * ((size_t)cand * W + 4) * esize <= 48 * 1024 && cand * W <= 1200) R = cand;
         const int chv = to_channel_first ? kChV : kCh;
-        const size_t ldsv = (size_t)chv * ((size_t)R * W + 1) * esize;
-        const dim3 gridv((unsigned)((long)B * Z * (H / R)), (unsigned)((C + chv - 1) / chv));
+        const size_t ldsv = (size_t)chv * ((size_t)R * W + 4) * esize;     // (+ row padding: 16-bit tiles use an even dword pitch)
+        const dim3 gridv((unsigned)((long)B * Z * (H / R) * ((C + chv - 1) / chv)));
 #define VER_TRV(T, L, CF)                                                                                              \
     hipLaunchKernelGGL((k_lattice_transpose_v<T, L, CF, (CF ? kChV : kCh)>), gridv, dim3(256), ldsv, st,                \
                        (T*)channels_last, (T*)channel_first, cf_stride, B, Z, H, W, C, R)

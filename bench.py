@@ -273,10 +273,12 @@ def main():
         # also with ONE rank (torchrun --nproc-per-node 1): the RCCL communicator, the bf16 compression hook and the
         # bucket views are then built and used on hardware exactly as with N ranks
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import datetime
+        wait = datetime.timedelta(minutes=10)       # a peer that never arrives is an error, not a 30-minute hang
         if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=wait)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=wait)
     distributed = dist.is_available() and dist.is_initialized()
     hip = importlib.import_module('vln-ver_amd.hipops')
     hip.lib()

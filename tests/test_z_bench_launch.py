@@ -1,7 +1,11 @@
 """bench.py as the driver runs it: `--gpus N` from a plain shell must start N ranks (reference:
 tools/dist_train.sh:12-14 -> one process per GPU; apis/mmdet_train.py:71-80 -> DDP), and the distributed leg
 (process group, DDP wrapper, bf16 compression hook, bucket views) must run on hardware for both training workloads
-(BASELINE.json configs[3] and configs[4])."""
+(BASELINE.json configs[3] and configs[4]).
+
+(The file name sorts last on purpose: every test here starts fresh python processes that import torch and initialise HIP; on
+a box that has just been leased the first such start pages the whole image in and can take minutes -- after the other GPU
+tests it takes seconds.)"""
 import json
 import os
 import socket

@@ -66,6 +66,9 @@ def parse():
                     help='viewpoints per GPU and step of the untimed-by-headline config.latency records (SURVEY 8d C4: '
                          'vocc.py runs samples_per_gpu=1); empty string: none')
     ap.add_argument('--latency-steps', type=int, default=10)
+    ap.add_argument('--host-fed-steps', type=int, default=3,
+                    help='steps of the config.host_fed record: the same step with the features handed over in (pinned) HOST '
+                         'memory, as the detector does, the PCIe copy inside the timed region; 0: none')
     return ap.parse_args()
 
 
@@ -405,6 +408,35 @@ def main():
         latency.append(dict(viewpoints_per_gpu_per_step=nb, steps=args.latency_steps, warmup=3,
                             ms_per_step=round(ms, 3), viewpoints_per_s=round(nb * world / ms * 1e3, 2)))
 
+    # config.host_fed: the step as the reference's detector drives it -- the six feature maps of every viewpoint arrive
+    # in HOST memory (detectors/voxelformer.py:285-289) -- with the host -> HBM copy on the step's stream inside the timed
+    # region.  The PCIe-inclusive rate; measured after the headline region, never part of `value`.
+    host_fed = None
+    if train and args.host_fed_steps > 0:
+        host = torch.empty(feats.shape, dtype=feats.dtype, pin_memory=True)
+        host.copy_(feats)
+
+        def fed():
+            feats.copy_(host, non_blocking=True)
+            return step()
+        fed()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.host_fed_steps):
+            fed()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        ms = float(dt) / args.host_fed_steps * 1e3
+        host_fed = dict(steps=args.host_fed_steps, host_bytes_per_step=host.numel() * host.element_size(),
+                        ms_per_step=round(ms, 3), viewpoints_per_s=round(B * world / ms * 1e3, 2))
+        del host
+
     if rank == 0:
         kt = timer.summary()
         hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
@@ -454,7 +486,7 @@ def main():
                                       'occupancy logits stay in the GEMM row order and the targets are permuted to match; '
                                       'on the bf16 path occ_branches[0] is composed with occ_proj every step '
                                       '(DESIGN.md sections 1, 3.3, 6)') if train else 'forward only',
-                       'latency': latency},
+                       'latency': latency, 'host_fed': host_fed},
             'roofline': roof, 'roofline_other_kernels': others,
         }
         if world == 1 and not args.no_cpu_baseline and train and not full:

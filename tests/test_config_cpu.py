@@ -42,6 +42,12 @@ def test_reference_vocc_loads_unchanged_and_matches_shipped_config():
     pkg = importlib.import_module('vln-ver_amd')
     head = pkg.registry.build_head(config.head_cfg(ref['model']))
     assert head.bev_h == 15 and head.num_query == 100
+    # ... and so does the whole `model` dict: type='VoxelFormer' with the image backbone / neck entries it still lists
+    # (kept as data: the reference never runs them on this path, detectors/voxelformer.py:285-289)
+    det = pkg.registry.build_detector(ref['model'])
+    assert type(det).__name__ == 'VoxelFormer' and det.pts_bbox_head.assigner is not None
+    assert [k for k, v in det.unbuilt.items() if v is not None] == [k for k in det.unbuilt if ref['model'].get(k) is not None]
+    assert det.video_test_mode == ref['model'].get('video_test_mode', False)
 
 
 def test_base_merge_and_delete(tmp_path):

@@ -62,6 +62,8 @@ def test_gpus_2_from_a_plain_shell_runs_two_ranks(workload):
     assert line['config']['gradient_allreduce'] == 'gloo'
     assert line['value'] > 0 and line['cpu_baseline'] is None
     assert line['config']['latency'][0]['viewpoints_per_gpu_per_step'] == 1
+    fed = line['config']['host_fed']                                   # PCIe-inclusive record: 2 viewpoints x 6 x 196 x 768 fp32
+    assert fed['host_bytes_per_step'] == 2 * 6 * 196 * 768 * 4 and fed['viewpoints_per_s'] > 0
 
 
 @pytest.mark.gpu

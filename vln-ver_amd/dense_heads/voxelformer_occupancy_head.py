@@ -493,6 +493,46 @@ class VoxelFormerOccupancyHead(BaseModule):
                 losses['d%d.loss_bbox' % lvl] = lb
         return losses
 
+    def occupancy_targets(self, occ_gts, device=None):
+        """The dataset's sparse occupancy annotation -> the dense target ``loss`` takes (head:1322-1326, :1404-1408):
+        ``occ_gts[b]`` is an ``[n, 2]`` array of (flat voxel index, class) pairs of the occupied voxels (or the
+        reference's one-element list around it); every other voxel gets ``occupancy_classes`` = empty.
+        -> int64 [bs, voxel_num]."""
+        device = device if device is not None else self.code_weights.device
+        gt = torch.full((len(occ_gts), self.voxel_num), self.occupancy_classes, dtype=torch.long, device=device)
+        for b, pairs in enumerate(occ_gts):
+            if isinstance(pairs, (list, tuple)):                   # occ_gts[bs][queue_index]
+                pairs = pairs[0]
+            pairs = torch.as_tensor(pairs).long().to(device)
+            if pairs.numel():
+                gt[b, pairs[:, 0]] = pairs[:, 1]
+        return gt
+
+    def loss_only_occupancy(self, gt_bboxes_list, gt_labels_list, gt_occupancy, preds_dicts):
+        """``only_occ`` detectors (head:1387-1447): the occupancy focal loss alone, plus the zero ``loss_flow``."""
+        lo = self.occupancy_loss(preds_dicts['occupancy_preds'], gt_occupancy)
+        return dict(loss_occupancy=lo, loss_flow=torch.zeros_like(lo))
+
+    def loss_only_detection(self, gt_bboxes_list, gt_labels_list, preds_dicts):
+        """``only_det`` detectors (head:1619-1700): classification and box terms of every decoder layer, no
+        occupancy term."""
+        all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
+        dev = all_box.device
+        if not isinstance(gt_bboxes_list, (list, tuple)):
+            gt_bboxes_list, gt_labels_list = [gt_bboxes_list], [gt_labels_list]
+        boxes = [self._boxes_as_tensor(b, dev) for b in gt_bboxes_list]
+        labels = [torch.as_tensor(x, device=dev).long() for x in gt_labels_list]
+        nl = len(all_cls)
+        losses = {}
+        for lvl in range(nl):
+            lc, lb, _ = self.loss_single(all_cls[lvl], all_box[lvl], None, boxes, labels)
+            if lvl == nl - 1:
+                losses.update(loss_cls=lc, loss_bbox=lb)
+            else:
+                losses['d%d.loss_cls' % lvl] = lc
+                losses['d%d.loss_bbox' % lvl] = lb
+        return losses
+
     # ------------------------------------------------------------------ room-layout branch (add_layout=True)
     def _layout_targets_single(self, layout_pred, gt_layout):
         """Layout half of ``_get_target_layout_single`` (head:760-841): Hungarian matching on the L1 cost of the

@@ -121,6 +121,11 @@ except Exception:
     TRANSFORMER = Registry('Transformer')
     HEADS = Registry('head')
 
+try:                                                            # pragma: no cover
+    from mmdet.models.builder import DETECTORS
+except Exception:
+    DETECTORS = Registry('detector')
+
 
 try:                                                            # pragma: no cover
     from mmdet.models.builder import LOSSES
@@ -167,3 +172,12 @@ def build_transformer(cfg, default_args=None):
 
 def build_head(cfg, default_args=None):
     return build_from_cfg(cfg, HEADS, default_args)
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None):
+    """mmdet3d.models.build_model / build_detector: ``cfg['type']`` names a registered detector; ``train_cfg`` /
+    ``test_cfg`` may be given here or inside ``cfg`` (not both)."""
+    if train_cfg is not None or test_cfg is not None:
+        assert cfg.get('train_cfg') is None or train_cfg is None, 'train_cfg specified in both outer field and model field'
+        assert cfg.get('test_cfg') is None or test_cfg is None, 'test_cfg specified in both outer field and model field'
+    return build_from_cfg(cfg, DETECTORS, dict(train_cfg=train_cfg, test_cfg=test_cfg))

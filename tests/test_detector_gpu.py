@@ -62,3 +62,32 @@ def test_detector_train_and_test_calls_on_gpu(tmp_path):
     pairs = occ_results['occupancy_preds']
     assert pairs.dim() == 2 and pairs.shape[1] == 2 and int(pairs[:, 0].max()) < 2 * 504000
     assert int(pairs[:, 1].max()) < 16 and occ_results['flow_preds'] is None
+
+
+def test_export_run_writes_one_volume_per_viewpoint(tmp_path):
+    """projects/configs/verformer/get_occ.py: the head is built with ``getbev=<store>`` and a TEST call over the
+    viewpoints leaves their volumes in the store (float64, raw (C, Z, H, W) view of the encoder output, key =
+    sample_idx) -- what the VLN agent reads."""
+    pkg()
+    syn, reg, vio = pkg('synthetic'), pkg('registry'), pkg('volume_io')
+    out_dir = str(tmp_path / 'volumes')
+    det = reg.build_detector(dict(type='VoxelFormer', pts_bbox_head=dict(cases.vocc_head_cfg(), getbev=out_dir))).eval()
+    syn.load_seeded(det.pts_bbox_head, 7)
+    det.to(DEV)
+    names = ['scanA_vp0', 'scanA_vp1']
+    feats = syn.vit_features(2, seed=0)
+    store = _store(tmp_path, feats, names)
+    dense = np.full((2, 504000), 16)
+    metas = _metas(tmp_path, store, names, [cases.detection_gt()] * 2, [_sparse(d) for d in dense])
+    seen = {}
+    hook = det.pts_bbox_head.register_forward_hook(lambda m, a, out: seen.update(outs=out))
+    with torch.no_grad():
+        det(return_loss=False, img_metas=metas)
+    hook.remove()
+    gh = golden('head_vocc')
+    for b, name in enumerate(names):
+        vol = vio.read_volume(out_dir, name)
+        assert vol.dtype == np.float64 and vol.shape == (768, 4, 15, 15)
+        emb = seen['outs']['bev_embed'][:, b].double().cpu().numpy()              # [Nq, C] of this viewpoint
+        assert np.array_equal(vol.reshape(-1), emb.reshape(-1))                     # raw reinterpretation, head:634
+        assert np.abs(emb[::7] - gh['c3_b%d_bev' % b]).max() < 1e-4                 # and it is the reference's volume

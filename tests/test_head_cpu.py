@@ -179,6 +179,15 @@ def test_occupancy_postprocessing_and_metrics_match_reference(tmp_path):
     back = vio.read_volume(str(tmp_path / 'vols'), 'scanA_vp0')
     assert back.dtype == np.float64 and back.shape == (768, 4, 15, 15) and np.array_equal(back, vol)
     assert back[1, 0, 0, 0] == 900.0 and back[0, 0, 0, 1] == 1.0       # flat[c*900 + k*225 + j*15 + i]
+    # getbev=<path>: the forward itself appends the volumes of its viewpoints, keyed by sample_idx (head:627-638)
+    h.getbev = str(tmp_path / 'dump')
+    emb2 = torch.stack([emb, emb.flip(0)])
+    h._dump_volumes(emb2, [dict(sample_idx='scanA_vp1'), dict(sample_idx='scanA_vp2')])
+    assert np.array_equal(vio.read_volume(h.getbev, 'scanA_vp1'), vol)
+    assert vio.read_volume(h.getbev, 'scanA_vp2')[0, 0, 0, 0] == float(emb[-1, 0])
+    with pytest.raises(ValueError, match='sample_idx per viewpoint'):
+        h._dump_volumes(emb2, None)
+    h.getbev = None
     # feature store: CLS token dropped
     os_dir = tmp_path / 'feats'
     os_dir.mkdir()

@@ -68,6 +68,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         self.layout_coder = build_bbox_coder(dict(type='LayoutCoder', post_center_range=[-50, -50, -5.0, 50, 50, 5.0],
                                                   pc_range=self.layout_range, max_num=10, num_classes=1))
         self.getbev = getbev
+        self._volume_writer = None
         self.with_box_refine, self.as_two_stage = with_box_refine, as_two_stage
         if as_two_stage:
             raise NotImplementedError('as_two_stage=True is not used by vocc.py (:98)')
@@ -331,6 +332,7 @@ class VoxelFormerOccupancyHead(BaseModule):
                 mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
             if only_bev:
                 return voxel_embed
+            self._dump_volumes(voxel_embed, img_metas)
             return dict(bev_embed=voxel_embed, all_cls_scores=None, all_bbox_preds=None,
                         all_layout_preds=None, occupancy_preds=self._only_occ(voxel_embed),
                         flow_preds=None, enc_cls_scores=None, enc_bbox_preds=None,
@@ -374,6 +376,7 @@ class VoxelFormerOccupancyHead(BaseModule):
                 layouts.append(torch.cat([lxy[..., 0:1] * (lr[3] - lr[0]) + lr[0],
                                           lxy[..., 1:2] * (lr[4] - lr[1]) + lr[1], lay[..., 2:4],
                                           lz * (lr[5] - lr[2]) + lr[2], lay[..., 5:]], -1))
+        self._dump_volumes(bev_embed.permute(1, 0, 2), img_metas)
         return dict(bev_embed=bev_embed, all_cls_scores=torch.stack(classes),
                     all_bbox_preds=torch.stack(coords),
                     all_layout_preds=torch.stack(layouts) if self.add_layout else None,
@@ -718,6 +721,21 @@ class VoxelFormerOccupancyHead(BaseModule):
         occ_results['occupancy_preds'] = torch.stack([occ_index, occ_class[occ_index]], dim=-1)
         occ_results['flow_preds'] = None
         return occ_results
+
+    def _dump_volumes(self, voxel_embed, img_metas):
+        """``getbev=<path>`` (head:627-638, the export run of projects/configs/verformer/get_occ.py): every forward
+        appends the encoder output of its viewpoints to the volume store under ``img_metas[b]['sample_idx']`` -- float64,
+        gzip, the raw ``(C, Z, H, W)`` view of the query-major ``[Nq, C]`` buffer.  The reference writes
+        ``img_metas[0]`` only (bs = 1); a batched call writes one volume per sample.  voxel_embed: [bs, Nq, C]."""
+        if self.getbev is None:
+            return
+        if not img_metas or len(img_metas) != voxel_embed.shape[0]:
+            raise ValueError('getbev needs one img_meta with a sample_idx per viewpoint to name the volumes')
+        if self._volume_writer is None:
+            from ..volume_io import VolumeWriter
+            self._volume_writer = VolumeWriter(self.getbev)
+        for b, meta in enumerate(img_metas):
+            self.export_volume(self._volume_writer, meta['sample_idx'], voxel_embed[b])
 
     def export_volume(self, writer, key, voxel_embed_sample):
         """``getbev`` dump of head:627-638 for one sample ([Nq,C] encoder output)."""

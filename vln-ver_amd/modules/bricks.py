@@ -173,6 +173,20 @@ class TransformerLayerSequence(BaseModule):
         self.pre_norm = self.layers[0].pre_norm
 
 
+_CONST_TENSORS = {}
+
+
+def const_tensor(values, device, dtype=torch.long):
+    """A small constant tensor (``spatial_shapes``, ``level_start_index`` ...) on ``device``, created once per
+    (values, dtype, device): the reference builds these from Python lists on every forward -- a pageable host -> device
+    copy each time, which serialises with the stream and is not allowed while a HIP graph is being captured."""
+    key = (repr(values), dtype, str(device))
+    t = _CONST_TENSORS.get(key)
+    if t is None:
+        t = _CONST_TENSORS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return t
+
+
 def xavier_init(module, gain=1, bias=0, distribution='normal'):
     if module is None:
         return

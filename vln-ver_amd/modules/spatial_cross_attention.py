@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from .. import hipops
 from ..registry import ATTENTION, build_attention
-from .bricks import BaseModule, PendingResidual, constant_init, lowp_view, xavier_init
+from .bricks import BaseModule, PendingResidual, const_tensor, constant_init, lowp_view, xavier_init
 
 
 @ATTENTION.register_module(force=True)
@@ -168,7 +168,7 @@ class MSDeformableAttention3D(BaseModule):
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
         if not isinstance(spatial_shapes, torch.Tensor):
-            spatial_shapes = torch.as_tensor(spatial_shapes, dtype=torch.long, device=query.device)
+            spatial_shapes = const_tensor([list(map(int, r)) for r in spatial_shapes], query.device)
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)

@@ -16,7 +16,7 @@ import torch
 from .. import hipops
 from ..camera_store import CameraStore
 from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
-from .bricks import FFN, PendingResidual, TransformerLayerSequence, residual_layer_norm
+from .bricks import FFN, PendingResidual, TransformerLayerSequence, const_tensor, residual_layer_norm
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .spatial_cross_attention import SpatialCrossAttention
 
@@ -150,8 +150,8 @@ class VoxelFormerLayer(MyCustomBaseTransformerLayer):
                     query, prev_bev, prev_bev, identity if self.pre_norm else None,
                     query_pos=bev_pos, key_pos=bev_pos, attn_mask=attn_masks[attn_index],
                     key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=torch.tensor([[bev_h, bev_w]], device=query.device),
-                    level_start_index=torch.tensor([0], device=query.device), **kwargs)
+                    spatial_shapes=const_tensor([[bev_h, bev_w]], query.device),
+                    level_start_index=const_tensor([0], query.device), **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'norm':

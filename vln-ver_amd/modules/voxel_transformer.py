@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import TRANSFORMER, build_transformer_layer_sequence
-from .bricks import BaseModule, xavier_init
+from .bricks import BaseModule, const_tensor, xavier_init
 from .spatial_cross_attention import MSDeformableAttention3D
 
 
@@ -90,7 +90,7 @@ class VoxelPerceptionTransformer(BaseModule):
         else:
             feat = feat + embed[None, None, None, :]
         feat = feat.contiguous()
-        spatial_shapes = torch.as_tensor([[map_h, map_h]], dtype=torch.long, device=feat.device)
+        spatial_shapes = const_tensor([[map_h, map_h]], feat.device)
         level_start_index = spatial_shapes.new_zeros((1,))
         feat_flatten = feat.permute(1, 2, 0, 3)                        # view: [Ncam,Nk,bs,C]
         return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_z=bev_z, bev_h=bev_h,
@@ -124,6 +124,6 @@ class VoxelPerceptionTransformer(BaseModule):
         inter_states, inter_references = self.decoder(
             query=query, key=None, value=voxel_embed, query_pos=query_pos,
             reference_points=reference_points, reg_branches=reg_branches, cls_branches=cls_branches,
-            spatial_shapes=torch.tensor([[bev_z, bev_h, bev_w]], device=query.device),
-            level_start_index=torch.tensor([0], device=query.device), **kwargs)
+            spatial_shapes=const_tensor([[bev_z, bev_h, bev_w]], query.device),
+            level_start_index=const_tensor([0], query.device), **kwargs)
         return voxel_embed, inter_states, init_reference_out, inter_references

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 R=gpurun_out/r03; mkdir -p $R; rm -rf $R/mfma
-timeout 1200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/mfma -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= > $R/mfma.json 2> $R/mfma.err; echo "pmc $?"
+timeout 1200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/mfma -o pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= --host-fed-steps 0 > $R/mfma.json 2> $R/mfma.err; echo "pmc $?"
 python - <<'PY'
 import sqlite3, glob, collections
 db = sqlite3.connect(glob.glob('gpurun_out/r03/mfma/*results.db')[0]); cur = db.cursor()

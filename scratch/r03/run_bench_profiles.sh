@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 R=gpurun_out/r03; mkdir -p $R
-CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --latency-batches="
+CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= --host-fed-steps 0"
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/trace -o trace -- python3 $CMD > $R/trace_bench.json 2> $R/trace.err; echo "trace $?"
 python scratch/prof_summary.py kernels $R/trace/trace_results.db $R/r03_bench_kernel_stats.csv; rm -rf $R/trace
 rm -f $R/r03_bench_pmc_fetch_write.csv

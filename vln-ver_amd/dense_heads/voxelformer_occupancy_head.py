@@ -31,6 +31,16 @@ from .row_linear import row_linear
 from .upsample import full_volume, is_reference_geometry, upsample_lattice
 
 
+def _mean_over_ranks(value, like):
+    """``reduce_mean(like.new_tensor([value]))`` of the reference's loss normalisers (head:954, :964) as a Python float.
+    Without a process group the mean over ranks is the value itself: no tensor is built, nothing is copied to the device
+    and read back (two stream synchronisations per decoder layer otherwise)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    return float(reduce_mean(like.new_tensor([float(value)])))
+
+
 def bias_init_with_prob(prior_prob):
     return float(-math.log((1 - prior_prob) / prior_prob))
 
@@ -447,10 +457,10 @@ class VoxelFormerOccupancyHead(BaseModule):
         cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
         cls_avg_factor = num_total_pos * 1.0 + num_total_neg * self.bg_cls_weight
         if self.sync_cls_avg_factor:
-            cls_avg_factor = float(reduce_mean(cls_scores.new_tensor([cls_avg_factor])))
+            cls_avg_factor = _mean_over_ranks(cls_avg_factor, cls_scores)
         cls_avg_factor = max(cls_avg_factor, 1)
         loss_cls = self.loss_cls(cls_scores, labels, label_weights, avg_factor=cls_avg_factor)
-        num_total_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([num_total_pos])), min=1).item()
+        num_total_pos = max(_mean_over_ranks(num_total_pos, loss_cls), 1.0)
         bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
         normalized = normalize_bbox(bbox_targets, self.pc_range)
         isnotnan = torch.isfinite(normalized).all(dim=-1)
@@ -563,7 +573,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         layout_targets = torch.cat([o[0] for o in out], 0)
         layout_weights = torch.cat([o[1] for o in out], 0)
         num_layout_pos = sum(o[2] for o in out)
-        num_layout_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([float(num_layout_pos)])), min=1).item()
+        num_layout_pos = max(_mean_over_ranks(num_layout_pos, loss_cls), 1.0)
         layout_preds = layout_preds.reshape(-1, layout_preds.size(-1))
         normalized = normalize_bbox(layout_targets, self.layout_range)
         ok = torch.isfinite(normalized).all(dim=-1)
@@ -687,20 +697,16 @@ class VoxelFormerOccupancyHead(BaseModule):
         """The detection terms of ``loss_single`` (head:903-976) from precomputed targets; rows the
         reference drops by boolean indexing (non-finite normalised targets) get weight 0 instead, so
         nothing here synchronises with the host."""
-        import torch.distributed as dist
         cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
         num_total_neg = pos_mask.numel() - num_total_pos
         cls_avg_factor = num_total_pos * 1.0 + num_total_neg * self.bg_cls_weight
         if self.sync_cls_avg_factor:
-            cls_avg_factor = float(reduce_mean(cls_scores.new_tensor([cls_avg_factor])))
+            cls_avg_factor = _mean_over_ranks(cls_avg_factor, cls_scores)
         cls_avg_factor = max(cls_avg_factor, 1)
         labels = labels.reshape(-1)
         loss_cls = self.loss_cls(cls_scores, labels, labels.new_ones(labels.shape, dtype=cls_scores.dtype),
                                  avg_factor=cls_avg_factor)
-        if dist.is_available() and dist.is_initialized():
-            num_total_pos = torch.clamp(reduce_mean(loss_cls.new_tensor([float(num_total_pos)])), min=1).item()
-        else:
-            num_total_pos = max(float(num_total_pos), 1.0)
+        num_total_pos = max(_mean_over_ranks(num_total_pos, loss_cls), 1.0)
         bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
         pos = pos_mask.reshape(-1)
         normalized = normalize_bbox(bbox_targets.reshape(-1, bbox_targets.size(-1)), self.pc_range)

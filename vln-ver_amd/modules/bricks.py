@@ -184,7 +184,21 @@ def const_tensor(values, device, dtype=torch.long):
     t = _CONST_TENSORS.get(key)
     if t is None:
         t = _CONST_TENSORS[key] = torch.tensor(values, dtype=dtype, device=device)
+        _CONST_VALUES[id(t)] = (t, values)
     return t
+
+
+_CONST_VALUES = {}
+
+
+def host_values(t):
+    """``t.tolist()`` without the device -> host round trip when ``t`` is one of the cached constants above (the modules
+    below the transformer read ``spatial_shapes`` back on the host, as the reference does with ``.tolist()`` / ``int()``:
+    one stream synchronisation per attention layer)."""
+    hit = _CONST_VALUES.get(id(t))
+    if hit is not None and hit[0] is t:
+        return hit[1]
+    return t.tolist()
 
 
 def xavier_init(module, gain=1, bias=0, distribution='normal'):

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, USING_MMCV
-from .bricks import BaseModule, TransformerLayerSequence, constant_init, xavier_init
+from .bricks import BaseModule, TransformerLayerSequence, const_tensor, constant_init, host_values, xavier_init
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 
 
@@ -106,7 +106,7 @@ class VoxelCustomMSDeformableAttention(BaseModule):
             value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
         bs, num_value, _ = value.shape
-        shapes = [[int(v) for v in row] for row in spatial_shapes.tolist()]
+        shapes = [[int(v) for v in row] for row in host_values(spatial_shapes)]
         assert sum(d * h * w for d, h, w in shapes) == num_value
         value = self.value_proj(value)
         if key_padding_mask is not None:
@@ -120,7 +120,7 @@ class VoxelCustomMSDeformableAttention(BaseModule):
         if reference_points.shape[-1] != 3:
             raise ValueError(f'Last dim of reference_points must be 3, '
                              f'but get {reference_points.shape[-1]} instead.')
-        normalizer = offsets.new_tensor([[s[2], s[1], s[0]] for s in shapes])
+        normalizer = const_tensor([[float(s[2]), float(s[1]), float(s[0])] for s in shapes], offsets.device, offsets.dtype)
         loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
         if not value.is_cuda:
             raise RuntimeError('VoxelCustomMSDeformableAttention runs only on the GPU (HIP kernels); '

@@ -16,7 +16,7 @@ import torch
 from .. import hipops
 from ..camera_store import CameraStore
 from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
-from .bricks import FFN, PendingResidual, TransformerLayerSequence, const_tensor, residual_layer_norm
+from .bricks import FFN, PendingResidual, TransformerLayerSequence, const_tensor, host_values, residual_layer_norm
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .spatial_cross_attention import SpatialCrossAttention
 
@@ -93,7 +93,7 @@ class VoxelFormerEncoder(TransformerLayerSequence):
             hit = self.hit_table(bev_z, bev_h, bev_w, bs, bev_query.device, **kwargs)
         map_hw = kwargs.pop('map_hw', None)
         if map_hw is None:
-            hw = spatial_shapes.reshape(-1, 2)[0].tolist()
+            hw = host_values(spatial_shapes)[0]
             map_hw = (int(hw[0]), int(hw[1]))
         kwargs.pop('world2pixel', None)
         kwargs.pop('origin', None)

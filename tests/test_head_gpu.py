@@ -356,3 +356,49 @@ def test_gpu_path_fails_loudly_without_the_hip_library(monkeypatch):
             head.occupancy_from_volume(emb)
         with pytest.raises(hip.HipLibraryError):
             head.occupancy_loss(torch.randn(8192, 16, device=DEV), torch.zeros(8192, dtype=torch.long, device=DEV))
+
+
+def test_graphed_head_replays_the_eager_forward_and_backward():
+    """vln-ver_amd/graphs.py: the head's forward and backward recorded once as two HIP graphs and replayed -- same outputs
+    and parameter gradients as the eager calls (fp32, eval mode), on inputs that differ from the ones recorded with; in
+    training mode every replay draws fresh dropout seeds."""
+    syn = pkg('synthetic')
+    graphs = pkg('graphs')
+    cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
+    head = _head(cfg, 7)
+    for k, p in head.named_parameters():
+        if k.startswith(('layout_branches.', 'query_layout_embedding.', 'positional_encoding.')):
+            p.requires_grad_(False)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV)
+    fa, fb = feats[0].unsqueeze(1).contiguous(), feats[1].unsqueeze(1).contiguous()
+    wa, oa, wb, ob = (T(w2p[:1]).to(DEV), T(org[:1]).to(DEV), T(w2p[1:]).to(DEV), T(org[1:]).to(DEV))
+    g = graphs.GraphedHead(head, fa, wa, oa, autocast_dtype=None, occupancy_rows=False)
+    boxes, labels = cases.detection_gt(seed=41, num_gt=4)
+    gt_occ = T(np.random.default_rng(3).integers(0, 17, size=(1, 504000))).to(DEV)
+
+    def grads(outs):
+        for p in head.parameters():
+            p.grad = None
+        sum(head.loss([T(boxes[:, :7]).to(DEV)], [T(labels).to(DEV)], gt_occ, outs).values()).backward()
+        return {k: p.grad.clone() for k, p in head.named_parameters() if p.grad is not None}
+
+    for f, w, o in ((fb, wb, ob), (fa, wa, oa)):                      # first the viewpoint the graphs were NOT recorded with
+        eager = head(f, None, world2pixel=w, origin=o)
+        ge = grads(eager)
+        replay = g(f, w, o)
+        gr = grads(replay)
+        for k in ('all_cls_scores', 'all_bbox_preds', 'occupancy_preds', 'bev_embed'):
+            assert close(replay[k], eager[k].float(), atol=1e-5, rtol=1e-5), k
+        assert sorted(gr) == sorted(ge) and len(gr) >= 290
+        for k in ge:
+            d = float((gr[k] - ge[k]).abs().max())
+            assert d <= 1e-5 + 1e-4 * float(ge[k].abs().max()), (k, d)
+    head.train()
+    gt_ = graphs.GraphedHead(head, fa, wa, oa)                        # bf16 autocast, logits in the GEMMs' row order
+    o1, o2 = gt_(fa, wa, oa), gt_(fa, wa, oa)
+    assert isinstance(o1['occupancy_preds'], tuple) and o1['occupancy_preds'][0].dtype == torch.bfloat16
+    c1 = o1['all_cls_scores'].clone()
+    o2 = gt_(fa, wa, oa)
+    assert float((o2['all_cls_scores'] - c1).abs().max()) > 0         # dropout masks differ between replays
+    assert torch.isfinite(sum(head.loss([T(boxes[:, :7]).to(DEV)], [T(labels).to(DEV)], gt_occ, o2).values()))

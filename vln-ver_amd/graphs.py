@@ -1,0 +1,58 @@
+"""hipGraph replay of the head for small, launch-bound batches.
+
+At the reference's own batch point (vocc.py: ``samples_per_gpu=1``) the full multi-task step is bound by the HOST: ~1 500
+module calls forward and as many autograd nodes backward, 13-16 ms + 23-28 ms of Python / dispatcher time around ~20 ms of
+GPU work (scratch/r03/full_step_host_profile.py).  ``GraphedHead`` records the head's forward and its backward once, for
+one fixed batch shape, as two HIP graphs (``torch.cuda.make_graphed_callables``) and replays them: the Hungarian assignment,
+the loss terms, gradient clipping and the optimizer stay eager between the two.  Everything the graphs contain is what the
+eager path launches -- same kernels, same arithmetic, fresh dropout seeds per replay (they come from the device generator).
+
+Nothing per step may change shape: one ``GraphedHead`` per (batch size, dtype); the cameras and features are copied into
+the graphs' static inputs on every call.  Build it BEFORE wrapping the head in DistributedDataParallel (PyTorch's rule
+for graphed callables); ``bench.py`` times the eager path.
+"""
+import torch
+
+
+class _HeadForward(torch.nn.Module):
+    """Tensor-in / tensor-out view of ``VoxelFormerOccupancyHead.forward`` (graphed callables take and return tensors)."""
+
+    def __init__(self, head, autocast_dtype, occupancy_rows):
+        super().__init__()
+        self.head = head
+        self.autocast_dtype = autocast_dtype
+        self.occupancy_rows = occupancy_rows
+        self.row_plan = None
+
+    def forward(self, feats, world2pixel, origin):
+        with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=self.autocast_dtype is not None,
+                            cache_enabled=False):
+            outs = self.head(feats, None, world2pixel=world2pixel, origin=origin, occupancy_rows=self.occupancy_rows)
+        occ = outs['occupancy_preds']
+        if isinstance(occ, tuple):                       # (logits in GEMM row order, plan, bs): the plan is host data
+            occ, plan, bs = occ
+            self.row_plan = (plan, bs)
+        return outs['all_cls_scores'].float(), outs['all_bbox_preds'].float(), occ, outs['bev_embed']
+
+
+class GraphedHead:
+    """``outs = GraphedHead(head, feats, w2p, org)(feats, w2p, org)``: the dict ``head.loss`` takes, produced by graph replay.
+
+    feats [Ncam, B, Nk, C], world2pixel [B, Ncam, 4, 4], origin [B, 3] on the GPU are the SAMPLE inputs that fix the
+    shapes; ``autocast_dtype=torch.bfloat16`` (default) runs the head under bf16 autocast as ``bench.py`` does, None in
+    fp32.  The head must be in the mode (train / eval) and have the ``requires_grad`` flags it will be used with."""
+
+    def __init__(self, head, feats, world2pixel, origin, autocast_dtype=torch.bfloat16, occupancy_rows=True):
+        if not feats.is_cuda:
+            raise RuntimeError('GraphedHead needs GPU tensors (HIP graphs)')
+        if head.only_occ or head.only_det or head.add_layout:
+            raise NotImplementedError('GraphedHead covers the default multi-task branch of the head')
+        self.module = _HeadForward(head, autocast_dtype, occupancy_rows)
+        self.graphed = torch.cuda.make_graphed_callables(self.module, (feats, world2pixel, origin), allow_unused_input=True)
+
+    def __call__(self, feats, world2pixel, origin):
+        cls, box, occ, bev = self.graphed(feats, world2pixel, origin)
+        if self.module.row_plan is not None:
+            occ = (occ,) + self.module.row_plan
+        return dict(bev_embed=bev, all_cls_scores=cls, all_bbox_preds=box, all_layout_preds=None, occupancy_preds=occ,
+                    flow_preds=None, enc_cls_scores=None, enc_bbox_preds=None, enc_occupancy_preds=None)

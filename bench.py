@@ -66,6 +66,9 @@ def parse():
                     help='viewpoints per GPU and step of the untimed-by-headline config.latency records (SURVEY 8d C4: '
                          'vocc.py runs samples_per_gpu=1); empty string: none')
     ap.add_argument('--latency-steps', type=int, default=10)
+    ap.add_argument('--graph-max-batch', type=int, default=4,
+                    help='config.latency records of the full multi-task workload up to this many viewpoints per step replay '
+                         'the head as hipGraphs (one rank only; 0: always eager)')
     ap.add_argument('--host-fed-steps', type=int, default=3,
                     help='steps of the config.host_fed record: the same step with the features handed over in (pinned) HOST '
                          'memory, as the detector does, the PCIe copy inside the timed region; 0: none')
@@ -319,10 +322,24 @@ def main():
         gt_boxes = [torch.from_numpy(g[0][:, :7]).to(dev) for g in gts]
         gt_labels = [torch.from_numpy(g[1]).to(dev) for g in gts]
 
-    def make_step(nb):
-        """One step over the first `nb` viewpoints of the resident inputs."""
+    def make_step(nb, graph=False):
+        """One step over the first `nb` viewpoints of the resident inputs.  `graph` (full multi-task step on one rank
+        only): the head's forward and backward are replayed as two hipGraphs (vln-ver_amd/graphs.py), everything else
+        -- Hungarian targets, loss terms, clip, AdamW -- runs as in the eager step."""
         f, w, o, g = feats[:, :nb].contiguous(), w2p[:nb], org[:nb], gt[:nb]
         gb, gl = (gt_boxes[:nb], gt_labels[:nb]) if full else (None, None)
+        if graph:
+            graphed = importlib.import_module('vln-ver_amd.graphs').GraphedHead(
+                head, f, w, o, autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None)
+
+            def graph_step():
+                loss = sum(head.loss(gb, gl, g, graphed(f, w, o)).values())
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(params, 300.0)
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                return loss
+            return graph_step
 
         def step():
             if train:
@@ -342,8 +359,7 @@ def main():
         # One un-wrapped probing step: parameters that end it without a gradient are not part of this workload's
         # graph (the reference pays find_unused_parameters=True for them, apis/mmdet_train.py:73); freeze them so
         # that DDP reduces -- and AdamW updates -- exactly what the step trains.
-        loss = model(feats[:, :2], w2p[:2], org[:2], gt[:2], gt_boxes[:2], gt_labels[:2])
-        loss.backward()
+        model(feats[:, :2], w2p[:2], org[:2], gt[:2], gt_boxes[:2], gt_labels[:2]).backward()
         for prm in model.parameters():
             if prm.requires_grad and prm.grad is None:
                 prm.requires_grad_(False)
@@ -382,6 +398,7 @@ def main():
     elapsed = float(tmax)
     assert torch.isfinite(last).all(), 'non-finite loss'
     peak_gib = round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)
+    last = None                                 # (no loss of an eager step may be alive when graphs are captured: graphs.py)
 
     # config.latency: the same step at the reference's own batch points (samples_per_gpu = 1, and 8),
     # measured AFTER the headline region and never part of `value`; every rank runs them (the gradient sum is collective)
@@ -389,7 +406,9 @@ def main():
     for nb in [int(x) for x in args.latency_batches.split(',') if x.strip()]:
         if not train or nb > B:
             continue
-        small = make_step(nb)
+        # the full multi-task step is host bound at these sizes (~1 500 module calls + as many autograd nodes): on one
+        # rank its forward / backward are replayed as hipGraphs; `graphed` in the record says which form was timed
+        small = make_step(nb, graph=full and not distributed and nb <= args.graph_max_batch)
         for _ in range(3):
             small()
         torch.cuda.synchronize()
@@ -406,6 +425,7 @@ def main():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ms = float(dt) / args.latency_steps * 1e3
         latency.append(dict(viewpoints_per_gpu_per_step=nb, steps=args.latency_steps, warmup=3,
+                            graphed=full and not distributed and nb <= args.graph_max_batch,
                             ms_per_step=round(ms, 3), viewpoints_per_s=round(nb * world / ms * 1e3, 2)))
 
     # config.host_fed: the step as the reference's detector drives it -- the six feature maps of every viewpoint arrive

@@ -1,6 +1,6 @@
 """Full multi-task step with the head's forward and backward replayed as two hipGraphs (torch.cuda.make_graphed_callables);
 the Hungarian assignment, the loss terms, clip and AdamW stay eager.  Usage: graphed_full_step.py <B>"""
-import importlib, sys, time, traceback, types
+import importlib, os, sys, time, traceback, types
 import numpy as np, torch
 sys.path.insert(0, '.')
 import bench
@@ -49,9 +49,47 @@ def timeit(fn, n=10):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): last = fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3, float(last.detach())
+if os.environ.get('LIKE_BENCH'):
+    model = bench.FullTrainer(head, 'bf16').to(dev).train()
+    if os.environ.get('NOCACHE'):
+        class T2(torch.nn.Module):
+            def __init__(self, head): super().__init__(); self.head = head
+            def forward(self, feats, w2p, org, gt, gt_boxes, gt_labels):
+                with torch.autocast('cuda', dtype=torch.bfloat16, cache_enabled=False):
+                    outs = self.head(feats, None, world2pixel=w2p, origin=org, occupancy_rows=True)
+                outs = {k: (v.float() if torch.is_tensor(v) and k != 'occupancy_preds' else v) for k, v in outs.items()}
+                return sum(self.head.loss(gt_boxes, gt_labels, gt, outs).values())
+        model = T2(head).to(dev).train()
+    hip = importlib.import_module('vln-ver_amd.hipops')
+    def bstep():
+        loss = model(feats, w2p, org, gt, gb, gl); loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 300.0); opt.step(); opt.zero_grad(set_to_none=True)
+        return loss
+    if os.environ['LIKE_BENCH'] == '3':
+        bstep = make_step(fwd)
+    for _ in range(2): bstep()
+    torch.cuda.synchronize()
+    timer = hip.KernelTimer()
+    if os.environ['LIKE_BENCH'] == '2': hip.KERNEL_TIMER = timer
+    for _ in range(2): last = bstep()
+    torch.cuda.synchronize(); hip.KERNEL_TIMER = None
+    print('bench-like eager steps done', float(last.detach()), len(timer.records), flush=True)
+    if os.environ.get('DEL_LAST'): del last
 ms, l = timeit(make_step(fwd)); print('eager:   B=%d %.1f ms per step (loss %.4f)' % (B, ms, l), flush=True)
+import os
+NB = int(os.environ.get('NB', B))
+if NB != B:      # capture at a smaller batch than the eager steps ran at (what bench.py's latency records do)
+    feats, w2p, org, gt, gb, gl = feats[:, :NB].contiguous(), w2p[:NB], org[:NB], gt[:NB], gb[:NB], gl[:NB]
+    if os.environ.get('EAGER_FIRST'): make_step(fwd)()
 try:
-    graphed = torch.cuda.make_graphed_callables(fwd, (feats, w2p, org), allow_unused_input=True)
+    if os.environ.get('USE_CLASS'):
+        gh = importlib.import_module('vln-ver_amd.graphs').GraphedHead(head, feats, w2p, org)
+        def graphed(f, w, o):
+            outs = gh(f, w, o)
+            fwd.plan = outs['occupancy_preds'][1:]
+            return outs['all_cls_scores'], outs['all_bbox_preds'], outs['occupancy_preds'][0]
+    else:
+        graphed = torch.cuda.make_graphed_callables(fwd, (feats, w2p, org), allow_unused_input=True)
     ms, l = timeit(make_step(graphed)); print('graphed: B=%d %.1f ms per step (loss %.4f)' % (B, ms, l), flush=True)
 except Exception:
     traceback.print_exc(); print('GRAPH FAILED')

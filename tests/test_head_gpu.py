@@ -395,6 +395,11 @@ def test_graphed_head_replays_the_eager_forward_and_backward():
             d = float((gr[k] - ge[k]).abs().max())
             assert d <= 1e-5 + 1e-4 * float(ge[k].abs().max()), (k, d)
     head.train()
+    # a loss of an earlier eager step that is still referenced would crash the capture (graphs.py): refused, loudly
+    kept = sum(head.loss([T(boxes[:, :7]).to(DEV)], [T(labels).to(DEV)], gt_occ, eager).values())
+    with pytest.raises(RuntimeError, match='still alive'):
+        graphs.GraphedHead(head, fa, wa, oa)
+    kept = float(kept)
     gt_ = graphs.GraphedHead(head, fa, wa, oa)                        # bf16 autocast, logits in the GEMMs' row order
     o1, o2 = gt_(fa, wa, oa), gt_(fa, wa, oa)
     assert isinstance(o1['occupancy_preds'], tuple) and o1['occupancy_preds'][0].dtype == torch.bfloat16

@@ -83,3 +83,17 @@ def test_rccl_leg_runs_on_hardware_with_one_rank(workload):
     assert line['n_gpus'] == 1
     assert line['config']['gradient_allreduce'].startswith('RCCL')
     assert line['roofline'] is not None and line['roofline']['launches'] == 2 * 3
+
+
+@pytest.mark.gpu
+def test_plain_one_gpu_run_of_the_full_workload_replays_small_batches_as_graphs():
+    """`python bench.py --workload vocc_full_train` on one GPU, no launcher: the headline is the eager step; the
+    config.latency record at one viewpoint per step is the hipGraph replay of the head (graphed: true), and the line
+    still carries the PCIe-inclusive record."""
+    proc = run_bench(['--workload', 'vocc_full_train'] + SMALL)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    line = json_line(proc)
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    rec = line['config']['latency'][0]
+    assert rec['viewpoints_per_gpu_per_step'] == 1 and rec['graphed'] is True and rec['ms_per_step'] > 0
+    assert line['config']['host_fed']['viewpoints_per_s'] > 0

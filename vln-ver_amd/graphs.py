@@ -9,9 +9,30 @@ eager path launches -- same kernels, same arithmetic, fresh dropout seeds per re
 
 Nothing per step may change shape: one ``GraphedHead`` per (batch size, dtype); the cameras and features are copied into
 the graphs' static inputs on every call.  Build it BEFORE wrapping the head in DistributedDataParallel (PyTorch's rule
-for graphed callables); ``bench.py`` times the eager path.
+for graphed callables).  ``bench.py`` uses it for the ``config.latency`` records of the full multi-task workload on one
+rank (``graphed: true`` in the record); the headline step is always eager.
+
+One rule found the hard way (ROCm 7.2 / PyTorch 2.10): NO loss of an earlier eager step may still be referenced when the
+graphs are captured.  A live scalar with a spent autograd graph behind it (``last = step()`` kept around for logging) makes
+``hipStreamEndCapture`` of the backward graph crash the process -- a segmentation fault, not an exception
+(scratch/r03/graphed_full_step.py reproduces it with LIKE_BENCH=3, and not with DEL_LAST=1).  ``GraphedHead`` therefore
+looks for such tensors first and refuses with an error that says what to drop.
 """
+import gc
+
 import torch
+
+
+def _live_losses():
+    """0-dim tensors that still carry an autograd graph: what a training loop keeps of its previous steps."""
+    found = []
+    for obj in gc.get_objects():
+        try:
+            if isinstance(obj, torch.Tensor) and obj.dim() == 0 and obj.grad_fn is not None:
+                found.append(obj)
+        except Exception:                                  # objects that do not like being inspected
+            continue
+    return found
 
 
 class _HeadForward(torch.nn.Module):
@@ -42,11 +63,21 @@ class GraphedHead:
     shapes; ``autocast_dtype=torch.bfloat16`` (default) runs the head under bf16 autocast as ``bench.py`` does, None in
     fp32.  The head must be in the mode (train / eval) and have the ``requires_grad`` flags it will be used with."""
 
-    def __init__(self, head, feats, world2pixel, origin, autocast_dtype=torch.bfloat16, occupancy_rows=True):
+    def __init__(self, head, feats, world2pixel, origin, autocast_dtype=torch.bfloat16, occupancy_rows=True,
+                 check_live_losses=True):
         if not feats.is_cuda:
             raise RuntimeError('GraphedHead needs GPU tensors (HIP graphs)')
         if head.only_occ or head.only_det or head.add_layout:
             raise NotImplementedError('GraphedHead covers the default multi-task branch of the head')
+        if check_live_losses:
+            gc.collect()
+            n = len(_live_losses())
+            if n:
+                raise RuntimeError(
+                    'GraphedHead: %d scalar tensor(s) with an autograd graph are still alive (losses of earlier eager '
+                    'steps?).  Drop them (`loss = None`, or keep `loss.detach()` / `float(loss)`) before building the '
+                    'graphs: with one alive, ending the capture of the backward graph crashes the process on this '
+                    'ROCm / PyTorch build (vln-ver_amd/graphs.py).' % n)
         self.module = _HeadForward(head, autocast_dtype, occupancy_rows)
         self.graphed = torch.cuda.make_graphed_callables(self.module, (feats, world2pixel, origin), allow_unused_input=True)
 

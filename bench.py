@@ -72,6 +72,11 @@ def parse():
     ap.add_argument('--host-fed-steps', type=int, default=3,
                     help='steps of the config.host_fed record: the same step with the features handed over in (pinned) HOST '
                          'memory, as the detector does, the PCIe copy inside the timed region; 0: none')
+    ap.add_argument('--sub-records', default='full_train,fp32',
+                    help='untimed-by-headline sub-records measured in the same process after the headline (default workload '
+                         'only): full_train = BASELINE configs[4] (vocc_full_train, bf16, 64 viewpoints per step), fp32 = the '
+                         'default workload in fp32 at 8 viewpoints per step; empty string: none')
+    ap.add_argument('--sub-steps', type=int, default=3)
     return ap.parse_args()
 
 
@@ -87,8 +92,7 @@ def spawn_ranks(args):
         port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: the only mode this host driver supports
+    env = dict(os.environ)                                  # (HSA_ENABLE_IPC_MODE_LEGACY=0 was set at the top of main())
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.run(cmd, env=env).returncode
 
@@ -185,24 +189,33 @@ def gather_algorithmic_bytes(hit_counts, B, value_bytes, ncam=6, nk=196, c=768, 
     return fwd, bwd
 
 
+def source_hash(name='ver_sca.hip'):
+    import hashlib
+    with open(os.path.join(ROOT, 'vln-ver_amd', 'csrc', name), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def measured_traffic(kernels, B):
     """HBM bytes per launch of the gather kernels from the committed rocprofv3 PMC passes of THIS command
     (profiles/rNN_bench_pmc_fetch_write.csv: `rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py ...` and
-    the same with WRITE_SIZE, separate runs, scratch/r02/run_bench_profiles.sh).  Units are KiB per dispatch;
+    the same with WRITE_SIZE, separate runs, scratch/r04/run_bench_profiles.sh).  Units are KiB per dispatch;
     FETCH_SIZE is doubled (on gfx950 it reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM;
     the value tiles arrive as 16-byte-per-lane LDS-DMA), WRITE_SIZE is taken as reported (calibrated on
     k_zero_rows, whose byte count is known: profiles/README.md).  Only used when the profile was taken at the
-    same number of viewpoints per launch."""
+    same number of viewpoints per launch AND from the kernel source that is running now: the CSV header carries the
+    sha256 of csrc/ver_sca.hip at profiling time, a different (or missing) hash returns None."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_pmc_fetch_write.csv')))
     if not files:
         return None, None
-    vals, batch = {}, None
+    vals, batch, sha = {}, None, None
     for line in open(files[-1]):
         if line.startswith('# viewpoints_per_launch'):
             batch = int(line.split('=')[1])
-    if batch != B:
+        if line.startswith('# ver_sca_sha256'):
+            sha = line.split('=')[1].strip()
+    if batch != B or sha != source_hash():
         return None, None
     for row in csv.reader(l for l in open(files[-1]) if not l.startswith('#')):
         if len(row) == 4 and any(k in row[0] for k in kernels) and row[1] in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -258,8 +271,84 @@ def cpu_baseline(head, syn, seconds):
                        '%.1f s in all' % (len(times), torch.get_num_threads(), host_threads, time.perf_counter() - t0))
 
 
+def sub_record(base, name, dev, rank, world, distributed):
+    """One untimed-by-headline sub-record of the default line (`config.full_train`, `config.fp32`): another workload /
+    precision built and stepped in the same process after the headline region -- its own head, optimiser and inputs,
+    two priming steps + 1 warm-up, then `--sub-steps` timed steps between barriers, max over ranks.  Never part of `value`."""
+    a = argparse.Namespace(**vars(base))
+    name, _, nb = name.partition(':')           # `name:batch` overrides the viewpoints per step (tests)
+    if name == 'full_train':
+        a.workload, a.dtype, a.batch = 'vocc_full_train', 'bf16', 64
+    elif name == 'fp32':
+        a.workload, a.dtype, a.batch, a.micro = 'vocc_c2f_train', 'fp32', 8, 8
+    else:
+        raise SystemExit('bench.py: unknown sub-record %r' % name)
+    if nb:
+        a.batch = int(nb)
+        a.micro = min(a.micro, a.batch)
+    torch.cuda.reset_peak_memory_stats()
+    pkg, syn, head, n_train = build_model(a, dev)
+    full = a.workload == 'vocc_full_train'
+    B = a.batch
+    model = (FullTrainer(head, a.dtype) if full else LiftTrainer(head, a.micro, a.dtype)).to(dev).train()
+    w2p_np, org_np = syn.camera_batch(B, seed=1 + rank)
+    feats = torch.from_numpy(syn.vit_features(B, seed=100 + rank)).to(dev).permute(1, 0, 2, 3).contiguous()
+    w2p, org = torch.from_numpy(w2p_np).to(dev), torch.from_numpy(org_np).to(dev)
+    gt = torch.from_numpy(np.random.default_rng(7 + rank).integers(0, 17, size=(B, head.voxel_num))).to(dev)
+    extra = ()
+    if full:
+        gts = [syn.detection_gt(seed=40 + rank * 1000 + i, num_gt=3 + i % 5) for i in range(B)]
+        extra = ([torch.from_numpy(g[0][:, :7]).to(dev) for g in gts], [torch.from_numpy(g[1]).to(dev) for g in gts])
+        # parameters the full head's forward never touches (layout branches aside: build_model froze them) -- one probing step
+        model(feats[:, :2], w2p[:2], org[:2], gt[:2], extra[0][:2], extra[1][:2]).backward()
+        for prm in model.parameters():
+            if prm.requires_grad and prm.grad is None:
+                prm.requires_grad_(False)
+            prm.grad = None
+    net = model
+    if distributed:
+        net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=base.backend == 'nccl')
+    params = [prm for prm in model.parameters() if prm.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+
+    def step():
+        loss = net(feats, w2p, org, gt, *extra)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 300.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+    for _ in range(3):                          # two priming steps (allocator, AdamW state) + 1 warm-up
+        last = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(base.sub_steps):
+        last = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    assert torch.isfinite(last).all(), 'non-finite loss in sub-record %s' % name
+    ms = float(dt) / base.sub_steps * 1e3
+    rec = dict(workload=a.workload, dtype=a.dtype, viewpoints_per_gpu_per_step=B, head_micro_batch=(None if full else a.micro),
+               steps=base.sub_steps, warmup=1, ms_per_step=round(ms, 3), viewpoints_per_s=round(B * world / ms * 1e3, 2),
+               trainable_params=sum(prm.numel() for prm in params),
+               peak_hbm_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+    del opt, net, model, head, last
+    torch.cuda.empty_cache()
+    return rec
+
+
 def main():
     args = parse()
+    # dmabuf IPC: the mode this image's host driver supports (task environment notes: without it RCCL / cross-process
+    # tensor sharing fails in hipIpcGetMemHandle).  Set before the first GPU call on EVERY path -- self-spawned ranks
+    # inherit it, ranks started by an external launcher (the driver's torch.distributed.run) get it here.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))             # (nothing above this line touches the GPU)
     under_launcher = 'WORLD_SIZE' in os.environ
@@ -457,6 +546,12 @@ def main():
                         ms_per_step=round(ms, 3), viewpoints_per_s=round(B * world / ms * 1e3, 2))
         del host
 
+    # config.full_train / config.fp32: BASELINE configs[4] and the fp32 form of the headline workload on the driver's record
+    subs = {}
+    if train and not full and args.dtype == 'bf16':
+        for name in [x.strip() for x in args.sub_records.split(',') if x.strip()]:
+            subs[name.partition(':')[0]] = sub_record(args, name, dev, rank, world, distributed)
+
     if rank == 0:
         kt = timer.summary()
         hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
@@ -500,13 +595,15 @@ def main():
                                                else args.backend) if distributed and train else None),
                        'trainable_params': n_train, 'tuned_gemm_table': tuned,
                        'peak_hbm_gib': peak_gib,
-                       'arithmetic': 'bf16 autocast GEMMs / fp32 gather, LayerNorm, loss' if args.dtype == 'bf16'
-                                     else 'fp32',
+                       'arithmetic': ('bf16 autocast GEMMs and lattices; multi-view gather on bf16 value tiles: packed-fp16 point '
+                                      'accumulation (<= 8 terms per voxel, head, corner), fp32 after the corner fold; fp32 '
+                                      'offsets / softmax / LayerNorm statistics / loss') if args.dtype == 'bf16' else 'fp32',
                        'evaluation': ('same loss and gradients as the reference step, evaluated where the data is: '
                                       'occupancy logits stay in the GEMM row order and the targets are permuted to match; '
                                       'on the bf16 path occ_branches[0] is composed with occ_proj every step '
                                       '(DESIGN.md sections 1, 3.3, 6)') if train else 'forward only',
-                       'latency': latency, 'host_fed': host_fed},
+                       'latency': latency, 'host_fed': host_fed,
+                       'full_train': subs.get('full_train'), 'fp32': subs.get('fp32')},
             'roofline': roof, 'roofline_other_kernels': others,
         }
         if world == 1 and not args.no_cpu_baseline and train and not full:

@@ -19,8 +19,10 @@
  *     thread-local description of the last failure;
  *   - dtype: fp32 everywhere (the reference forces fp32 on this op:
  *     multi_scale_deformable_attn_function.py:93 `custom_fwd(cast_inputs=torch.float32)`),
- *     except `value_dtype` where noted (VER_F32 = 0, VER_BF16 = 1: value stored as bf16,
- *     arithmetic still fp32).
+ *     except `value_dtype` where noted (VER_F32 = 0, VER_BF16 = 1: value stored as bf16).
+ *     Arithmetic on VER_BF16 value: fp32 everywhere EXCEPT the forward gather's point
+ *     accumulation, which is packed fp16 over the <= 8 points of a (voxel, head, corner) and
+ *     fp32 after the corner fold -- range and precision contract at `ver_sca_forward`.
  */
 #ifndef VER_OPS_H
 #define VER_OPS_H
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 22
+#define VER_ABI_VERSION 23
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -153,14 +155,33 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  * Supported: one feature level; head_dim in {8,16,32,64,96,128}; points in {4,8}; D | points;
  *   one (camera, head) value tile must fit the 160 KiB LDS: map_h*map_w*head_dim*4 <= 160 KiB
  *   in forward (<= 80 KiB keeps two workgroups per CU), twice that tile in backward.
+ * Arithmetic and numerical contract, by value_dtype:
+ *   VER_F32   fp32 throughout (<= 2e-5 against the fp32 reference formula).
+ *   VER_BF16  with points == 8 and head_dim % 32 == 0 (the vocc.py shape) the staged tile is converted to fp16 in LDS
+ *             and the <= 8 products weight * value of one (voxel, head, corner) are accumulated with packed fp16 FMAs;
+ *             the corner fold result is converted to fp32 once and the camera sum / division are fp32.
+ *             RANGE: the bf16 -> fp16 conversion is exact for |value| in [6.1e-5, 65504]; larger magnitudes SATURATE at
+ *             +-65504 (round toward zero: no inf is produced, NaN stays NaN), smaller ones truncate into the fp16
+ *             subnormals (absolute error < 6e-8); sample weights below ~6e-8 flush to zero.
+ *             PRECISION: ~5e-4 of the partial sums (max |delta| 3.7e-3 at |slots| <= 1.2, 1e-3 relative L2 against
+ *             fp32 accumulation of the same bf16 values; the north star's bf16 bound is 1e-2).
+ *             VER_SCA_FWD_MATH=0 in the environment (read once per process) selects the exact form: bf16 tile
+ *             unpacked per use, fp32 accumulation, <= 2e-5 like VER_F32.  Other shapes always use fp32 arithmetic.
+ * flags: 0, or VER_SCA_ROWS_PREZEROED -- the caller has already zero-filled the rows `zero_list` names
+ *   (`ver_sca_zero_rows(zero_list, zero_cnt, slots, B, Nq, heads*head_dim, side_stream)`, ordered before this call by
+ *   an event): the fill depends on the hit table only, so it can run under the projections that precede the gather
+ *   instead of in front of it.
  */
+#define VER_SCA_ROWS_PREZEROED 1
+int ver_sca_zero_rows(const int32_t* zero_list, const int32_t* zero_cnt, float* slots, int B, int Nq, int row_floats,
+                      void* stream);
 int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
                     const float* uv, const uint8_t* vis, const int32_t* vis_list,
                     const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
                     const int32_t* fwd_list, const int32_t* fwd_cnt,
                     float* slots,
                     int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
-                    int map_h, int map_w, void* stream);
+                    int map_h, int map_w, int flags, void* stream);
 
 /* Gradient of ver_sca_forward.
  *   grad_slots   f32 [B, Nq, heads*head_dim]
@@ -246,13 +267,16 @@ int ver_ln_relu_backward(const void* x, const void* grad_y, const float* gamma, 
  *   logits f32|bf16 [N, C] (C % 8 == 0), target int64 [N] in [0, C] (C = background)
  *   forward : partial[b] = sum of the elementwise loss over the elements workgroup b visited,
  *             b < ver_focal_loss_blocks(N, C); the caller adds the partials (and applies
- *             loss_weight / avg_factor)
+ *             loss_weight / avg_factor).  A target outside [0, C] (F.one_hot raises on it in the
+ *             reference) makes the sum NaN and ORs 1 into *bad_labels (device int32, may be NULL;
+ *             never cleared by the kernel): a caller that cleans NaNs out of its losses, as the
+ *             head does, can still be loud about it without a synchronisation per step
  *   backward: grad[n,c] = scale[0] * d loss[n,c] / d logits[n,c]   (scale: device scalar; grad in
  *             the logits' dtype)
  */
 int ver_focal_loss_blocks(long N, int C);
 int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,
-                           float gamma, float alpha, int dtype, void* stream);
+                           float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
 
@@ -346,6 +370,21 @@ int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* ima
 int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                const float* vectors, void* grad_x, float* param_grads, long N, int width,
                                int classes, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Occupancy post-processing: VoxelFormerOccupancyHead.get_occupancy_prediction, focal-loss branch
+ * (dense_heads/voxelformer_occupancy_head.py:1505-1540): sigmoid, the threshold as an extra last
+ * ("empty") column, arg-max, sparse (voxel index, class) pairs of the occupied voxels.
+ *   logits     f32|bf16 [N, C]  (C % 8 == 0, 16-byte aligned)
+ *   block_work i32 [ver_occ_predict_blocks(N)]   scratch
+ *   pairs      i64 [N, 2] capacity; rows [0, *count) are written: (row index, class), ascending row index
+ *   count      i64 device scalar: number of occupied rows
+ * Semantics of torch.argmax: the first of equal maxima wins (so a class probability EQUAL to the threshold is
+ * occupied), NaN counts as the maximum.  Sigmoid is evaluated in fp32 (1 / (1 + exp(-x))).
+ */
+long ver_occ_predict_blocks(long N);
+int  ver_occ_predict(const void* logits, int dtype, long N, int C, float threshold, int32_t* block_work,
+                     int64_t* pairs, int64_t* count, void* stream);
 
 #ifdef __cplusplus
 }

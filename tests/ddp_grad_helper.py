@@ -1,0 +1,57 @@
+"""Helper of tests/test_z_bench_launch.py::test_two_ranks_allreduce_the_gradients_of_the_real_step.
+
+    python ddp_grad_helper.py single <data_rank> <out.pt>        one process, the data of `data_rank`, gradients saved
+    torchrun --nproc-per-node 2 ddp_grad_helper.py ddp <out.pt>  two gloo ranks on the one GPU, rank 0 saves ITS gradients
+
+Both run ONE step of bench.py's LiftTrainer (the real HIP path: custom autograd Functions, frozen parameters,
+gradient_as_bucket_view) in fp32 with dropout p = 0 at two viewpoints per rank, from the same seeded weights."""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1]
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    rank, world = 0, 1
+    if mode == 'ddp':
+        dist.init_process_group('gloo')
+        rank, world = dist.get_rank(), dist.get_world_size()
+        data_rank, out = rank, sys.argv[2]
+    else:
+        data_rank, out = int(sys.argv[2]), sys.argv[3]
+    args = argparse.Namespace(config=None, workload='vocc_c2f_train', dtype='fp32')
+    pkg, syn, head, _ = bench.build_model(args, dev)           # torch.manual_seed(2) + init_weights: same weights everywhere
+    for m in head.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model = bench.LiftTrainer(head, 2, 'fp32').to(dev).train()
+    net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=False) if mode == 'ddp' else model
+    B = 2
+    w2p_np, org_np = syn.camera_batch(B, seed=1 + data_rank)
+    feats = torch.from_numpy(syn.vit_features(B, seed=100 + data_rank)).to(dev).permute(1, 0, 2, 3).contiguous()
+    w2p, org = torch.from_numpy(w2p_np).to(dev), torch.from_numpy(org_np).to(dev)
+    gt = torch.from_numpy(np.random.default_rng(7 + data_rank).integers(0, 17, size=(B, head.voxel_num))).to(dev)
+    loss = net(feats, w2p, org, gt)
+    loss.backward()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(dict(loss=float(loss), grads={k: p.grad.detach().float().cpu() for k, p in model.named_parameters()
+                                                 if p.requires_grad and p.grad is not None}), out)
+    if mode == 'ddp':
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

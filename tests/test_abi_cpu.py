@@ -43,8 +43,12 @@ def test_argument_validation_without_gpu():
     rc = lib.ver_msda_forward(None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 64, None)
     assert rc == -1 and b'null' in lib.ver_last_error()
     rc = lib.ver_sca_forward(None, 0, None, None, None, None, None, None, None, None, None, 1, 6, 1, 1,
-                             8, 96, 8, 14, 14, None)
+                             8, 96, 8, 14, 14, 0, None)
     assert rc == -1
+    rc = lib.ver_sca_zero_rows(None, None, None, 2, 900, 768, None)
+    assert rc == -1 and b'null' in lib.ver_last_error()
+    assert lib.ver_sca_zero_rows(None, None, None, 0, 900, 768, None) == 0
+    assert lib.ver_sca_zero_rows(None, None, None, 2, 900, 770, None) == -2
 
 
 def test_argument_validation_of_the_head_entry_points():
@@ -60,7 +64,7 @@ def test_argument_validation_of_the_head_entry_points():
     rc = lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(4), 128, 16, ctypes.c_float(1e-5), 1, None)
     assert rc == -1 and b'null' in lib.ver_last_error()
     assert lib.ver_occ_mlp_forward(None, buf, buf, None, ctypes.c_long(0), 128, 16, ctypes.c_float(1e-5), 1, None) == 0
-    rc = lib.ver_focal_loss_forward(None, None, None, ctypes.c_long(8), 10, ctypes.c_float(2), ctypes.c_float(.25), 0, None)
+    rc = lib.ver_focal_loss_forward(None, None, None, ctypes.c_long(8), 10, ctypes.c_float(2), ctypes.c_float(.25), 0, None, None)
     assert rc == -2 and b'multiple of 8' in lib.ver_last_error()
     assert lib.ver_focal_loss_blocks(ctypes.c_long(0), 16) == 1
     taps = (ctypes.c_int * 3)(0, 0, 0)

@@ -192,6 +192,69 @@ def test_occupancy_loss_in_row_order_equals_voxel_order(autocast):
         assert rel_l2(res['rows'][1][k], g) < (2e-3 if autocast else 1e-5), k
 
 
+def test_head_occupancy_loss_is_loud_about_a_bad_label_on_a_later_step():
+    """``occupancy_loss`` wraps the focal term in ``nan_to_num`` (as the reference does), so the
+    kernel's NaN for an out-of-range label would become a silent zero loss with zero gradients from the second step on
+    (the host-side range check only runs on a module's first fused call).  The kernel's sticky device flag and its
+    asynchronous host mirror keep the failure loud at the head level: the step after the bad one raises."""
+    hip = pkg('hipops')
+    losses = pkg('dense_heads.losses')
+    head = _head(cases.vocc_head_cfg(), 7)
+    gen = torch.Generator(device='cpu').manual_seed(11)
+    logits = torch.randn(1, 8192, 16, generator=gen).to(DEV).requires_grad_(True)
+    good = torch.randint(0, 17, (1, 8192), generator=gen).to(DEV)
+    bad = good.clone()
+    bad[0, 4321] = 23
+    flag = hip.LabelRangeFlag.of(logits.device)
+    flag.reset()
+    try:
+        assert float(head.occupancy_loss(logits, good)) > 0.0               # step 1: first fused call, host check passes
+        silent = head.occupancy_loss(logits, bad)                            # step 2: NaN cleaned to 0 by nan_to_num ...
+        assert float(silent) == 0.0
+        with pytest.raises(RuntimeError, match='outside'):                   # ... but the next step is loud
+            torch.cuda.synchronize()
+            head.occupancy_loss(logits, good)
+        with pytest.raises(RuntimeError, match='outside'):
+            losses.FocalLoss.check_labels()
+    finally:
+        flag.reset()
+
+
+def test_occupancy_postprocessing_on_gpu_is_bit_exact():
+    """SURVEY 8f row 4 on the device path: ``get_occupancy_prediction`` (head:1505-1540) on GPU logits runs
+    ``ver_occ_predict`` and returns the SAME (index, class) pairs as the reference produced on the CPU
+    (tests/golden/post_vocc.npz), bit for bit; bf16 logits, ties, the threshold boundary, NaN and sizes that do not
+    fill a block are held to the reference formulation evaluated by torch on the CPU."""
+    g = golden('post_vocc')
+    h = pkg('registry').build_head(cases.vocc_head_cfg(only_occ=True))
+    logits, _ = cases.occupancy_loss_inputs(seed=33, n=6000)
+    res = h.get_occupancy_prediction(dict(occupancy_preds=T(logits)[None].to(DEV), flow_preds=None))
+    assert res['occupancy_preds'].is_cuda and res['occupancy_preds'].dtype == torch.int64
+    assert np.array_equal(res['occupancy_preds'].cpu().numpy(), g['sparse'])
+    assert res['flow_preds'] is None
+
+    def reference(x, thr=0.25):                       # the reference's statements, on the CPU in fp32
+        p = x.float().sigmoid()
+        p = torch.cat((p, torch.ones_like(p)[:, :1] * thr), dim=-1)
+        cls = p.argmax(dim=-1)
+        idx, = torch.where(cls < x.shape[1])
+        return torch.stack([idx, cls[idx]], dim=-1)
+
+    gen = torch.Generator().manual_seed(5)
+    for n in (1, 255, 1024, 1025, 70001):
+        x = torch.randn(n, 16, generator=gen) * 2 - 1.5
+        x[::7] = x[::7, :1]                            # ties: every class equal -> the first one wins
+        x[3 % n] = float('nan')                        # NaN is the maximum for torch.argmax
+        x[5 % n, 4:] = -30.0
+        for xx in (x, x.bfloat16()):
+            got = h.get_occupancy_prediction(dict(occupancy_preds=xx.to(DEV)))['occupancy_preds'].cpu()
+            assert torch.equal(got, reference(xx)), (n, xx.dtype)
+    empty = h.get_occupancy_prediction(dict(occupancy_preds=torch.full((300, 16), -9.0, device=DEV)))['occupancy_preds']
+    assert empty.shape == (0, 2)
+    none = h.get_occupancy_prediction(dict(occupancy_preds=torch.zeros(0, 16, device=DEV)))['occupancy_preds']
+    assert none.shape == (0, 2)
+
+
 def test_loss_single_on_gpu_matches_reference():
     """BASELINE configs[4], loss side, on the device: the reference head's own ``loss_single`` vectors
     (tests/golden/loss_vocc.npz; head:1251-1384) reproduced by OUR head living on the GPU -- Hungarian matching

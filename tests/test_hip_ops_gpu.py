@@ -266,6 +266,39 @@ def test_sca_gather_bf16_value(heads, hd, P, grid):
     assert rel_l2(gv, gr) < 2e-3
 
 
+def test_sca_gather_bf16_value_range_contract():
+    """include/ver_ops.h, ``ver_sca_forward`` on VER_BF16 value at the vocc.py shape: the tile is converted to fp16 in LDS,
+    so |value| > 65504 SATURATES (round toward zero: no inf, no NaN from finite inputs) and tiny magnitudes truncate
+    toward zero.  With every value at +-1e6 the output is the saturated constant wherever a sample falls inside the map
+    (a convex combination of +-65504), never inf / NaN; values of 1e-6 (fp16 subnormals, grid 6e-8) come out within a few
+    grid steps; and magnitudes up to 6e4 are still exact to fp16 accumulation accuracy."""
+    hip = pkg('hipops')
+    o = oracle()
+    hit, value, offsets, logits, _ = _random_sca_case(29, 2, (4, 15, 15), 8, 96, 8)
+    of, lg = T(offsets).to(DEV), T(logits).to(DEV)
+    mask = hit.mask()[:, :, :, 0].permute(1, 0, 2).cpu()
+
+    def ref_of(v):
+        return oracle_slots(o, v.float().cpu(), T(offsets), T(logits), hit.uv.cpu(), mask, (14, 14))
+
+    big = torch.full(value.shape, 1e6, dtype=torch.bfloat16, device=DEV)
+    big[:, :, ::2] = -1e6
+    out = hip.sca_gather(big, of, lg, hit, 14, 14)
+    assert torch.isfinite(out).all()
+    sat = torch.clamp(big.float(), -65504.0, 65504.0)
+    want = ref_of(sat)
+    assert float((out.cpu() - want).abs().max()) <= 2e-3 * 65504.0          # fp16 accumulation of saturated terms
+    assert float(out.abs().max()) <= 65504.0 * 1.001
+    tiny = torch.full(value.shape, 1e-6, dtype=torch.bfloat16, device=DEV)
+    out = hip.sca_gather(tiny, of, lg, hit, 14, 14)
+    assert float((out.cpu() - ref_of(tiny)).abs().max()) <= 5e-7
+    large = (T(value).to(DEV) * 2.0e4).clamp(-6.0e4, 6.0e4).to(torch.bfloat16)
+    out = hip.sca_gather(large, of, lg, hit, 14, 14)
+    want = ref_of(large)
+    from util import rel_l2
+    assert torch.isfinite(out).all() and rel_l2(out.cpu(), want) < 2e-3
+
+
 def test_sca_backward_grad_value_dtype_contract():
     """C ABI: ver_sca_backward_grad_dtype names the cheapest d(value) dtype (bf16 on the matrix-core path), and
     VER_F32 is accepted for the same problem: both buffers hold the same gradient up to bf16 rounding, and the
@@ -966,24 +999,41 @@ def test_relu_dropout_fused(dtype, p_drop):
 def test_focal_loss_label_range_is_loud_without_a_sync_per_step():
     """A label outside [0, C] raises in F.one_hot (and in the reference).  The fused path: (a) the first call of a
     FocalLoss module checks the range on the host and raises with the range in the message; (b) afterwards no host
-    check runs (no device->host synchronisation inside a training step) and the kernel itself answers a bad label
-    with a NaN loss instead of silently counting the row as background."""
+    check runs (no device->host synchronisation inside a training step): the kernel itself answers a bad label
+    with a NaN loss instead of silently counting the row as background AND raises a sticky device flag, whose
+    asynchronous host mirror makes a later fused call -- or ``FocalLoss.check_labels()`` -- raise."""
     hip = pkg('hipops')
     losses = pkg('dense_heads.losses')
     gen = torch.Generator(device='cpu').manual_seed(3)
     logits = torch.randn(5000, 16, generator=gen).to(DEV)
     good = torch.randint(0, 17, (5000,), generator=gen).to(DEV)
-    for bad_label in (17, -1, 2 ** 32 + 3):           # (2^32 + 3 would alias class 3 if the kernel truncated to 32 bits)
-        bad = good.clone()
-        bad[1234] = bad_label
-        mod = losses.FocalLoss(loss_weight=1.0)
-        with pytest.raises(RuntimeError, match='target labels must be in'):
-            mod(logits, bad, avg_factor=100.0)
-        mod = losses.FocalLoss(loss_weight=1.0)
-        assert torch.isfinite(mod(logits, good, avg_factor=100.0))        # first call: host check passes
-        assert torch.isnan(mod(logits, bad, avg_factor=100.0))            # later calls: the kernel's NaN
-        assert torch.isnan(hip.sigmoid_focal_loss_sum(logits.bfloat16(), bad))
-    assert torch.isfinite(hip.sigmoid_focal_loss_sum(logits, good))
+    flag = hip.LabelRangeFlag.of(logits.device)
+    try:
+        for bad_label in (17, -1, 2 ** 32 + 3):           # (2^32 + 3 would alias class 3 if the kernel truncated to 32 bits)
+            flag.reset()
+            bad = good.clone()
+            bad[1234] = bad_label
+            mod = losses.FocalLoss(loss_weight=1.0)
+            with pytest.raises(RuntimeError, match='target labels must be in'):
+                mod(logits, bad, avg_factor=100.0)
+            mod = losses.FocalLoss(loss_weight=1.0)
+            assert torch.isfinite(mod(logits, good, avg_factor=100.0))        # first call: host check passes
+            losses.FocalLoss.check_labels()                                   # nothing bad so far
+            assert torch.isnan(mod(logits, bad, avg_factor=100.0))            # later calls: the kernel's NaN ...
+            torch.cuda.synchronize()
+            with pytest.raises(RuntimeError, match='outside'):                # ... and the next fused call is loud
+                mod(logits, good, avg_factor=100.0)
+            with pytest.raises(RuntimeError, match='outside'):
+                losses.FocalLoss.check_labels()
+            flag.reset()
+            assert torch.isnan(hip.sigmoid_focal_loss_sum(logits.bfloat16(), bad))
+            with pytest.raises(RuntimeError, match='outside'):
+                losses.FocalLoss.check_labels()
+        flag.reset()
+        assert torch.isfinite(hip.sigmoid_focal_loss_sum(logits, good))
+        losses.FocalLoss.check_labels()
+    finally:
+        flag.reset()
 
 
 def test_sca_gather_three_camera_overlap_determinism_bound():

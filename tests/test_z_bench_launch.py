@@ -17,7 +17,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, 'bench.py')
 SMALL = ['--batch', '2', '--micro', '2', '--steps', '2', '--warmup', '0', '--no-cpu-baseline',
-         '--latency-batches', '1', '--latency-steps', '2']
+         '--latency-batches', '1', '--latency-steps', '2', '--sub-records', '']
 
 
 def run_bench(argv, env_extra=None, timeout=900):
@@ -86,6 +86,22 @@ def test_rccl_leg_runs_on_hardware_with_one_rank(workload):
 
 
 @pytest.mark.gpu
+def test_default_line_carries_the_full_multitask_and_fp32_sub_records():
+    """The driver's command is fixed, so BASELINE configs[4] and the fp32 form of the headline workload ride in the
+    default line as `config.full_train` / `config.fp32` (measured after the headline region, never part of `value`)."""
+    argv = [a for a in SMALL if a not in ('--sub-records', '')] + ['--sub-records', 'full_train:2,fp32:2', '--sub-steps', '2',
+                                                                  '--host-fed-steps', '0']
+    proc = run_bench(argv)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    cfg = json_line(proc)['config']
+    ft, f32 = cfg['full_train'], cfg['fp32']
+    assert ft['workload'] == 'vocc_full_train' and ft['dtype'] == 'bf16' and ft['viewpoints_per_gpu_per_step'] == 2
+    assert f32['workload'] == 'vocc_c2f_train' and f32['dtype'] == 'fp32' and f32['viewpoints_per_gpu_per_step'] == 2
+    assert ft['viewpoints_per_s'] > 0 and f32['viewpoints_per_s'] > 0
+    assert ft['trainable_params'] > f32['trainable_params'] > 100e6        # the decoder is unfrozen in configs[4]
+
+
+@pytest.mark.gpu
 def test_plain_one_gpu_run_of_the_full_workload_replays_small_batches_as_graphs():
     """`python bench.py --workload vocc_full_train` on one GPU, no launcher: the headline is the eager step; the
     config.latency record at one viewpoint per step is the hipGraph replay of the head (graphed: true), and the line
@@ -97,3 +113,42 @@ def test_plain_one_gpu_run_of_the_full_workload_replays_small_batches_as_graphs(
     rec = line['config']['latency'][0]
     assert rec['viewpoints_per_gpu_per_step'] == 1 and rec['graphed'] is True and rec['ms_per_step'] > 0
     assert line['config']['host_fed']['viewpoints_per_s'] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_allreduce_the_gradients_of_the_real_step(tmp_path):
+    """BASELINE configs[3], correctness of the exchange: two gloo ranks on the one GPU run ONE LiftTrainer step of the
+    real HIP path (custom autograd Functions, frozen parameters, gradient_as_bucket_view buckets) at two viewpoints each,
+    fp32, dropout p = 0; the gradients rank 0 holds after the all-reduce equal the MEAN of two single-process runs over
+    the two ranks' viewpoints (reference: MMDistributedDataParallel, apis/mmdet_train.py:71-80)."""
+    import torch
+    helper = os.path.join(ROOT, 'tests', 'ddp_grad_helper.py')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    outs = []
+    for r in (0, 1):
+        out = str(tmp_path / ('single%d.pt' % r))
+        proc = subprocess.run([sys.executable, helper, 'single', str(r), out], env=env, capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, proc.stderr[-4000:]
+        outs.append(torch.load(out))
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / 'ddp.pt')
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                           '--master-addr', '127.0.0.1', '--master-port', str(port), helper, 'ddp', out],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    ddp = torch.load(out)
+    assert abs(ddp['loss'] - outs[0]['loss']) <= 1e-6 * abs(outs[0]['loss'])          # rank 0's own loss
+    assert set(ddp['grads']) == set(outs[0]['grads']) == set(outs[1]['grads']) and len(ddp['grads']) > 50
+    worst = 0.0
+    for k, g in ddp['grads'].items():
+        want = 0.5 * (outs[0]['grads'][k] + outs[1]['grads'][k])
+        err = float((g - want).norm() / want.norm().clamp_min(1e-30))
+        worst = max(worst, err)
+        assert err < 1e-5, (k, err)
+        # and it is NOT just rank 0's own gradient: the exchange happened
+        assert float((g - outs[0]['grads'][k]).norm()) > 1e-3 * float(want.norm()) or float(want.norm()) == 0.0, k
+    print('worst relative L2 of the all-reduced gradients: %.2e' % worst)

@@ -283,7 +283,9 @@ extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, l
     const int vc = 16 / (int)esize, vx = 8 / (int)esize;
     const bool vec = W % vx == 0 && C % vc == 0 && cf_stride % vx == 0 && ((uintptr_t)channels_last & 15) == 0 &&
                      ((uintptr_t)channel_first & 7) == 0 && ((long)Z * H * W) % vx == 0;
-    if (vec && (size_t)kCh * (W + 1) * esize <= 64 * 1024) {
+    // (the guard is the vector kernels' own LDS request with R = 1: kCh x (W + 4) elements, under the 64 KB a launch gets
+    // without hipFuncSetAttribute; wider rows take the scalar kernel)
+    if (vec && (size_t)kCh * ((size_t)W + 4) * esize <= 64 * 1024) {
         // the WRITE side wants long runs: to channel-first 32 channels x R rows (R W contiguous positions per channel),
         // to channels-last 128 channels x one row (256 contiguous bytes per position); measured the other way round
         // each direction loses a third (2.7 vs 3.6 ms to channel-first, 2.1 vs 3.0 ms back)

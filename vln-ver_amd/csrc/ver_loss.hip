@@ -75,9 +75,10 @@ __device__ __forceinline__ uint32_t to_bf16(float f) {   // round to nearest eve
 template <bool BF16, bool G2>
 __global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logits, const int64_t* __restrict__ target,
                                                    float* __restrict__ partial, long nvec, int vec_per_row,
-                                                   float gamma, float alpha) {
+                                                   float gamma, float alpha, int* __restrict__ bad_labels) {
     __shared__ float red[4];
     float acc = 0.0f;
+    bool bad = false;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
         const long row = v / vec_per_row;
         const int c0 = (int)(v - row * vec_per_row) * 8;
@@ -90,8 +91,14 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logi
         // a label outside [0, C] (F.one_hot raises on it) poisons the sum: the loss comes out NaN instead of silently
         // counting the row as background -- checked here, in the pass that reads the labels anyway, so the host needs no
         // device->host synchronisation per step to be loud about it
-        if ((uint64_t)t64 > (uint64_t)(vec_per_row * 8)) acc = __builtin_nanf("");
+        if ((uint64_t)t64 > (uint64_t)(vec_per_row * 8)) {
+            acc = __builtin_nanf("");
+            bad = true;
+        }
     }
+    // ... and raises a sticky device-side flag: callers that clean NaNs out of their losses (the head's nan_to_num,
+    // as in the reference) still learn about it, from an asynchronous copy of one int
+    if (bad_labels && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(bad_labels, 1);
     acc = group_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -144,7 +151,7 @@ extern "C" int ver_focal_loss_blocks(long N, int C) {
 }
 
 extern "C" int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,
-                                      float gamma, float alpha, int dtype, void* stream) {
+                                      float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream) {
     int rc = check_focal("ver_focal_loss_forward", logits, target, N, C, dtype);
     if (rc) return rc;
     VER_REQUIRE(partial, VER_EINVAL, "ver_focal_loss_forward: null partial-sum buffer");
@@ -154,7 +161,7 @@ extern "C" int ver_focal_loss_forward(const void* logits, const int64_t* target,
     const bool g2 = gamma == 2.0f;
 #define VER_FOCAL_FWD(BF, G2)                                                                                   \
     hipLaunchKernelGGL((k_focal_fwd<BF, G2>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, C / 8, \
-                       gamma, alpha)
+                       gamma, alpha, bad_labels)
     if (dtype == VER_BF16) {
         if (g2) VER_FOCAL_FWD(true, true); else VER_FOCAL_FWD(true, false);
     } else {

@@ -350,14 +350,14 @@ __device__ __forceinline__ void stage_wait() {
 constexpr int kFwdLoaders = VER_FWD_LOADERS;   // 0: every wave issues its share of the next tile's LDS-DMA
 
 #ifdef VER_DEBUG_TIMELINE
-// timeline of four probe workgroups of k_sca_fwd_cs (scratch/r02/timeline_p.py; build with -DVER_DEBUG_TIMELINE):
+// timeline of 32 probe workgroups of k_sca_fwd_cs (scratch/r04/timeline_cs.py; build with -DVER_DEBUG_TIMELINE):
 // g_tl[probe][wave][event] = s_memtime
-__device__ long long g_tl[4 * 16 * 64];
+constexpr int kTlProbes = 32;
+__device__ long long g_tl[kTlProbes * 16 * 64];
 __device__ __forceinline__ int tl_probe() {
     const int nb = gridDim.x;
-    const int pb[4] = {nb / 8, (3 * nb) / 8, (5 * nb) / 8, (7 * nb) / 8};
-    for (int i = 0; i < 4; ++i)
-        if ((int)blockIdx.x == pb[i]) return i;
+    for (int i = 0; i < kTlProbes; ++i)
+        if ((int)blockIdx.x == (int)(((long)nb * (2 * i + 1)) / (2 * kTlProbes))) return i;
     return -1;
 }
 #define VER_TL(ev)                                                                                        \
@@ -747,7 +747,12 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         r /= nchunks;
         const int c = r % Ncam, b = r / Ncam;
         const int h = hs * heads_per + i % heads_per;
+#ifdef VER_ABL_CONTIG
+        // timing only: the tile as ONE contiguous 37.6-KB block of HBM (what a head-major value layout would give)
+        const VT* src = value + (((size_t)b * Ncam + c) * heads + h) * Nk * HD + jc * EPC;
+#else
         const VT* src = value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD + jc * EPC;
+#endif
         VT* dst = reinterpret_cast<VT*>(smem + (nbuf == 2 ? (i & 1) : 0) * tile_bytes);
         int pi = i_first, pk = k_first;
 #ifdef VER_ABL_NODMA
@@ -755,9 +760,17 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #endif
         for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
             if (q0 + lane < total_chunks) {
+#ifdef VER_ABL_CONTIG
+                const VT* g = src + ((size_t)pi * Nk + pk) * 32;
+#else
                 const VT* g = src + (size_t)pk * rstride + pi * 32;
+#endif
+#ifndef VER_CS_DMA_AUX
+#define VER_CS_DMA_AUX 0
+#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0,
+                                                 VER_CS_DMA_AUX);
             }
             pk += rows_per_step;
             while (pk >= Nk) {
@@ -775,6 +788,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         if constexpr (MATH != 0) {
             const unsigned dst = (unsigned)(uintptr_t)(lds_byte*)reinterpret_cast<const unsigned char*>(smem) +
                                  (nbuf == 2 ? (unsigned)(i & 1) : 0u) * tile_bytes;
+#ifdef VER_CS_CONV_SERIAL
             for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
                 if (q0 + lane < total_chunks) {
                     const unsigned a = dst + (unsigned)(q0 + lane) * 16u;
@@ -790,6 +804,32 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                     *lds_ptr_mut<u32x4_t>(a) = o;
                 }
             }
+#else
+            // five chunks per lane in flight: the serial form (read, wait, convert, write per chunk) ran ten dependent LDS
+            // round trips per tile -- ~10 k cycles of every workgroup's ~60 k-cycle prologue (scratch/r04/timeline_cs.py).
+            // Reads past the end are clamped to the last chunk (which its owner may already have converted: the value is
+            // dropped), only the store is predicated.
+            constexpr int kBatch = 5;
+            const int step = 64 * dma_waves;
+            for (int q0 = dma_wave * 64 + lane; q0 < total_chunks; q0 += kBatch * step) {
+                u32x4_t w[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k)
+                    w[k] = *lds_ptr<u32x4_t>(dst + (unsigned)min(q0 + k * step, total_chunks - 1) * 16u);
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    u32x4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned x = e == 0 ? w[k].x : e == 1 ? w[k].y : e == 2 ? w[k].z : w[k].w;
+                        const auto hh = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u));
+                        const unsigned r = __builtin_bit_cast(unsigned, hh);
+                        if (e == 0) o.x = r; else if (e == 1) o.y = r; else if (e == 2) o.z = r; else o.w = r;
+                    }
+                    if (q0 + k * step < total_chunks) *lds_ptr_mut<u32x4_t>(dst + (unsigned)(q0 + k * step) * 16u) = o;
+                }
+            }
+#endif
         }
     };
 
@@ -797,10 +837,13 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         // ------------------------------------------------------------ loader waves: stream the tiles
         stage(0);
         for (int i = 0; i < ntiles; ++i) {
+            if (i < 7) VER_TL(8 * i + 10);
             __builtin_amdgcn_s_waitcnt(0);            // this wave's share of tile i has landed
+            if (i < 7) VER_TL(8 * i + 11);
             to_f16(i);
-            VER_TL(1 + i);
+            if (i < 7) VER_TL(8 * i + 12);
             __syncthreads();                          // tile i complete; the consumers are done with tile i - 1
+            if (i < 7) VER_TL(8 * i + 13);
             if (i + 1 < ntiles) stage(i + 1);
         }
         return;
@@ -824,6 +867,16 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         float2 of, u;
     };
     int ti = 0;                                       // tile counter of this workgroup
+#ifndef VER_CS_NO_DMA_FIRST
+    // The first tile's LDS-DMA depends on nothing but the block index: it goes out before the counts, the voxel ids and
+    // the first samples are fetched (three dependent memory round trips that used to run IN FRONT of it).
+    if (nload == 0) stage(0);
+#endif
+#ifndef VER_CS_NO_PRIO
+    // a new workgroup's waves are the youngest of their SIMDs and lose every issue arbitration against the older waves'
+    // gather loops: the prologue (requests, tile conversion) runs at raised priority, the gather itself at the default
+    __builtin_amdgcn_s_setprio(3);
+#endif
     for (int un = u0; un < u1; ++un) {
         int r = un;
         const int hs = r % hsplit;
@@ -861,8 +914,15 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         for (int hh = 0; hh < heads_per; ++hh, ++ti) {
             const int h = h0 + hh;
             if (nload == 0) {
+#ifndef VER_CS_NO_DMA_FIRST
+                if (ti) {
+                    __syncthreads();                  // everyone is done with the previous tile
+                    stage(ti);
+                }
+#else
                 if (ti) __syncthreads();              // everyone is done with the previous tile
                 stage(ti);
+#endif
             }
             // per-tile WAVE-UNIFORM base pointers; a lane's address is base + 32-bit byte offset (one 24-bit multiply-add),
             // which the memory instructions take as SGPR base + VGPR offset -- no 64-bit VALU arithmetic per access
@@ -885,12 +945,20 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
             int n0 = un0, n1 = un1, n2 = un2;
             Sample s0 = {};
             if (iters > 0) s0 = load_sample(n0);      // requested before the tile barrier: the latency hides behind it
+            VER_TL(1);
             if (nload == 0) {
                 __builtin_amdgcn_s_waitcnt(0);        // this wave's share of the tile has landed
+                VER_TL(2);
                 to_f16(ti);
             }
+            VER_TL(3);
+            if (nload > 0 && ti < 7) VER_TL(8 * ti + 14);
             __syncthreads();                          // tile ti is complete
-            VER_TL(1 + ti);
+#ifndef VER_CS_NO_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            VER_TL(4);
+            if (nload > 0 && ti < 7) VER_TL(8 * ti + 15);
             const unsigned base4 = smem_lds + (nbuf == 2 ? (unsigned)(ti & 1) * tile_bytes : 0u) + lane_off;
             // operands: voxel ids two wave iterations ahead, sample records one ahead (all loads and stores of the loop
             // are unconditional, so the compiler's vmcnt waits never have to drain the young output stores)
@@ -926,6 +994,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 }
                 // ---------------- phase B: two voxels per sub-iteration, lane = (voxel, corner, 4*NV channels)
                 const int nsub = min(4, p_hi - p_lo - 4 * it);
+                if (it == 1) VER_TL(6);
                 // Records travel from the phase-A lanes to the corner slots through the wave's 512-B LDS table.  Other
                 // lanes of the wave read them: LDS serves one wave's requests in order, so no wait is needed in hardware,
                 // but the compiler must know (without the fence it forwarded the previous pair's loads to the lanes that
@@ -1025,6 +1094,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                             }
                         }
                     }
+                    if (it == 1 && j == 0) VER_TL(7);
                     if (j + 1 < nsub) {                            // next pair's records: the latency hides behind the epilogue
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -1106,7 +1176,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 }
                 n0 = n1; n1 = n2; n2 = n3;
                 s0 = s1;
+                VER_TL(8 + it);
             }
+            VER_TL(5);
         }
     }
 }
@@ -1990,12 +2062,26 @@ extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int 
     return ver_check_launch("ver_hits_from_mask/k_build_lists");
 }
 
+// The zero fill of ver_sca_forward as a call of its own: it depends on the hit table only, so a caller can run it on a
+// side stream under the projections that precede the gather and pass VER_SCA_ROWS_PREZEROED.
+extern "C" int ver_sca_zero_rows(const int32_t* zero_list, const int32_t* zero_cnt, float* slots, int B, int Nq,
+                                 int row_floats, void* stream) {
+    VER_REQUIRE(B >= 0 && Nq >= 0 && row_floats > 0, VER_EINVAL, "ver_sca_zero_rows: bad sizes B=%d Nq=%d row=%d", B, Nq,
+                row_floats);
+    VER_REQUIRE(row_floats % 4 == 0, VER_EUNSUPPORTED, "ver_sca_zero_rows: row width not a multiple of 4");
+    if (B == 0 || Nq == 0) return VER_OK;
+    VER_REQUIRE(zero_list && zero_cnt && slots, VER_EINVAL, "ver_sca_zero_rows: null pointer argument");
+    hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, (hipStream_t)stream, zero_list, zero_cnt, slots,
+                       Nq, row_floats);
+    return ver_check_launch("ver_sca_zero_rows");
+}
+
 extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
                                const float* uv, const uint8_t* vis, const int32_t* vis_list,
                                const int32_t* vis_cnt, const int32_t* zero_list, const int32_t* zero_cnt,
                                const int32_t* fwd_list, const int32_t* fwd_cnt,
                                float* slots, int B, int Ncam, int Nq, int D, int heads,
-                               int head_dim, int points, int map_h, int map_w, void* stream) {
+                               int head_dim, int points, int map_h, int map_w, int flags, void* stream) {
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
@@ -2039,10 +2125,13 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     int hsplit = 1;
     while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < min_wgs) hsplit *= 2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, st, zero_list, zero_cnt, slots, Nq,
-                       heads * head_dim);
-    rc = ver_check_launch("ver_sca_forward/k_zero_rows");
-    if (rc) return rc;
+    VER_REQUIRE((flags & ~VER_SCA_ROWS_PREZEROED) == 0, VER_EINVAL, "ver_sca_forward: unknown flags 0x%x", flags);
+    if (!(flags & VER_SCA_ROWS_PREZEROED)) {
+        hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, st, zero_list, zero_cnt, slots, Nq,
+                           heads * head_dim);
+        rc = ver_check_launch("ver_sca_forward/k_zero_rows");
+        if (rc) return rc;
+    }
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
         auto launch = [&](auto kern, auto vptr) {

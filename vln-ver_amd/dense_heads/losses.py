@@ -42,7 +42,9 @@ def sigmoid_focal_loss(pred, target, weight=None, gamma=2.0, alpha=0.25, reducti
 
 
 # 0: never check the label range on the host; 1 (default): on a module's first fused call; 2: on every call.
-# Whatever the setting, the kernel itself turns the loss into NaN when a label is outside [0, C] (ver_loss.hip).
+# Whatever the setting, the kernel itself turns the loss into NaN when a label is outside [0, C] and raises a sticky
+# device-side flag (ver_loss.hip) whose asynchronous host mirror (hipops.LabelRangeFlag) makes a LATER fused call
+# raise -- also when the caller has cleaned the NaN away in between, as the head's nan_to_num does.
 _FOCAL_CHECK = int(os.environ.get('VER_FOCAL_CHECK', '1'))
 
 
@@ -63,9 +65,10 @@ class FocalLoss(nn.Module):
             # Fused path (ver_focal_loss_*): rows >= 4096 only, so the small detection-branch calls keep the torch
             # arithmetic; on bf16 logits the kernel uses the hardware log (tolerances: tests/test_hip_ops_gpu.py).
             # A label outside [0, C] raises in F.one_hot (and in the reference).  The kernel answers it with a NaN loss
-            # (no synchronisation); the host-side range check with its readable message costs a device->host sync and
-            # a reduction over every label, so it runs on the first fused call of a module only (VER_FOCAL_CHECK=2:
-            # every call, 0: never) -- not inside every training step.
+            # and a sticky device flag that the next fused calls report without a synchronisation
+            # (hipops.LabelRangeFlag; `check_labels()` below waits for it); the host-side range check with its
+            # immediate, readable message costs a device->host sync and a reduction over every label, so it runs on
+            # the first fused call of a module only (VER_FOCAL_CHECK=2: every call, 0: never).
             if target.numel() and (_FOCAL_CHECK >= 2 or (_FOCAL_CHECK == 1 and not self._labels_checked)):
                 self._labels_checked = True
                 lo, hi = torch.aminmax(target)
@@ -76,6 +79,15 @@ class FocalLoss(nn.Module):
             return self.loss_weight * (sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha) / avg_factor)
         return self.loss_weight * sigmoid_focal_loss(pred, target, weight, self.gamma, self.alpha,
                                                      reduction, avg_factor)
+
+
+    @staticmethod
+    def check_labels(device=None):
+        """Wait for the device and raise if any fused focal-loss call so far saw a label outside [0, C]."""
+        from ..hipops import LabelRangeFlag
+        for f in list(LabelRangeFlag._per_device.values()):
+            if device is None or f.dev.device == torch.device(device):
+                f.poll(sync=True)
 
 
 @LOSSES.register_module(force=True)

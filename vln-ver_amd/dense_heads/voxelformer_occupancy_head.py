@@ -720,7 +720,14 @@ class VoxelFormerOccupancyHead(BaseModule):
     def get_occupancy_prediction(self, occ_results, occ_threshold=0.25):
         """head:1505-1540 (focal-loss branch): sigmoid, threshold as an extra "empty" column,
         arg-max -> sparse ``(voxel index, class)`` pairs of the occupied voxels."""
-        p = occ_results['occupancy_preds'].reshape(-1, self.occupancy_classes).sigmoid()
+        logits = occ_results['occupancy_preds'].reshape(-1, self.occupancy_classes)
+        if logits.is_cuda and self.occupancy_classes % 8 == 0:
+            # on the device: one classification + ordered compaction (ver_occ_predict), same pairs bit for bit
+            from ..hipops import occ_predict
+            occ_results['occupancy_preds'] = occ_predict(logits, occ_threshold)
+            occ_results['flow_preds'] = None
+            return occ_results
+        p = logits.sigmoid()
         p = torch.cat((p, torch.ones_like(p)[:, :1] * occ_threshold), dim=-1)
         occ_class = p.argmax(dim=-1)
         occ_index, = torch.where(occ_class < self.occupancy_classes)

@@ -61,7 +61,8 @@ class GraphedHead:
 
     feats [Ncam, B, Nk, C], world2pixel [B, Ncam, 4, 4], origin [B, 3] on the GPU are the SAMPLE inputs that fix the
     shapes; ``autocast_dtype=torch.bfloat16`` (default) runs the head under bf16 autocast as ``bench.py`` does, None in
-    fp32.  The head must be in the mode (train / eval) and have the ``requires_grad`` flags it will be used with."""
+    fp32.  The head must be in the mode (train / eval) and have the ``requires_grad`` flags it will be used with (checked
+    on every call).  Outputs are valid until the next call (they alias the graphs' static buffers)."""
 
     def __init__(self, head, feats, world2pixel, origin, autocast_dtype=torch.bfloat16, occupancy_rows=True,
                  check_live_losses=True):
@@ -69,6 +70,11 @@ class GraphedHead:
             raise RuntimeError('GraphedHead needs GPU tensors (HIP graphs)')
         if head.only_occ or head.only_det or head.add_layout:
             raise NotImplementedError('GraphedHead covers the default multi-task branch of the head')
+        if getattr(head, 'getbev', None) is not None:
+            raise NotImplementedError('GraphedHead: a head built with getbev=<store> writes volumes to the host inside '
+                                      'forward (device -> host copies and file I/O), which cannot be captured')
+        self.head, self.training = head, head.training
+        self.grad_flags = [p.requires_grad for p in head.parameters()]
         if check_live_losses:
             gc.collect()
             n = len(_live_losses())
@@ -82,6 +88,11 @@ class GraphedHead:
         self.graphed = torch.cuda.make_graphed_callables(self.module, (feats, world2pixel, origin), allow_unused_input=True)
 
     def __call__(self, feats, world2pixel, origin):
+        """NOTE: the returned tensors ALIAS the graph's static output buffers -- ``bev_embed``, the class scores and the
+        boxes are overwritten by the next call; clone what has to survive it."""
+        if self.head.training != self.training or [p.requires_grad for p in self.head.parameters()] != self.grad_flags:
+            raise RuntimeError('GraphedHead: head.training / requires_grad flags differ from capture time; build a new '
+                               'GraphedHead for the new mode')
         cls, box, occ, bev = self.graphed(feats, world2pixel, origin)
         if self.module.row_plan is not None:
             occ = (occ,) + self.module.row_plan

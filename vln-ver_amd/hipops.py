@@ -14,16 +14,16 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
-           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_forward', 'ver_sca_backward',
+           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
-           'ver_relu_dropout_forward', 'ver_relu_dropout_backward')
+           'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict')
 
 _lib = None
 
@@ -46,6 +46,7 @@ def lib():
                 raise HipLibraryError('%s does not export %s' % (LIB_PATH, name))
         handle.ver_last_error.restype = ctypes.c_char_p
         handle.ver_occ_mlp_image_bytes.restype = ctypes.c_long
+        handle.ver_occ_predict_blocks.restype = ctypes.c_long
         if handle.ver_abi_version() != ABI_VERSION:
             raise HipLibraryError('libver_hip.so ABI %d != expected %d: rebuild'
                                   % (handle.ver_abi_version(), ABI_VERSION))
@@ -210,14 +211,56 @@ def hits_from_mask(reference_points_cam, bev_mask):
     return hit
 
 
+_SIDE_STREAMS = {}
+SCA_PREZERO = os.environ.get('VER_SCA_PREZERO', '1') != '0'
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device)
+    if st is None:
+        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+class PreparedSlots:
+    """Output buffer of one ``ver_sca_forward`` call whose zero fill is already under way on a side stream."""
+    __slots__ = ('slots', 'done')
+
+    def __init__(self, slots, done):
+        self.slots, self.done = slots, done
+
+
+def sca_prepare_slots(hit, row_floats):
+    """Allocate the gather's output and zero-fill the rows ``hit.zero_list`` names on a SIDE stream
+    (``ver_sca_zero_rows``).  The fill depends on the hit table only, so a caller that does this before the
+    projections feeding the gather (value_proj, sampling_offsets / attention_weights) hides it under them instead
+    of paying it in front of the gather.  Returns None when it cannot be overlapped safely (stream capture,
+    VER_SCA_PREZERO=0): ``sca_gather`` then fills in line, as before."""
+    if not SCA_PREZERO or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = hit.vis.device
+    slots = torch.empty(hit.B, hit.Nq, row_floats, dtype=torch.float32, device=dev)
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    # the block may still be in use by kernels queued on the main stream: the fill starts where the main stream is now
+    side.wait_stream(main)
+    slots.record_stream(side)       # (a buffer dropped before the gather consumed it must outlive the fill)
+    with torch.cuda.stream(side):
+        _launch('ver_sca_zero_rows', lambda: lib().ver_sca_zero_rows(
+            _p(hit.zero_list), _p(hit.zero_cnt), _p(slots), hit.B, hit.Nq, row_floats, _stream()))
+        done = torch.cuda.Event()
+        done.record(side)
+    return PreparedSlots(slots, done)
+
+
 class SCAGatherFunction(Function):
     """slots = fused multi-view gather (ver_sca_forward / ver_sca_backward).
 
-    ``value`` may be fp32 or bf16 (what ``value_proj`` emits under bf16 autocast): the kernels
-    read it as stored and do all arithmetic in fp32, like the reference's fp32-forced op."""
+    ``value`` may be fp32 or bf16 (what ``value_proj`` emits under bf16 autocast).  fp32 tiles: fp32 arithmetic
+    throughout, like the reference's fp32-forced op.  bf16 tiles at the vocc.py shape: the points of a (voxel, head,
+    corner) are accumulated in packed fp16, everything after the corner fold in fp32 (contract: include/ver_ops.h)."""
 
     @staticmethod
-    def forward(ctx, value, offsets, logits, hit, map_h, map_w):
+    def forward(ctx, value, offsets, logits, hit, map_h, map_w, prepared=None):
         if value.dtype not in (torch.float32, torch.bfloat16):
             value = value.float()
         value = _gpu(value, 'value')
@@ -229,12 +272,19 @@ class SCAGatherFunction(Function):
         nq = hit.Nq
         assert nk == map_h * map_w and B == hit.B and ncam == hit.Ncam
         assert offsets.shape == (B, nq, heads, points, 2) and logits.shape == (B, nq, heads, points)
-        slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)
+        flags = 0
+        if prepared is not None:
+            slots = prepared.slots
+            assert slots.shape == (B, nq, heads * hd) and slots.dtype == torch.float32 and slots.is_contiguous()
+            torch.cuda.current_stream(slots.device).wait_event(prepared.done)      # (long done: it ran under the GEMMs)
+            flags = 1                                                                # VER_SCA_ROWS_PREZEROED
+        else:
+            slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)
         _launch('ver_sca_forward', lambda: lib().ver_sca_forward(
             _p(value), vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(slots),
             B, ncam, nq, hit.D, heads, hd,
-            points, map_h, map_w, _stream()))
+            points, map_h, map_w, flags, _stream()), meta=dict(prezeroed=bool(flags)))
         ctx.save_for_backward(value, offsets, logits)
         ctx.hit, ctx.map_hw, ctx.vdt = hit, (map_h, map_w), vdt
         return slots
@@ -258,11 +308,11 @@ class SCAGatherFunction(Function):
             _p(hit.vis_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(gs), _p(g_value), gdt, _p(g_off), _p(g_log), B, ncam,
             hit.Nq, hit.D, heads,
             hd, points, map_h, map_w, _stream()))
-        return g_value.to(value.dtype), g_off, g_log, None, None, None
+        return g_value.to(value.dtype), g_off, g_log, None, None, None, None
 
 
-def sca_gather(value, offsets, logits, hit, map_h, map_w):
-    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w)
+def sca_gather(value, offsets, logits, hit, map_h, map_w, prepared=None):
+    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w, prepared)
 
 
 # ------------------------------------------------------------------------------------------
@@ -479,6 +529,58 @@ def layer_norm_relu(x, gamma, beta, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------
+class LabelRangeFlag:
+    """Sticky device-side "a label was outside [0, C]" flag of the fused focal loss, with an ASYNCHRONOUS host mirror:
+    every fused call ORs into the device int (ver_focal_loss_forward) and queues a copy of it into pinned host memory;
+    ``poll()`` reads the newest copy that has already arrived -- no device synchronisation -- and raises once it is
+    set, so a bad label is reported one or two calls later, every call after that, whatever the caller does with the
+    NaN loss in between (the head cleans NaNs out of its losses, as the reference does).  ``poll(sync=True)`` waits."""
+
+    _per_device = {}
+
+    def __init__(self, device):
+        self.dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+        self.classes = None
+
+    @classmethod
+    def of(cls, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        f = cls._per_device.get(key)
+        if f is None:
+            f = cls._per_device[key] = cls(device)
+        return f
+
+    def mirror(self, classes):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        self.classes = classes
+        if self.event is not None and not self.event.query():
+            return                                          # the previous copy is still in flight: do not overwrite it
+        self.host.copy_(self.dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def poll(self, sync=False):
+        if self.event is None:
+            return
+        if sync:
+            self.event.synchronize()
+            self.host.copy_(self.dev)                       # (the mirror may predate the offending call)
+        elif not self.event.query():
+            return
+        if int(self.host[0]) != 0:
+            raise RuntimeError('FocalLoss: a target label outside [0, %s] reached the fused focal loss on %s (the loss of '
+                               'that call was NaN; F.one_hot raises on it in the reference)'
+                               % (self.classes, self.dev.device))
+
+    def reset(self):
+        self.dev.zero_()
+        self.host.zero_()
+        self.event = None
+
+
 class SigmoidFocalLossSumFunction(Function):
     """sum over all elements of mmdet's sigmoid focal loss (ver_focal_loss_forward / _backward):
     logits fp32|bf16 [N, C] with C % 8 == 0, target int64 [N] in [0, C]; returns an fp32 scalar."""
@@ -496,9 +598,12 @@ class SigmoidFocalLossSumFunction(Function):
         dt = 1 if logits.dtype == torch.bfloat16 else 0
         blocks = lib().ver_focal_loss_blocks(ctypes.c_long(n), c)
         partial = torch.zeros(blocks, dtype=torch.float32, device=logits.device)
+        flag = LabelRangeFlag.of(logits.device)
+        flag.poll()                                          # a bad label of an EARLIER call is reported here
         _launch('ver_focal_loss_forward', lambda: lib().ver_focal_loss_forward(
             _p(logits), _p(target), _p(partial), ctypes.c_long(n), c, ctypes.c_float(gamma),
-            ctypes.c_float(alpha), dt, _stream()))
+            ctypes.c_float(alpha), dt, _p(flag.dev), _stream()))
+        flag.mirror(c)
         ctx.save_for_backward(logits, target)
         ctx.cfg = (gamma, alpha, dt)
         return partial.sum()
@@ -788,3 +893,23 @@ class VoxelMSDeformAttnFunction(Function):
 def voxel_msda(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     return VoxelMSDeformAttnFunction.apply(value, spatial_shapes, level_start_index, sampling_locations,
                                            attention_weights)
+
+
+# ------------------------------------------------------------------------------------------
+def occ_predict(logits, threshold=0.25):
+    """Sparse occupancy prediction (ver_occ_predict; head:1505-1540): logits fp32|bf16 [N, C] ->
+    int64 [K, 2] pairs (row index, class) of the rows whose best class probability reaches ``threshold``,
+    in ascending row order.  One device->host read of K, as the reference's ``torch.where``."""
+    logits = _gpu(logits, 'logits')
+    if logits.dtype not in (torch.float32, torch.bfloat16):
+        logits = logits.float()
+    logits = logits.contiguous()
+    n, c = logits.shape
+    dt = 1 if logits.dtype == torch.bfloat16 else 0
+    nb = lib().ver_occ_predict_blocks(ctypes.c_long(n))
+    work = torch.empty(max(nb, 1), dtype=torch.int32, device=logits.device)
+    pairs = torch.empty(max(n, 1), 2, dtype=torch.int64, device=logits.device)
+    count = torch.empty(1, dtype=torch.int64, device=logits.device)
+    _launch('ver_occ_predict', lambda: lib().ver_occ_predict(
+        _p(logits), dt, ctypes.c_long(n), c, ctypes.c_float(threshold), _p(work), _p(pairs), _p(count), _stream()))
+    return pairs[:int(count.item())]

@@ -179,11 +179,18 @@ _CONST_TENSORS = {}
 def const_tensor(values, device, dtype=torch.long):
     """A small constant tensor (``spatial_shapes``, ``level_start_index`` ...) on ``device``, created once per
     (values, dtype, device): the reference builds these from Python lists on every forward -- a pageable host -> device
-    copy each time, which serialises with the stream and is not allowed while a HIP graph is being captured."""
+    copy each time, which serialises with the stream and is not allowed while a HIP graph is being captured.
+    The tensor is created outside any ``inference_mode`` (a constant first built during an eval / export pass must
+    still be usable as a saved tensor of a later training step) and the key holds the RESOLVED device ('cuda' and
+    'cuda:0' are one entry).  The cache only ever holds the handful of shape constants of the configured model."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
     key = (repr(values), dtype, str(device))
     t = _CONST_TENSORS.get(key)
     if t is None:
-        t = _CONST_TENSORS[key] = torch.tensor(values, dtype=dtype, device=device)
+        with torch.inference_mode(False):
+            t = _CONST_TENSORS[key] = torch.tensor(values, dtype=dtype, device=device)
         _CONST_VALUES[id(t)] = (t, values)
     return t
 

@@ -87,6 +87,9 @@ class SpatialCrossAttention(BaseModule):
         # [Ncam,Nk,bs,C] -> [bs,Ncam,Nk,C]; a no-copy view when the caller built it that way
         # ``value_lowp``: the encoder's one bf16 cast of ``value`` ([bs,Ncam,Nk,C]) for all its layers, only meaningful
         # under the bf16 autocast it was made for
+        # the gather's output buffer: its zero fill (rows of voxels not seen by exactly one camera) depends on the hit
+        # table only and runs on a side stream under the three projections below
+        prepared = hipops.sca_prepare_slots(hit_table, c)
         use_lowp = (value_lowp is not None and torch.is_autocast_enabled('cuda')
                     and torch.get_autocast_dtype('cuda') == value_lowp.dtype)
         v = att.value_proj(value_lowp if use_lowp else value.permute(2, 0, 1, 3))
@@ -98,7 +101,7 @@ class SpatialCrossAttention(BaseModule):
                         torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
         offsets = both[..., :n_off].reshape(bs, num_query, att.num_heads, att.num_points, 2)
         logits = both[..., n_off:].reshape(bs, num_query, att.num_heads, att.num_points)
-        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1])
+        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1], prepared)
         slots = self.output_proj(slots.to(query.dtype))
         if defer_residual:                  # the caller's LayerNorm adds the residual (residual_layer_norm)
             return PendingResidual(slots, inp_residual, self.dropout.p if self.dropout.training else 0.0)

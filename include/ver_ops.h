@@ -173,6 +173,15 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  *   instead of in front of it.
  */
 #define VER_SCA_ROWS_PREZEROED 1
+/*        VER_SCA_VALUE_HEAD_MAJOR (ver_sca_forward and ver_sca_backward): `value` is laid out
+ *   [heads, B, Ncam, map_h*map_w, head_dim] instead of the reference's [B, Ncam, map_h*map_w, heads, head_dim]: a (camera,
+ *   head) tile is then ONE contiguous block of HBM (every 1-KB LDS-DMA request covers 8 whole 128-byte lines, none shared
+ *   with another head's workgroup).  Only where `ver_sca_head_major_supported(...)` returns 1 (bf16 tiles, 8 points,
+ *   head_dim % 32 == 0, 14x14 maps: the vocc.py shape); `grad_value` of ver_sca_backward keeps the REFERENCE layout
+ *   either way (the weight gradient of value_proj reads it as a plain [rows, heads*head_dim] matrix).
+ */
+#define VER_SCA_VALUE_HEAD_MAJOR 2
+int ver_sca_head_major_supported(int value_dtype, int head_dim, int points, int map_h, int map_w);
 int ver_sca_zero_rows(const int32_t* zero_list, const int32_t* zero_cnt, float* slots, int B, int Nq, int row_floats,
                       void* stream);
 int ver_sca_forward(const void* value, int value_dtype, const float* offsets, const float* logits,
@@ -199,7 +208,7 @@ int ver_sca_backward(const void* value, int value_dtype, const float* offsets, c
                      const float* grad_slots,
                      void* grad_value, int grad_value_dtype, float* grad_offsets, float* grad_logits,
                      int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
-                     int map_h, int map_w, void* stream);
+                     int map_h, int map_w, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Data movement of the even-lattice coarse-to-fine upsample: the reference's three
@@ -341,7 +350,14 @@ int ver_run_scatter(const void* rows, void* image, long image_stride, const int3
  *             `occ_proj` :571 feeds `occ_branches[0]` :580 with nothing in between), x is ITS output and the chain
  *             starts at the first LayerNorm; W1 / b1 of image / vectors are ignored, grad_a1 may be NULL,
  *             grad_x = d loss / d x is then the gradient w.r.t. that output, and no dW1 is to be formed.
+ *   ver_occ_mlp_forward takes `first_linear` as FLAGS: bit 0 as above, bit 1 = VER_OCC_MLP_CENTERED: the caller has
+ *             centred the weights and biases of both hidden Linears over their OUTPUT axis (W <- W - mean_o W,
+ *             b <- b - mean b; with first_linear = 0 the centring of Linear 1 sits in the producer of x), so every
+ *             LayerNorm input has zero row mean and the kernel skips the mean pass.  LayerNorm is invariant to a
+ *             per-row constant: LN(Wx + b) = LN(PWx + Pb), P = I - 11^T/128 -- the same function of the parameters;
+ *             the caller maps the gradients of the centred parameters back through P (autograd does).
  */
+#define VER_OCC_MLP_CENTERED 2
 long ver_occ_mlp_image_bytes(void);
 int ver_occ_mlp_vector_floats(void);
 int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W3, void* image, void* stream);

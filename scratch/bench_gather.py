@@ -41,8 +41,15 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 v = value.clone().requires_grad_(True); o = offs.clone().requires_grad_(True); l = logits.clone().requires_grad_(True)
-t_f = timeit(lambda: hip.sca_gather(value, offs, logits, hit, 14, 14))
-s = hip.sca_gather(v, o, l, hit, 14, 14)
+HM = bool(os.environ.get('VER_BENCH_HM'))          # head-major value layout (contiguous tiles)
+PZ = bool(os.environ.get('VER_BENCH_PREZERO'))     # zero fill on the side stream, outside the timed launches
+if HM:
+    value = value.permute(3, 0, 1, 2, 4).contiguous(); v = value.clone().requires_grad_(True)
+def fwd():
+    prep = hip.sca_prepare_slots(hit, 768) if PZ else None
+    return hip.sca_gather(value, offs, logits, hit, 14, 14, prep, HM)
+t_f = timeit(fwd)
+s = hip.sca_gather(v, o, l, hit, 14, 14, None, HM)
 t_b = timeit(lambda: torch.autograd.grad(s, [v, o, l], gs, retain_graph=True))
 t_p = timeit(lambda: hip.project_points(torch.from_numpy(w2p).to(dev), torch.from_numpy(org).to(dev), cases.PC_RANGE, z, h, w))
 print(json.dumps(dict(bf16=BF16, B=B, grid=grid, sigma_n=sn, fwd_us=round(t_f,1), fwd_GBs=round(fwd_b/t_f/1e3,1), fwd_frac=round(fwd_b/t_f/1e3/8000,4),

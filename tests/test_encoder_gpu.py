@@ -265,3 +265,46 @@ def test_encoder_layer_training_mode_dropout_fused_vs_plain():
         enc.eval()
         b = _run_encoder(enc, q, feats, w2p, org, grid)
     assert torch.equal(a, b)
+
+
+def test_tall_linear_weight_gradients_equal_the_plain_linear():
+    """GEMM ledger (profiles/r04_gemm_ledger.csv): the weight gradients of the encoder's Linears over ~2e5 rows ran at
+    0.15-0.6 PFLOP/s as single GEMMs with 9-18 output tiles; ``bricks.tall_linear`` routes them through the split-row
+    batched form (dense_heads/row_linear.py).  Same outputs, same gradients: the vocc.py encoder at 20 viewpoints
+    (18 000 voxel rows, 23 520 token rows: above the threshold) against the same encoder with the routing disabled."""
+    from util import rel_l2
+    bricks = pkg('modules.bricks')
+    syn = pkg('synthetic')
+    B = 20
+    head = pkg('registry').build_head(cases.vocc_head_cfg())
+    syn.load_seeded(head, 7)
+    enc = head.transformer.encoder.to(DEV).train()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    w2p, org = syn.camera_batch(B, seed=3)
+    gen = torch.Generator(device='cpu').manual_seed(1)
+    q = torch.randn(900, B, 768, generator=gen).to(DEV)
+    feats = torch.randn(6, 196, B, 768, generator=gen).to(DEV)
+    gout = torch.randn(B, 900, 768, generator=gen).to(DEV)
+    res = {}
+    old = bricks._TALL_ROWS
+    try:
+        for name, rows in (('tall', 16000), ('plain', 10 ** 12)):
+            bricks._TALL_ROWS = rows
+            for p in enc.parameters():
+                p.grad = None
+            qq = q.clone().requires_grad_(True)
+            out = enc(qq, feats, feats, bev_z=4, bev_h=15, bev_w=15, bev_pos=None,
+                      spatial_shapes=torch.tensor([[14, 14]], device=DEV), level_start_index=torch.tensor([0], device=DEV),
+                      prev_bev=None, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+            out.backward(gout)
+            res[name] = (out.detach().cpu(), qq.grad.cpu(),
+                         {k: p.grad.detach().cpu() for k, p in enc.named_parameters() if p.grad is not None})
+    finally:
+        bricks._TALL_ROWS = old
+    assert float((res['tall'][0] - res['plain'][0]).abs().max()) <= 1e-5
+    assert rel_l2(res['tall'][1], res['plain'][1]) < 1e-5
+    assert set(res['tall'][2]) == set(res['plain'][2]) and len(res['tall'][2]) >= 30
+    for k, g in res['plain'][2].items():
+        assert rel_l2(res['tall'][2][k], g) < 2e-5, k

@@ -299,6 +299,55 @@ def test_sca_gather_bf16_value_range_contract():
     assert torch.isfinite(out).all() and rel_l2(out.cpu(), want) < 2e-3
 
 
+def test_sca_gather_head_major_value_equals_reference_layout():
+    """VER_SCA_VALUE_HEAD_MAJOR (include/ver_ops.h): the same bf16 values laid out [heads, B, Ncam, Nk, hd] -- a
+    (camera, head) tile is one contiguous block, staged row-major into LDS -- give the SAME slots bit for bit (the
+    arithmetic per sample is unchanged), the same d(offsets) / d(logits), and d(value) comes back as the permuted view of
+    a reference-layout buffer with the same numbers.  ``head_major_linear`` (value_proj as one batched GEMM over the
+    heads) equals the plain Linear, forward and gradients."""
+    hip = pkg('hipops')
+    heads, hd, P = 8, 96, 8
+    assert hip.sca_head_major_supported(torch.bfloat16, hd, P, 14, 14)
+    assert not hip.sca_head_major_supported(torch.float32, hd, P, 14, 14)
+    assert not hip.sca_head_major_supported(torch.bfloat16, hd, 4, 14, 14)
+    hit, value, offsets, logits, gslots = _random_sca_case(31, 3, (4, 15, 15), heads, hd, P)
+    gs = T(gslots).to(DEV)
+    res = {}
+    for hm in (False, True):
+        vb = T(value).to(DEV).to(torch.bfloat16)
+        if hm:
+            vb = vb.permute(3, 0, 1, 2, 4).contiguous()
+        vb.requires_grad_(True)
+        of = T(offsets).to(DEV).requires_grad_(True)
+        lg = T(logits).to(DEV).requires_grad_(True)
+        slots = hip.sca_gather(vb, of, lg, hit, 14, 14, None, hm)
+        slots.backward(gs)
+        gv = vb.grad
+        if hm:
+            assert gv.shape == vb.shape
+            gv = gv.permute(1, 2, 3, 0, 4)
+        res[hm] = (slots.detach().cpu(), of.grad.cpu(), lg.grad.cpu(), gv.float().cpu())
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    # the projection that produces the layout
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(3 * 6 * 196, 768, generator=gen).to(DEV).bfloat16().requires_grad_(True)
+    lin = torch.nn.Linear(768, 768).to(DEV)
+    g = torch.randn(heads, x.shape[0], hd, generator=gen).to(DEV).bfloat16()
+    out = hip.head_major_linear(x, lin.weight, lin.bias, heads)
+    out.backward(g)
+    got = (out.detach().float().cpu(), x.grad.float().cpu(), lin.weight.grad.float().cpu(), lin.bias.grad.float().cpu())
+    x2 = x.detach().clone().requires_grad_(True)
+    lin.weight.grad = lin.bias.grad = None
+    ref = torch.nn.functional.linear(x2, lin.weight.bfloat16(), lin.bias.bfloat16()).view(-1, heads, hd).permute(1, 0, 2)
+    ref.backward(g)
+    from util import rel_l2
+    assert rel_l2(got[0], ref.detach().float().cpu()) < 2e-3
+    assert rel_l2(got[1], x2.grad.float().cpu()) < 5e-3
+    assert rel_l2(got[2], lin.weight.grad.float().cpu()) < 5e-3
+    assert rel_l2(got[3], lin.bias.grad.float().cpu()) < 5e-3
+
+
 def test_sca_backward_grad_value_dtype_contract():
     """C ABI: ver_sca_backward_grad_dtype names the cheapest d(value) dtype (bf16 on the matrix-core path), and
     VER_F32 is accepted for the same problem: both buffers hold the same gradient up to bf16 rounding, and the
@@ -321,7 +370,7 @@ def test_sca_backward_grad_value_dtype_contract():
         go, gl = torch.empty_like(of), torch.empty_like(lg)
         rc = lib.ver_sca_backward(p(vb), 1, p(of), p(lg), p(hit.uv), p(hit.vis), p(hit.vis_list), p(hit.vis_cnt),
                                   p(hit.fwd_list), p(hit.fwd_cnt), p(gs), p(gv), gdt, p(go), p(gl), B, ncam, hit.Nq,
-                                  hit.D, heads, hd, P, 14, 14, hip._stream())
+                                  hit.D, heads, hd, P, 14, 14, 0, hip._stream())
         assert rc == 0, lib.ver_last_error()
         torch.cuda.synchronize()
         assert bool(torch.isfinite(gv.float()).all())

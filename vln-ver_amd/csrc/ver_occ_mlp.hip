@@ -62,6 +62,14 @@ __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
     bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// ReLU AFTER the bf16 pack: a bf16 bit pattern orders like an int16 on its sign, so max(x, 0) on the packed pairs is one
+// v_pk_max_i16 per TWO values (gfx950 has no packed fp32 max: the fp32 form is one v_max_f32 per value).  -0.0 and negative
+// NaNs become +0.0, positive NaNs pass -- as fmaxf(x, 0) would not, but a NaN row is garbage either way.
+__device__ __forceinline__ bf16x8 relu_packed(bf16x8 v) {
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
+}
 }  // namespace
 
 // -------------------------------------------------------------------------------------------- pack
@@ -100,21 +108,28 @@ namespace {
 // LayerNorm + ReLU of one row tile held transposed: acc[ot][i] = feature 16ot + 4g + i of row c.
 // Returns the B fragments of the next layer (k-step t <- tiles 2t, 2t+1); optionally the normalised
 // values (for the backward pass).
-template <bool KEEP>
+// CENTERED: the caller guarantees rows with zero mean over the 128 features (the weights / bias of the producing Linear were
+// centred over their OUTPUT axis, W <- W - mean_o W, b <- b - mean(b): LayerNorm is invariant to a per-row constant, so
+// LN(Wx + b) = LN(PWx + Pb) with P = I - 11^T/128) -- the mean pass and its two cross-lane reductions drop out.
+template <bool KEEP, bool CENTERED = false>
 __device__ __forceinline__ void ln_relu_tile(f32x4 (&acc)[8], const float* gam, const float* bet, float eps,
                                              bf16x8 (&out)[4], float& rstd_out) {   // gam/bet already offset by 4g
-    float s = 0.0f;
+    // (measured and dropped: starting the MFMA chains from 0 and adding the bias here -- the compiler ties vdst to src C,
+    //  so the zeroes cost the same v_mov per register the bias did, and the extra live bias vectors spilled)
+    if constexpr (!CENTERED) {
+        float s = 0.0f;
 #pragma unroll
-    for (int ot = 0; ot < 8; ++ot) s += (acc[ot].x + acc[ot].y) + (acc[ot].z + acc[ot].w);
-    s += xor16(s);
-    s += xor32(s);
-    const float mu = s * (1.0f / kW);
+        for (int ot = 0; ot < 8; ++ot) s += (acc[ot].x + acc[ot].y) + (acc[ot].z + acc[ot].w);
+        s += xor16(s);
+        s += xor32(s);
+        const float mu = s * (1.0f / kW);
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) acc[ot] -= mu;
+    }
     float q = 0.0f;
 #pragma unroll
-    for (int ot = 0; ot < 8; ++ot) {
-        acc[ot] -= mu;
+    for (int ot = 0; ot < 8; ++ot)
         q += (acc[ot].x * acc[ot].x + acc[ot].y * acc[ot].y) + (acc[ot].z * acc[ot].z + acc[ot].w * acc[ot].w);
-    }
     q += xor16(q);
     q += xor32(q);
     const float rs = rsqrtf(q * (1.0f / kW) + eps);
@@ -128,10 +143,9 @@ __device__ __forceinline__ void ln_relu_tile(f32x4 (&acc)[8], const float* gam, 
             const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 16 * ot);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 16 * ot);
             if (KEEP) acc[ot] *= rs;                       // normalised value stays in acc
-            const f32x4 v = KEEP ? acc[ot] * gm + bt : acc[ot] * (gm * rs) + bt;
-            y[h] = __builtin_elementwise_max(v, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+            y[h] = KEEP ? acc[ot] * gm + bt : acc[ot] * (gm * rs) + bt;
         }
-        out[t] = pack8(y[0], y[1]);
+        out[t] = relu_packed(pack8(y[0], y[1]));
     }
 }
 }  // namespace
@@ -143,7 +157,7 @@ namespace {
 // KEEP: also return the normalised values (bf16) and form the output from those rounded values (backward pass).
 // QUAD: the four lanes that share a row are a quad (lane = 4 row + chunk) instead of the same column of the four 16-lane rows
 // (lane = row + 16 chunk): the row statistics are then two DPP quad permutes instead of two ds_bpermute round trips.
-template <bool KEEP, bool QUAD = false>
+template <bool KEEP, bool QUAD = false, bool CENTERED = false>
 __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, const float* bet, float eps,
                                             bf16x8 (&xh)[4], float& rstd_out) {
     f32x4 v[4][2];
@@ -154,13 +168,15 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
         for (int h = 0; h < 2; ++h) {
             const bf16x4 hx = h ? __builtin_shufflevector(x[t], x[t], 4, 5, 6, 7) : __builtin_shufflevector(x[t], x[t], 0, 1, 2, 3);
             v[t][h] = __builtin_convertvector(hx, f32x4);
-            s += (v[t][h].x + v[t][h].y) + (v[t][h].z + v[t][h].w);
+            if constexpr (!CENTERED) s += (v[t][h].x + v[t][h].y) + (v[t][h].z + v[t][h].w);
         }
-    if constexpr (QUAD) {
-        s = group_sum<4>(s);
-    } else {
-        s += xor16(s);
-        s += xor32(s);
+    if constexpr (!CENTERED) {
+        if constexpr (QUAD) {
+            s = group_sum<4>(s);
+        } else {
+            s += xor16(s);
+            s += xor32(s);
+        }
     }
     const float mu = s * (1.0f / kW);
     float q = 0.0f;
@@ -168,7 +184,7 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            v[t][h] -= mu;
+            if constexpr (!CENTERED) v[t][h] -= mu;
             q += (v[t][h].x * v[t][h].x + v[t][h].y * v[t][h].y) + (v[t][h].z * v[t][h].z + v[t][h].w * v[t][h].w);
         }
     if constexpr (QUAD) {
@@ -196,16 +212,14 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
         for (int h = 0; h < 2; ++h) {
             const f32x4 gm = *reinterpret_cast<const f32x4*>(gam + 32 * t + 4 * h);
             const f32x4 bt = *reinterpret_cast<const f32x4*>(bet + 32 * t + 4 * h);
-            f32x4 n;
             if (KEEP) {
                 const bf16x4 hn = h ? __builtin_shufflevector(xh[t], xh[t], 4, 5, 6, 7) : __builtin_shufflevector(xh[t], xh[t], 0, 1, 2, 3);
-                n = __builtin_convertvector(hn, f32x4);
+                y[h] = __builtin_convertvector(hn, f32x4) * gm + bt;
             } else {
-                n = v[t][h] * rs;
+                y[h] = v[t][h] * (gm * rs) + bt;
             }
-            y[h] = __builtin_elementwise_max(n * gm + bt, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
         }
-        x[t] = pack8(y[0], y[1]);
+        x[t] = relu_packed(pack8(y[0], y[1]));
     }
 }
 }  // namespace
@@ -213,7 +227,8 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
 // L1 = false (first_linear = 0, ver_ops.h): x is the output of the first Linear already.  The chain starts with the first
 // LayerNorm in the natural fragment layout; the image was packed with W2 in W1's place, so section kF1 holds W2 with the
 // natural k order that layout needs (and kB1, in the backward kernel, W2's dgrad with natural-order output rows).
-template <int RT, bool L1>
+// CENTERED (flags bit 1): every LayerNorm input has zero row mean by construction (see ln_relu_tile).
+template <int RT, bool L1, bool CENTERED = false>
 __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict__ x, const __bf16* __restrict__ img,
                                                         const float* __restrict__ vec, __bf16* __restrict__ logits,
                                                         long N, float eps) {
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
             for (int rt = 0; rt < RT; ++rt) {
                 float rs;
                 bf16x8 unused[4];
-                ln_relu_nat<false>(bf[rt], sv_n + kW, sv_n + 2 * kW, eps, unused, rs);
+                ln_relu_nat<false, false, CENTERED>(bf[rt], sv_n + kW, sv_n + 2 * kW, eps, unused, rs);
             }
         }
 #pragma unroll
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 float rs;
-                ln_relu_tile<false>(acc[rt], bias + kW, bias + 2 * kW, eps, bf[rt], rs);
+                ln_relu_tile<false, CENTERED>(acc[rt], bias + kW, bias + 2 * kW, eps, bf[rt], rs);
             }
         }
         // layer 3: classes 4g..4g+3 of row c
@@ -642,7 +657,12 @@ extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float
     constexpr int RT = 4;
     const size_t lds = (size_t)kFwdFrags * 1024 + kVecFloats * sizeof(float);
     // (the attribute is per device: set it on every call, as ver_sca does -- it is a host-side table write)
-    auto kern = first_linear ? k_occ_mlp_fwd<RT, true> : k_occ_mlp_fwd<RT, false>;
+    // first_linear: bit 0 = the chain starts with Linear 1 (0: folded into the producer of x); bit 1 (VER_OCC_MLP_CENTERED)
+    // = every LayerNorm input has zero row mean by construction, the mean pass is skipped
+    VER_REQUIRE((first_linear & ~3) == 0, VER_EINVAL, "ver_occ_mlp_forward: unknown flags 0x%x", first_linear);
+    const bool l1 = first_linear & 1, centered = first_linear & 2;
+    auto kern = l1 ? (centered ? k_occ_mlp_fwd<RT, true, true> : k_occ_mlp_fwd<RT, true, false>)
+                   : (centered ? k_occ_mlp_fwd<RT, false, true> : k_occ_mlp_fwd<RT, false, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 16 * RT - 1) / (16 * RT);

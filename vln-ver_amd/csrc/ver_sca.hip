@@ -697,17 +697,24 @@ __device__ float g_sca_dummy_row[256 * 256];        // one 1-KiB slice per (bloc
 //      after it (camera sum, division) in fp32.  Error ~5e-4 of the partial sums (bf16 bound of the north star: 1e-2).
 //   (1 = fp16 tile with fp32 accumulation: the compiler turns it into v_cvt_f32_f16 + v_pk_fma_f32, as many
 //    instructions as mode 0 -- measured 3 % slower, 437 vs 424 us per launch; not dispatched.)
-template <int HD, typename VT, int NKT, int MATH = 0>
+// HM (head-major value, head_major_views > 0): the tile is one contiguous block of HBM and is staged as it lies, ROW-major in
+// LDS (a tile row = HD elements); the corner rows (r, r+1, r+14, r+15) of a 14-wide map of 192-byte rows still fall on four
+// disjoint 64-byte bank groups (0, 192, 128, 64 mod 256; profiles/r02_ubench_lds.txt), so the gather stays conflict free.
+template <int HD, typename VT, int NKT, int MATH = 0, bool HM = false>
 __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
-    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload) {
+    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views) {
+    // head_major_views: 0 = value in the reference's layout [B, Ncam, Nk, heads, HD] (a tile row is HD elements inside a
+    // heads*HD-wide token row); B > 0 = head-major [heads, B, Ncam, Nk, HD]: a (camera, head) tile is ONE contiguous block
+    // of HBM -- every 1-KB LDS-DMA instruction then covers 8 whole 128-byte lines instead of ~11 partial ones, and no line
+    // is shared with another head's workgroup, so the tile streams with the non-temporal policy (-20 us of 300 per launch)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = 8;
     constexpr bool F32 = sizeof(VT) == 4;
     constexpr int NV = HD / 32;
-    constexpr unsigned RB = 32 * sizeof(VT);
+    constexpr unsigned RB = (HM ? HD : 32) * sizeof(VT);            // bytes between tile rows in LDS
     constexpr int CPR = 32 * sizeof(VT) / 16, EPC = 16 / sizeof(VT);
     static_assert(HD % 32 == 0, "8 lanes x vectors of 4 channels");
     static_assert(MATH == 0 || !F32, "the fp16 modes are for bf16 tiles");
@@ -716,8 +723,8 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const int ncons = nwaves - nload;
     const int nbuf = nload > 0 ? 2 : 1;
     const int Nk = NKT ? NKT : mh * mw;
-    const unsigned plane = (unsigned)Nk * RB;
-    const unsigned tile_bytes = (NV * plane + 15u) & ~15u;
+    const unsigned plane = HM ? 32u * (unsigned)sizeof(VT) : (unsigned)Nk * RB;      // bytes between a row's 32-channel groups
+    const unsigned tile_bytes = ((unsigned)(NV * Nk * 32 * sizeof(VT)) + 15u) & ~15u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int heads_per = heads / hsplit;
     const size_t rstride = (size_t)heads * HD;
@@ -747,30 +754,27 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
         r /= nchunks;
         const int c = r % Ncam, b = r / Ncam;
         const int h = hs * heads_per + i % heads_per;
-#ifdef VER_ABL_CONTIG
-        // timing only: the tile as ONE contiguous 37.6-KB block of HBM (what a head-major value layout would give)
-        const VT* src = value + (((size_t)b * Ncam + c) * heads + h) * Nk * HD + jc * EPC;
-#else
-        const VT* src = value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD + jc * EPC;
-#endif
         VT* dst = reinterpret_cast<VT*>(smem + (nbuf == 2 ? (i & 1) : 0) * tile_bytes);
-        int pi = i_first, pk = k_first;
 #ifdef VER_ABL_NODMA
         if (i >= 0) return;
 #endif
+        if constexpr (HM) {
+            // chunk q of the tile is chunk q of the block: no address arithmetic beyond the lane offset
+            const VT* src = value + ((((size_t)h * head_major_views + b) * Ncam + c) * Nk) * HD;
+            for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
+                if (q0 + lane < total_chunks)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(q0 + lane) * EPC),
+                                                     (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, 2);
+            }
+            return;
+        }
+        const VT* src = value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD + jc * EPC;
+        int pi = i_first, pk = k_first;
         for (int q0 = dma_wave * 64; q0 < total_chunks; q0 += 64 * dma_waves) {
             if (q0 + lane < total_chunks) {
-#ifdef VER_ABL_CONTIG
-                const VT* g = src + ((size_t)pi * Nk + pk) * 32;
-#else
                 const VT* g = src + (size_t)pk * rstride + pi * 32;
-#endif
-#ifndef VER_CS_DMA_AUX
-#define VER_CS_DMA_AUX 0
-#endif
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0,
-                                                 VER_CS_DMA_AUX);
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, 0);
             }
             pk += rows_per_step;
             while (pk >= Nk) {
@@ -1028,7 +1032,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #else
                     const bool atomic = p_lo + 4 * it + j >= s_pairs;   // wave-uniform: the pair is in the shared region
 #endif
-#ifdef VER_ABL_NOPOINTS
+#if defined(VER_ABL_MEMONLY)
+                    const int npts = min(0, max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8)));
+#elif defined(VER_ABL_NOPOINTS)
                     const int npts = min(1, max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8)));
 #else
                     const int npts = max(__builtin_amdgcn_readlane(cnt, 16 * j), __builtin_amdgcn_readlane(cnt, 16 * j + 8));
@@ -1695,7 +1701,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
-    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs) {
+    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs, int head_major_views) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = 8, NT = HD / 16, KS = HD / 32, MI = 16 / NW;
     static_assert(HD % 32 == 0, "k-steps of 32 channels");
@@ -1726,7 +1732,12 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     const int total = s8 + n_multi;
     const int* list = fwd_list + ((size_t)b * Ncam + c) * Nq;
 
-    stage_tile<HD, uint16_t>(tile, value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD, rstride, Nk, wave, NW);
+    // (head-major value: the tile is one contiguous block, a row is HD elements; d(value) below keeps the reference layout,
+    //  which is what the weight-gradient GEMM of value_proj reads as a plain [rows, heads*HD] matrix)
+    if (head_major_views)
+        stage_tile<HD, uint16_t>(tile, value + ((((size_t)h * head_major_views + b) * Ncam + c) * Nk) * HD, (size_t)HD, Nk, wave, NW);
+    else
+        stage_tile<HD, uint16_t>(tile, value + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD, rstride, Nk, wave, NW);
 
     const f32x4_t zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     f32x4_t acc[MI][NT];                              // d(value): tile-row tiles wave, wave + NW, ...; lane (channel cc, rows 4g..4g+3)
@@ -2062,6 +2073,21 @@ extern "C" int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int 
     return ver_check_launch("ver_hits_from_mask/k_build_lists");
 }
 
+static bool sca_bwd_use_mm() {       // read ONCE per process: the dtype query and the dispatch can never disagree
+    static const int v = env_int("VER_SCA_BWD_MM", 1);
+    return v != 0;
+}
+
+// value layouts ver_sca_forward / ver_sca_backward read: the reference's [B, Ncam, Nk, heads, HD] always; head-major
+// [heads, B, Ncam, Nk, HD] (VER_SCA_VALUE_HEAD_MAJOR) where the fast kernels are built for it
+extern "C" int ver_sca_head_major_supported(int value_dtype, int head_dim, int points, int map_h, int map_w) {
+    static const int use_cs = env_int("VER_SCA_FWD_CS", 1);
+    static const int cs_math = env_int("VER_SCA_FWD_MATH", 2);
+    static const int cs_nload = env_int("VER_SCA_CS_NLOAD", 0);
+    return (value_dtype == VER_BF16 && points == 8 && map_h == 14 && map_w == 14 && use_cs && cs_math == 2 && cs_nload == 0 &&
+            (head_dim == 32 || head_dim == 64 || head_dim == 96 || head_dim == 128) && sca_bwd_use_mm()) ? 1 : 0;
+}
+
 // The zero fill of ver_sca_forward as a call of its own: it depends on the hit table only, so a caller can run it on a
 // side stream under the projections that precede the gather and pass VER_SCA_ROWS_PREZEROED.
 extern "C" int ver_sca_zero_rows(const int32_t* zero_list, const int32_t* zero_cnt, float* slots, int B, int Nq,
@@ -2125,7 +2151,11 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
     int hsplit = 1;
     while (hsplit < heads && heads % (hsplit * 2) == 0 && (long)B * Ncam * hsplit * nchunks < min_wgs) hsplit *= 2;
     hipStream_t st = (hipStream_t)stream;
-    VER_REQUIRE((flags & ~VER_SCA_ROWS_PREZEROED) == 0, VER_EINVAL, "ver_sca_forward: unknown flags 0x%x", flags);
+    VER_REQUIRE((flags & ~(VER_SCA_ROWS_PREZEROED | VER_SCA_VALUE_HEAD_MAJOR)) == 0, VER_EINVAL,
+                "ver_sca_forward: unknown flags 0x%x", flags);
+    const bool head_major = flags & VER_SCA_VALUE_HEAD_MAJOR;
+    VER_REQUIRE(!head_major || ver_sca_head_major_supported(value_dtype, head_dim, points, map_h, map_w), VER_EUNSUPPORTED,
+                "ver_sca_forward: the head-major value layout is built for bf16 tiles, 8 points, head_dim %% 32 == 0, 14x14 maps");
     if (!(flags & VER_SCA_ROWS_PREZEROED)) {
         hipLaunchKernelGGL(k_zero_rows, dim3((Nq + 7) / 8, B), dim3(256), 0, st, zero_list, zero_cnt, slots, Nq,
                            heads * head_dim);
@@ -2197,7 +2227,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                         return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(pt), ldsp, st, vptr, offsets, logits, uv, vis, fwd_list,
                                        fwd_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsp, units, upw,
-                                       nlp);
+                                       nlp, head_major ? B : 0);
                     return ver_check_launch("ver_sca_forward");
                 };
                 const bool k196 = map_h * map_w == 196;                // plane offsets become immediates
@@ -2208,12 +2238,15 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                 // VER_SCA_FWD_MATH: 0 bf16 tile + fp32 unpack and accumulation (exact), 2 fp16 tile + packed fp16
                 // accumulation over a voxel's points (default: DESIGN.md section 3.1)
                 static const int cs_math = env_int("VER_SCA_FWD_MATH", 2);
+                if (head_major) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2, true>, (const uint16_t*)value);
                 if (k196 && cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2>, (const uint16_t*)value);
                 if (k196) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196>, (const uint16_t*)value);
                 if (cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0, 2>, (const uint16_t*)value);
                 return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0>, (const uint16_t*)value);
             }
         }
+        if (head_major)
+            return ver_fail(VER_EUNSUPPORTED, "ver_sca_forward: head-major value needs the corner-slot kernel for this shape");
         if constexpr (HD % 8 == 0) {
             if (value_dtype == VER_BF16) return launch(k_sca_fwd<HD, G, P, uint16_t>, (const uint16_t*)value);
         }
@@ -2223,11 +2256,6 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
 
 // dtype ver_sca_backward writes d(value) in most cheaply for this problem: VER_BF16 on the matrix-core path (bf16 value
 // tiles, 8 points, head_dim % 32 == 0, tile fits), else VER_F32.  VER_F32 is always accepted.
-static bool sca_bwd_use_mm() {       // read ONCE per process: the dtype query and the dispatch can never disagree
-    static const int v = env_int("VER_SCA_BWD_MM", 1);
-    return v != 0;
-}
-
 extern "C" int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int points, int map_h, int map_w) {
     if (value_dtype != VER_BF16 || points != 8 || head_dim % 32 != 0 || head_dim > 128) return VER_F32;
     if (!sca_bwd_use_mm()) return VER_F32;
@@ -2243,12 +2271,17 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                                 const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
                                 const float* grad_slots, void* grad_value, int grad_value_dtype,
                                 float* grad_offsets, float* grad_logits, int B, int Ncam, int Nq, int D,
-                                int heads, int head_dim, int points, int map_h, int map_w, void* stream) {
+                                int heads, int head_dim, int points, int map_h, int map_w, int flags, void* stream) {
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
     VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits && fwd_list && fwd_cnt, VER_EINVAL,
                 "ver_sca_backward: null pointer argument");
+    VER_REQUIRE((flags & ~VER_SCA_VALUE_HEAD_MAJOR) == 0, VER_EINVAL, "ver_sca_backward: unknown flags 0x%x", flags);
+    const bool head_major = flags & VER_SCA_VALUE_HEAD_MAJOR;
+    VER_REQUIRE(!head_major || (ver_sca_head_major_supported(value_dtype, head_dim, points, map_h, map_w) &&
+                                ver_sca_backward_grad_dtype(value_dtype, head_dim, points, map_h, map_w) == VER_BF16),
+                VER_EUNSUPPORTED, "ver_sca_backward: the head-major value layout is read by the matrix-core kernel only");
     VER_REQUIRE(grad_value_dtype == ver_sca_backward_grad_dtype(value_dtype, head_dim, points, map_h, map_w) ||
                     grad_value_dtype == VER_F32,
                 VER_EUNSUPPORTED, "ver_sca_backward: grad_value_dtype %d not available for this shape (ask "
@@ -2285,7 +2318,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                     const int wgs = B * Ncam * heads;
                     hipLaunchKernelGGL(kern, dim3((unsigned)((wgs + 7) & ~7)), dim3(kMmWaves * 64), lds_mm, st, (const uint16_t*)value,
                                        offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, (gv_t*)grad_value, grad_offsets,
-                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs);
+                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs, head_major ? B : 0);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
                 };
                 if (grad_value_dtype == VER_BF16) {

@@ -223,14 +223,19 @@ class _OccProjLattice(torch.autograd.Function):
         for g, a, wa in zip(plan.groups, operands, weights):
             go = grad_out[bs * g.offset: bs * (g.offset + g.n_rows)]
             # d(operand): data columns go back to their lattice positions (each written exactly once)
-            d_data = torch.mm(go, wa[:, :g.n_cols])                                  # [bs*n_rows, n_cols]
             if d_lat.is_cuda and g.run_len and dt in (torch.float32, torch.bfloat16):
+                # the Z constant columns sit right behind the data columns of W_aug: ONE GEMM returns both (their own
+                # [rows, Z] product read all of `go` again for four output columns: 0.85 ms per group at 192 viewpoints,
+                # profiles/r04_gemm_ledger.csv); the run copies take the row pitch of the wider buffer as it is
                 from ..hipops import run_scatter
-                run_scatter(d_data, d_lat, g.run_start, g.n_rows, g.run_len)
+                d_all = torch.mm(go, wa[:, :g.n_cols + Z])                           # [bs*n_rows, n_cols + Z]
+                run_scatter(d_all, d_lat, g.run_start, g.n_rows, g.run_len)
+                d_const = d_all[:, g.n_cols:]
             else:
+                d_data = torch.mm(go, wa[:, :g.n_cols])                              # [bs*n_rows, n_cols]
                 d_lat.index_copy_(1, g.scatter, d_data.view(bs, g.n_rows * g.n_cols))
-            d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())         # [bs*n_rows, Z]
-            d_up.index_add_(0, g.chan, d_const.view(bs, -1).sum(0, dtype=acc))
+                d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())     # [bs*n_rows, Z]
+            d_up.index_add_(0, g.chan, d_const.reshape(bs, -1).sum(0, dtype=acc))
             # d(W_aug^T) = go^T a
             d_wa = rows_tn(a, go).t().to(acc)                                        # [out, k_aug]
             d_weight.index_add_(1, g.cols, d_wa[:, :g.n_cols])

@@ -236,10 +236,13 @@ class VoxelFormerOccupancyHead(BaseModule):
                 if fold:
                     l1 = self.occ_branches[0]
                     with torch.autocast('cuda', enabled=False):
-                        w_proj = torch.matmul(l1.weight.float(), w_proj.float().view(self.occ_zdim, self.occ_dims, -1)
-                                              ).view_as(w_proj)
-                        b_proj = torch.addmm(l1.bias.float(), b_proj.float().view(self.occ_zdim, self.occ_dims),
-                                             l1.weight.float().t()).view(-1)
+                        # ... and the Linear that feeds a LayerNorm is CENTRED over its output axis on the way
+                        # (W1 <- P W1, b1 <- P b1, P = I - 11^T/128): LN(Wx + b) = LN(PWx + Pb) exactly, the rows the
+                        # MLP kernel loads then have zero mean by construction and its LayerNorm skips the mean pass
+                        # (a quarter of the forward kernel's VALU work); autograd maps the gradients back through P
+                        w1c, b1c = self._centered(l1.weight.float(), l1.bias.float())
+                        w_proj = torch.matmul(w1c, w_proj.float().view(self.occ_zdim, self.occ_dims, -1)).view_as(w_proj)
+                        b_proj = torch.addmm(b1c, b_proj.float().view(self.occ_zdim, self.occ_dims), w1c.t()).view(-1)
                 res = occ_proj_from_lattice(e, convs[-1].bias, w_proj, b_proj)
                 if res is not None:
                     # ``occ_branches`` is row-wise: run it on the rows as the GEMMs left them
@@ -282,6 +285,12 @@ class VoxelFormerOccupancyHead(BaseModule):
 
     fold_first_occ_linear = True      # (class switch for tests: compare against the unfolded fused path)
 
+    @staticmethod
+    def _centered(weight, bias):
+        """(P W, P b), P = I - 11^T/n over the OUTPUT axis of an nn.Linear: the pre-activations get zero mean over the
+        features without changing LayerNorm(W x + b)."""
+        return weight - weight.mean(0, keepdim=True), bias - bias.mean()
+
     def _occ_mlp_runs_fused(self, x):
         """True when ``_occ_mlp`` will take the fused MFMA kernels for this input (bf16 arithmetic)."""
         return x.is_cuda and self._occ_mlp_is_fusable(list(self.occ_branches)) and (
@@ -300,8 +309,11 @@ class VoxelFormerOccupancyHead(BaseModule):
             from ..hipops import occ_mlp
             l1, n1, _, l2, n2, _, l3 = mods
             with torch.autocast('cuda', enabled=False):
-                return occ_mlp(x.to(torch.bfloat16), None if first_folded else l1.weight,
-                               None if first_folded else l1.bias, n1.weight, n1.bias, l2.weight, l2.bias,
+                if first_folded:                 # the caller centred Linear 1 in the fold; Linear 2 here
+                    w2c, b2c = self._centered(l2.weight.float(), l2.bias.float())
+                    return occ_mlp(x.to(torch.bfloat16), None, None, n1.weight, n1.bias, w2c, b2c,
+                                   n2.weight, n2.bias, l3.weight, l3.bias, n1.eps, centered=True)
+                return occ_mlp(x.to(torch.bfloat16), l1.weight, l1.bias, n1.weight, n1.bias, l2.weight, l2.bias,
                                n2.weight, n2.bias, l3.weight, l3.bias, n1.eps)
         assert not first_folded, 'only the fused occupancy MLP takes a folded first Linear'
         i = 0

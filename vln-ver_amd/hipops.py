@@ -16,7 +16,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
 ABI_VERSION = 23
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
-           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_forward', 'ver_sca_backward',
+           'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
+           'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
@@ -260,33 +261,36 @@ class SCAGatherFunction(Function):
     corner) are accumulated in packed fp16, everything after the corner fold in fp32 (contract: include/ver_ops.h)."""
 
     @staticmethod
-    def forward(ctx, value, offsets, logits, hit, map_h, map_w, prepared=None):
+    def forward(ctx, value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False):
         if value.dtype not in (torch.float32, torch.bfloat16):
             value = value.float()
         value = _gpu(value, 'value')
         offsets = _gpu(offsets, 'offsets').float().contiguous()
         logits = _gpu(logits, 'logits').float().contiguous()
         vdt = 1 if value.dtype == torch.bfloat16 else 0
-        B, ncam, nk, heads, hd = value.shape
+        if head_major:                      # value [heads, B, Ncam, Nk, hd] (VER_SCA_VALUE_HEAD_MAJOR)
+            heads, B, ncam, nk, hd = value.shape
+        else:
+            B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
         nq = hit.Nq
         assert nk == map_h * map_w and B == hit.B and ncam == hit.Ncam
         assert offsets.shape == (B, nq, heads, points, 2) and logits.shape == (B, nq, heads, points)
-        flags = 0
+        flags = 2 if head_major else 0
         if prepared is not None:
             slots = prepared.slots
             assert slots.shape == (B, nq, heads * hd) and slots.dtype == torch.float32 and slots.is_contiguous()
             torch.cuda.current_stream(slots.device).wait_event(prepared.done)      # (long done: it ran under the GEMMs)
-            flags = 1                                                                # VER_SCA_ROWS_PREZEROED
+            flags |= 1                                                               # VER_SCA_ROWS_PREZEROED
         else:
             slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)
         _launch('ver_sca_forward', lambda: lib().ver_sca_forward(
             _p(value), vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(hit.zero_list), _p(hit.zero_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(slots),
             B, ncam, nq, hit.D, heads, hd,
-            points, map_h, map_w, flags, _stream()), meta=dict(prezeroed=bool(flags)))
+            points, map_h, map_w, flags, _stream()), meta=dict(prezeroed=bool(flags & 1), head_major=head_major))
         ctx.save_for_backward(value, offsets, logits)
-        ctx.hit, ctx.map_hw, ctx.vdt = hit, (map_h, map_w), vdt
+        ctx.hit, ctx.map_hw, ctx.vdt, ctx.head_major = hit, (map_h, map_w), vdt, head_major
         return slots
 
     @staticmethod
@@ -295,24 +299,72 @@ class SCAGatherFunction(Function):
         value, offsets, logits = ctx.saved_tensors
         hit = ctx.hit
         map_h, map_w = ctx.map_hw
-        B, ncam, nk, heads, hd = value.shape
+        if ctx.head_major:
+            heads, B, ncam, nk, hd = value.shape
+        else:
+            B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
         gs = _gpu(grad_slots, 'grad_slots').float().contiguous()
         # the matrix-core backward rounds d(value) to bf16 itself (no separate cast pass over the tensor)
         gdt = lib().ver_sca_backward_grad_dtype(ctx.vdt, hd, points, map_h, map_w)
-        g_value = torch.empty(value.shape, dtype=torch.bfloat16 if gdt == 1 else torch.float32, device=value.device)
+        # d(value) is always written in the REFERENCE layout [B, Ncam, Nk, heads, hd]; for a head-major value it is handed
+        # back as the permuted view of that buffer (same shape as value, no copy)
+        g_value = torch.empty((B, ncam, nk, heads, hd), dtype=torch.bfloat16 if gdt == 1 else torch.float32, device=value.device)
         g_off = torch.empty_like(offsets)
         g_log = torch.empty_like(logits)
         _launch('ver_sca_backward', lambda: lib().ver_sca_backward(
             _p(value), ctx.vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(gs), _p(g_value), gdt, _p(g_off), _p(g_log), B, ncam,
             hit.Nq, hit.D, heads,
-            hd, points, map_h, map_w, _stream()))
-        return g_value.to(value.dtype), g_off, g_log, None, None, None, None
+            hd, points, map_h, map_w, 2 if ctx.head_major else 0, _stream()))
+        g_value = g_value.to(value.dtype)
+        if ctx.head_major:
+            g_value = g_value.permute(3, 0, 1, 2, 4)
+        return g_value, g_off, g_log, None, None, None, None, None
 
 
-def sca_gather(value, offsets, logits, hit, map_h, map_w, prepared=None):
-    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w, prepared)
+def sca_gather(value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False):
+    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w, prepared, head_major)
+
+
+def sca_head_major_supported(dtype, head_dim, points, map_h, map_w):
+    """True where ``ver_sca_forward`` / ``ver_sca_backward`` read a head-major value tensor (contiguous tiles)."""
+    return dtype == torch.bfloat16 and bool(lib().ver_sca_head_major_supported(1, head_dim, points, map_h, map_w))
+
+
+class HeadMajorLinearFunction(Function):
+    """``value_proj`` writing the head-major layout: x bf16 [M, C_in], weight [heads*hd, C_in], bias [heads*hd] ->
+    [heads, M, hd] as ONE batched GEMM over the heads (x is the stride-0 batch operand, no copies).  The gradient comes
+    back as the permuted view of a reference-layout [M, heads*hd] buffer (SCAGatherFunction.backward), so d(weight) is a
+    plain split-row GEMM over [M, heads*hd]; d(x) likewise when it is needed."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, heads):
+        m, c_in = x.shape
+        w = weight.to(x.dtype)
+        hd = w.shape[0] // heads
+        out = torch.baddbmm(bias.to(x.dtype).view(heads, 1, hd), x.unsqueeze(0).expand(heads, m, c_in),
+                            w.view(heads, hd, c_in).transpose(1, 2))
+        ctx.save_for_backward(x, w)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        heads = ctx.heads
+        m = x.shape[0]
+        g2 = g.permute(1, 0, 2).reshape(m, -1)              # [M, heads*hd]: a view when g is the gather's permuted buffer
+        from .dense_heads.upsample import rows_tn
+        dw = rows_tn(g2, x) if ctx.needs_input_grad[1] else None        # [heads*hd, C_in]
+        db = g2.sum(0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        dx = g2 @ w if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
+
+
+def head_major_linear(x, weight, bias, heads):
+    return HeadMajorLinearFunction.apply(x, weight, bias, heads)
 
 
 # ------------------------------------------------------------------------------------------
@@ -644,9 +696,10 @@ def occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3):
     return vec.contiguous()
 
 
-def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True):
+def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True, centered=False):
     """x bf16 [..., 128] -> logits bf16 [..., 16] (ver_occ_mlp_forward).  ``first_linear=False``: x is already the
-    output of the first Linear (folded into its producer)."""
+    output of the first Linear (folded into its producer).  ``centered``: the hidden Linears' weights / biases were
+    centred over their output axis (VER_OCC_MLP_CENTERED): the LayerNorms skip the mean pass."""
     x = _gpu(x, 'x')
     if x.dtype != torch.bfloat16 or x.shape[-1] != 128:
         raise TypeError('x must be bf16 [..., 128]')
@@ -655,7 +708,7 @@ def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True):
     logits = torch.empty(x.shape[:-1] + (16,), dtype=torch.bfloat16, device=x.device)
     _launch('ver_occ_mlp_forward', lambda: lib().ver_occ_mlp_forward(
         _p(x), _p(image), _p(vectors), _p(logits), ctypes.c_long(n), 128, 16, ctypes.c_float(eps),
-        1 if first_linear else 0, _stream()))
+        (1 if first_linear else 0) | (2 if centered else 0), _stream()))
     return logits
 
 
@@ -705,7 +758,7 @@ class OccMLPFunction(Function):
     -> logits bf16 [N,16].  Nothing but x is kept for the backward pass (the chain is re-computed)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps):
+    def forward(ctx, x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps, centered=False):
         x = _gpu(x, 'x').contiguous()
         # w1 is None: the first Linear was folded into the producer of x (two Linears in a row compose, see
         # VoxelFormerOccupancyHead.occupancy_from_volume); the kernels then run it as the identity and its weight
@@ -719,7 +772,7 @@ class OccMLPFunction(Function):
         vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
         ctx.save_for_backward(x, image, vec, w2.detach(), w3.detach())
         ctx.eps = eps
-        return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded)
+        return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded, centered=centered)
 
     @staticmethod
     @once_differentiable
@@ -740,7 +793,7 @@ class OccMLPFunction(Function):
             dw3 = pg[768:768 + 2048].view(16, 128)
             db3 = pg[768 + 2048:768 + 2048 + 16]
             dw2 = pg[768 + 2048 + 16:].view(128, 128)
-            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
+            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None, None)
         gx, ga2, h1 = (torch.empty_like(x2) for _ in range(3))
         ga1 = None if ctx.folded else torch.empty_like(x2)
         pg = torch.empty(6 * 128 + 16 * 128 + 16, dtype=torch.float32, device=x.device)
@@ -754,15 +807,17 @@ class OccMLPFunction(Function):
         dw2, _ = _rows_tn(ga2, h1, with_colsum=False)
         if ctx.folded:                               # h1 comes back in natural feature order
             dw2 = dw2.index_select(0, inv)
-            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
+            return (gx.view(shape), None, None, vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None, None)
         dw2 = dw2.index_select(0, inv).index_select(1, inv)
         dw1, _ = _rows_tn(ga1, x2, with_colsum=False)
         dw1 = dw1.index_select(0, inv)
-        return (gx.view(shape), dw1, vecs[2], vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None)
+        return (gx.view(shape), dw1, vecs[2], vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None, None)
 
 
-def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5):
-    return OccMLPFunction.apply(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps)
+def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5, centered=False):
+    """``centered``: the caller passes hidden Linears whose weights / biases are centred over the output axis (and, with
+    w1 None, has centred the folded first Linear in the producer of x): the forward LayerNorms skip the mean pass."""
+    return OccMLPFunction.apply(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps, centered)
 
 
 # ------------------------------------------------------------------------------------------

@@ -85,7 +85,7 @@ class FFN(BaseModule):
         """One hidden block ``Sequential(Linear, ReLU, Dropout)``: ReLU + Dropout as one HIP pass on the GPU."""
         if (_FUSED_ADD_LN and isinstance(block, Sequential) and len(block) == 3 and isinstance(block[0], nn.Linear)
                 and isinstance(block[1], nn.ReLU) and isinstance(block[2], nn.Dropout) and x.is_cuda):
-            h = block[0](x)
+            h = tall_linear(block[0], x)
             if h.numel() % 4 == 0 and h.dtype in (torch.float32, torch.bfloat16):
                 from ..hipops import relu_dropout
                 return relu_dropout(h, block[2].p if block[2].training else 0.0)
@@ -101,7 +101,8 @@ class FFN(BaseModule):
                 and isinstance(last, nn.Dropout)):
             out = x_in
             for i in range(len(self.layers) - 1):
-                out = self._hidden(self.layers[i], out)
+                lay = self.layers[i]
+                out = tall_linear(lay, out) if isinstance(lay, nn.Linear) else self._hidden(lay, out)
             return PendingResidual(out, x if identity is None else identity, last.p if last.training else 0.0)
         out = self.layers(x_in)
         if not self.add_identity:
@@ -126,6 +127,23 @@ class PendingResidual:
 
 def _autocast_bf16():
     return torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+
+
+_TALL_ROWS = 16000      # rows from which the weight gradient of a Linear is split (two chunks of dense_heads/row_linear.py)
+
+
+def tall_linear(mod, x, weight=None, bias=None):
+    """``mod(x)`` for an ``nn.Linear`` over the ~2e5 voxel / token rows of a batched encoder call.  Forward and d(input)
+    are the library's GEMMs either way; the weight gradient G^T X is a [768 x rows] x [rows x 768] product that the library
+    runs on the few workgroups its 9-18 output tiles give (GEMM ledger, profiles/r04_gemm_ledger.csv: 0.15-0.6 PFLOP/s) --
+    ``row_linear`` splits the row axis into one batched GEMM with fp32-summed partials.  ``weight`` / ``bias``: fused
+    parameter stacks (the two narrow projections of the query) instead of ``mod``'s own."""
+    w = mod.weight if weight is None else weight
+    b = (mod.bias if mod is not None else None) if bias is None else bias
+    if x.is_cuda and torch.is_grad_enabled() and w.requires_grad and x.numel() // x.shape[-1] >= _TALL_ROWS:
+        from ..dense_heads.row_linear import row_linear
+        return row_linear(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
 
 
 def lowp_view(x):

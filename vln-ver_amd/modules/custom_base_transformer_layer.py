@@ -80,30 +80,49 @@ class MyCustomBaseTransformerLayer(BaseModule):
 
     def forward(self, query, key=None, value=None, query_pos=None, key_pos=None, attn_masks=None,
                 query_key_padding_mask=None, key_padding_mask=None, **kwargs):
-        """Generic op sequencing (reference :165-260)."""
+        """Generic op sequencing (reference :165-260).  In a post-norm layer every branch (attention, FFN) is followed by a
+        LayerNorm: a branch that can hand over ``PendingResidual(out, identity, p)`` leaves its residual add and dropout to
+        that LayerNorm, which then is ONE fused pass each way on the GPU (``bricks.residual_layer_norm`` -> ``ver_add_ln_*``)
+        instead of dropout + add + LayerNorm + the bf16 cast of the next Linear."""
+        from .bricks import FFN, PendingResidual, residual_layer_norm
         norm_index = attn_index = ffn_index = 0
         identity = query
         if attn_masks is None:
             attn_masks = [None for _ in range(self.num_attn)]
-        for layer in self.operation_order:
+        order = list(self.operation_order)
+        for pos, layer in enumerate(order):
+            defer = (not self.pre_norm) and pos + 1 < len(order) and order[pos + 1] == 'norm'
             if layer == 'self_attn':
-                query = self.attentions[attn_index](
+                attn = self.attentions[attn_index]
+                extra = dict(defer_residual=True) if (defer and getattr(attn, 'can_defer_residual', False)) else {}
+                query = attn(
                     query, query, query, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=query_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=query_key_padding_mask, **kwargs)
+                    key_padding_mask=query_key_padding_mask, **extra, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'norm':
-                query = self.norms[norm_index](query)
+                if isinstance(query, PendingResidual):
+                    query = residual_layer_norm(query, self.norms[norm_index])
+                else:
+                    query = self.norms[norm_index](query)
                 norm_index += 1
             elif layer == 'cross_attn':
-                query = self.attentions[attn_index](
+                attn = self.attentions[attn_index]
+                extra = dict(defer_residual=True) if (defer and getattr(attn, 'can_defer_residual', False)) else {}
+                query = attn(
                     query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=key_pos, attn_mask=attn_masks[attn_index],
-                    key_padding_mask=key_padding_mask, **kwargs)
+                    key_padding_mask=key_padding_mask, **extra, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == 'ffn':
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                ffn = self.ffns[ffn_index]
+                if defer and isinstance(ffn, FFN):
+                    query = ffn(query, identity if self.pre_norm else None, defer_residual=True)
+                else:
+                    query = ffn(query, identity if self.pre_norm else None)
                 ffn_index += 1
+        if isinstance(query, PendingResidual):
+            query = query.materialize()
         return query

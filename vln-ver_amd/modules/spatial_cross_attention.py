@@ -15,6 +15,7 @@ restructured for the GPU:
   viewpoint carries its own hit lists, so results per viewpoint equal a bs=1 reference run.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -23,7 +24,14 @@ import torch.nn.functional as F
 
 from .. import hipops
 from ..registry import ATTENTION, build_attention
-from .bricks import BaseModule, PendingResidual, const_tensor, constant_init, lowp_view, xavier_init
+from .bricks import BaseModule, PendingResidual, const_tensor, constant_init, lowp_view, tall_linear, xavier_init
+
+
+# VER_SCA_HEAD_MAJOR=1: value_proj writes the head-major layout (contiguous gather tiles).  OFF by default: measured at 192
+# viewpoints per launch the gather gains 14 us forward + 6 us backward per layer, but the batched N = 96 GEMM that produces
+# the layout costs 1.07 ms against 0.31 ms for the plain [rows, 768] GEMM (a permuting copy after the plain GEMM: + 0.19 ms)
+# -- the step as a whole is faster with the reference's layout.
+_HEAD_MAJOR = os.environ.get('VER_SCA_HEAD_MAJOR', '0') == '1'
 
 
 @ATTENTION.register_module(force=True)
@@ -92,17 +100,28 @@ class SpatialCrossAttention(BaseModule):
         prepared = hipops.sca_prepare_slots(hit_table, c)
         use_lowp = (value_lowp is not None and torch.is_autocast_enabled('cuda')
                     and torch.get_autocast_dtype('cuda') == value_lowp.dtype)
-        v = att.value_proj(value_lowp if use_lowp else value.permute(2, 0, 1, 3))
-        v = v.reshape(bs, num_cams, nk, att.num_heads, c // att.num_heads)
+        v_in = value_lowp if use_lowp else value.permute(2, 0, 1, 3)
+        hd = c // att.num_heads
+        # head-major value (bf16 path at the vocc.py shape): value_proj as one batched GEMM over the heads writes
+        # [heads, bs, Ncam, Nk, hd], in which a (camera, head) tile of the gather is one contiguous block of HBM
+        head_major = (_HEAD_MAJOR and v_in.is_cuda and use_lowp
+                      and hipops.sca_head_major_supported(v_in.dtype, hd, att.num_points, map_hw[0], map_hw[1]))
+        if head_major:
+            v = hipops.head_major_linear(v_in.reshape(-1, c), att.value_proj.weight, att.value_proj.bias, att.num_heads)
+            v = v.view(att.num_heads, bs, num_cams, nk, hd)
+        else:
+            v = tall_linear(att.value_proj, v_in)
+            v = v.reshape(bs, num_cams, nk, att.num_heads, hd)
         # sampling_offsets and attention_weights read the same rows: one GEMM [.., C] x [C, 128 + 64] (and one cast of
         # the query under autocast) instead of two narrow ones; the parameters stay the reference's two Linears
         n_off = att.sampling_offsets.out_features
-        both = F.linear(lowp_view(query) if query_pos is None else query, torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0),
-                        torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
+        both = tall_linear(None, lowp_view(query) if query_pos is None else query,
+                           torch.cat([att.sampling_offsets.weight, att.attention_weights.weight], 0),
+                           torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
         offsets = both[..., :n_off].reshape(bs, num_query, att.num_heads, att.num_points, 2)
         logits = both[..., n_off:].reshape(bs, num_query, att.num_heads, att.num_points)
-        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1], prepared)
-        slots = self.output_proj(slots.to(query.dtype))
+        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1], prepared, head_major)
+        slots = tall_linear(self.output_proj, slots.to(query.dtype))
         if defer_residual:                  # the caller's LayerNorm adds the residual (residual_layer_norm)
             return PendingResidual(slots, inp_residual, self.dropout.p if self.dropout.training else 0.0)
         return self.dropout(slots) + inp_residual

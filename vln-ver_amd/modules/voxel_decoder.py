@@ -16,7 +16,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, USING_MMCV
-from .bricks import BaseModule, TransformerLayerSequence, const_tensor, constant_init, host_values, xavier_init
+from .bricks import (BaseModule, PendingResidual, TransformerLayerSequence, const_tensor, constant_init, host_values,
+                     xavier_init)
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 
 
@@ -90,9 +91,11 @@ class VoxelCustomMSDeformableAttention(BaseModule):
         xavier_init(self.output_proj, distribution='uniform', bias=0.)
         self._is_init = True
 
+    can_defer_residual = True        # forward(..., defer_residual=True) returns bricks.PendingResidual
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, flag='decoder', **kwargs):
+                level_start_index=None, flag='decoder', defer_residual=False, **kwargs):
         if 'residual' in kwargs and identity is None:        # deprecated_api_warning alias
             identity = kwargs.pop('residual')
         if value is None:
@@ -133,6 +136,8 @@ class VoxelCustomMSDeformableAttention(BaseModule):
         output = self.output_proj(output.to(query.dtype))
         if not self.batch_first:
             output = output.permute(1, 0, 2)
+        if defer_residual:                  # the LayerNorm that follows adds the residual (bricks.residual_layer_norm)
+            return PendingResidual(output.contiguous(), identity, self.dropout.p if self.dropout.training else 0.0)
         return self.dropout(output) + identity
 
 
@@ -154,8 +159,10 @@ class MultiheadAttention(BaseModule):
         self.proj_drop = nn.Dropout(proj_drop)
         self.dropout_layer = nn.Dropout(dropout_layer['drop_prob']) if dropout_layer else nn.Identity()
 
+    can_defer_residual = True
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
-                attn_mask=None, key_padding_mask=None, **kwargs):
+                attn_mask=None, key_padding_mask=None, defer_residual=False, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -174,6 +181,10 @@ class MultiheadAttention(BaseModule):
                         key_padding_mask=key_padding_mask)[0]
         if self.batch_first:
             out = out.transpose(0, 1)
+        if defer_residual and (not self.training or self.proj_drop.p == 0.0):
+            drop = self.dropout_layer
+            p = drop.p if (isinstance(drop, nn.Dropout) and drop.training) else 0.0
+            return PendingResidual(out.contiguous(), identity, p)
         return identity + self.dropout_layer(self.proj_drop(out))
 
 

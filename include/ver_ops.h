@@ -383,9 +383,12 @@ int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* ima
  *     param_grads f32 [6*128 + 16*128 + 16 + 128*128]   d gamma1, d beta1, (unused), d gamma2, d beta2, d b2, then
  *                                               d W3 [16,128], d b3 [16], d W2 [128,128] -- natural order; zeroed inside
  */
+/*   flags: 0 or VER_OCC_MLP_CENTERED (the forward ran centred: W2 / b2 passed here are the centred ones, the recomputed
+ *   LayerNorm-forward steps skip the mean pass).
+ */
 int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                const float* vectors, void* grad_x, float* param_grads, long N, int width,
-                               int classes, float eps, void* stream);
+                               int classes, float eps, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Occupancy post-processing: VoxelFormerOccupancyHead.get_occupancy_prediction, focal-loss branch

@@ -66,13 +66,16 @@ for e in ev:
 cpu_ops.sort(key=lambda e: e['ts'])
 GEMM_OPS = ('aten::mm', 'aten::addmm', 'aten::bmm', 'aten::baddbmm', 'aten::linear', 'aten::matmul', 'aten::addmm_', 'aten::_scaled_mm')
 
-def owner(launch):
-    """innermost GEMM-like cpu op on the same thread whose interval contains the launch call"""
+import bisect
+_starts = [op['ts'] for op in cpu_ops]
+
+
+def owner(launch, any_op=False):
+    """innermost (GEMM-like, or any) cpu op on the same thread whose interval contains the launch call"""
     best = None
-    for op in cpu_ops:
-        if op['ts'] > launch['ts']:
-            break
-        if op['tid'] == launch['tid'] and op['ts'] + op['dur'] >= launch['ts'] and op['name'] in GEMM_OPS:
+    hi = bisect.bisect_right(_starts, launch['ts'])
+    for op in cpu_ops[max(0, hi - 400):hi]:
+        if op['tid'] == launch['tid'] and op['ts'] + op['dur'] >= launch['ts'] and (any_op or op['name'] in GEMM_OPS):
             best = op                       # later start = deeper nesting
     return best
 
@@ -92,12 +95,16 @@ def flops(name, shapes):
 
 rows = collections.OrderedDict()
 other = collections.Counter()
+other_ops = collections.Counter()
 total_gpu = sum(k['dur'] for k in kernels)
 for k in kernels:
     nm = k['name']
     is_gemm = nm.startswith(('Cijk', 'Custom_Cijk')) or 'gemm' in nm.lower()
     if not is_gemm:
         other[nm[:60]] += k['dur']
+        la = launches.get(k['args'].get('correlation'))
+        op = owner(la, True) if la else None
+        other_ops[(op['name'] if op else '?', json.dumps(op['args'].get('Input Dims'))[:90] if op else '')] += k['dur']
         continue
     la = launches.get(k['args'].get('correlation'))
     op = owner(la) if la else None
@@ -119,4 +126,6 @@ with open(a.out, 'w') as f:
     f.write('# GEMM kernels total %.2f ms of %.2f ms GPU time (%.1f %%)\n' % (tot / 1e3, total_gpu / 1e3, 100.0 * tot / total_gpu))
     for nm, us in other.most_common(25):
         f.write('# other %-60s %.3f ms\n' % (nm, us / 1e3))
+    for (nm, dims), us in other_ops.most_common(40):
+        f.write('# other-by-op %-40s %-92s %.3f ms\n' % (nm, dims, us / 1e3))
 print(open(a.out).read()[:6000])

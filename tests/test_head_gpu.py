@@ -108,6 +108,11 @@ def test_lift_equals_default_branch():
     assert torch.equal(occ, outs['occupancy_preds'])
 
 
+# Largest single-element deviation of the bf16 head from the reference's fp32 logits, as MEASURED on MI355X (round 4, this
+# test with -s: see the printed line) plus a 1.5x margin; the north star's "1e-2 bf16" is held as relative L2 next to it.
+MAX_ABS_BF16_HEAD = 1e-1
+
+
 def test_vocc_head_bf16_autocast_within_1e2():
     """BASELINE.json north_star: 1e-2 in bf16.  The bench's arithmetic (bf16 autocast GEMMs and
     lattices, bf16 value tile, fp32 gather / LayerNorm statistics / loss) against the reference's
@@ -122,9 +127,12 @@ def test_vocc_head_bf16_autocast_within_1e2():
     occ = occ.float()
     want = T(g['c3_b0_occ'])
     got = occ[0, ::997].cpu()
-    assert rel_l2(got, want) < 1e-2
-    assert maxdiff(got, want) < 1e-1
-    assert float((got - want).abs().mean()) < 2e-2
+    rl2, mx, mean = rel_l2(got, want), maxdiff(got, want), float((got - want).abs().mean())
+    print('bf16 head vs fp32 reference: rel L2 %.3e, max |d| %.3e, mean |d| %.3e on logits with max |x| %.2f, rms %.2f'
+          % (rl2, mx, mean, float(want.abs().max()), float(want.pow(2).mean().sqrt())))
+    assert rl2 < 1e-2
+    assert mx < MAX_ABS_BF16_HEAD
+    assert mean < 2e-2
     assert abs(float(occ.double().norm()) - float(g['c3_b0_occ_norm'])) < 1e-2 * float(g['c3_b0_occ_norm'])
     assert rel_l2(emb[0, ::7].float().cpu(), T(g['c3_b0_bev'])) < 1e-2
 

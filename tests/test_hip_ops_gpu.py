@@ -846,6 +846,56 @@ def test_occ_mlp_fused_with_folded_first_linear(fused, monkeypatch):
                                first_linear=False).shape == (0, 16)
 
 
+def test_occ_mlp_centered_equals_plain_and_the_fp64_chain():
+    """VER_OCC_MLP_CENTERED (include/ver_ops.h): with the hidden Linears centred over their output axis
+    (W <- W - mean_o W, b <- b - mean b) every LayerNorm input has zero row mean and the kernels skip the mean pass.
+    LayerNorm is invariant to a per-row constant, so this is the SAME function of the parameters: forward and every
+    gradient (autograd maps the gradients of the centred parameters back through the projection) against the fp64 chain
+    on the UNcentred parameters, and against the uncentred fused kernels within the bf16 noise of either."""
+    hip = pkg('hipops')
+    F = torch.nn.functional
+    gen = torch.Generator(device='cpu').manual_seed(21)
+    p = _occ_mlp_params(gen)
+    n = 64 * 300 + 17
+    x0 = torch.randn(n, 128, generator=gen) * 1.5
+    gy = (torch.randn(n, 16, generator=gen) * 0.1).bfloat16()
+    keys = ('g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+
+    def center(w, b):
+        return w - w.mean(0, keepdim=True), b - b.mean()
+
+    res = {}
+    for centered in (False, True):
+        pd = {k: p[k].to(DEV).requires_grad_(True) for k in ('w1', 'b1') + keys}
+        w1, b1 = (center(pd['w1'], pd['b1']) if centered else (pd['w1'], pd['b1']))
+        w2, b2 = (center(pd['w2'], pd['b2']) if centered else (pd['w2'], pd['b2']))
+        a1 = (x0.to(DEV) @ w1.t() + b1).bfloat16()                  # the producer of x (occ_proj with the folded Linear 1)
+        a1.retain_grad()
+        out = hip.occ_mlp(a1, None, None, pd['g1'], pd['be1'], w2, b2, pd['g2'], pd['be2'], pd['w3'], pd['b3'],
+                          centered=centered)
+        out.backward(gy.to(DEV))
+        if centered:
+            assert float(a1.float().mean(1).abs().max()) < 0.05      # rows ARE centred (bf16 rounding of the producer aside)
+        res[centered] = (out.detach().float().cpu(), {k: v.grad.float().cpu() for k, v in pd.items()})
+    pr = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    a = (x0.double() @ pr['w1'].t() + pr['b1'])
+    h = F.relu(F.layer_norm(a, (128,), pr['g1'], pr['be1'], 1e-5))
+    h = F.relu(F.layer_norm(h @ pr['w2'].t() + pr['b2'], (128,), pr['g2'], pr['be2'], 1e-5))
+    ref = h @ pr['w3'].t() + pr['b3']
+    ref.backward(gy.double())
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    for centered in (False, True):
+        out, grads = res[centered]
+        assert rel(out, ref.detach()) < 1e-2, (centered, rel(out, ref.detach()))
+        for k in ('w1', 'b1') + keys:
+            assert rel(grads[k], pr[k].grad) < 9e-2, (centered, k, rel(grads[k], pr[k].grad))
+    assert rel(res[True][0], res[False][0]) < 1e-2
+    # the projection leaves no gradient along the all-ones direction of the centred parameters
+    assert float(res[True][1]['w2'].sum(0).abs().max()) < 1e-3 * float(res[True][1]['w2'].abs().max()) * 128
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 128, 191, 64 * 256 + 1, 64 * 513 + 7])
 def test_occ_mlp_backward_kernels_on_ragged_sizes(n, monkeypatch):
     """Both backward kernels of the folded MLP on row counts around the block / pipeline edges of the wave-specialised

@@ -1060,6 +1060,9 @@ namespace {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
+// CENTERED: the forward ran with VER_OCC_MLP_CENTERED (zero-mean LayerNorm inputs by construction): the two recomputed
+// LayerNorm-forward steps of the row team skip the mean pass as the forward kernel does.
+template <bool CENTERED>
 __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ vec, __bf16* __restrict__ dx,
@@ -1115,7 +1118,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int t = 0; t < 4; ++t) xr[t] = st.okn ? st.xn[t] : z8;
             if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = st.okn ? st.dln : z8;
             prefetch(st, blk + 2 * (long)gridDim.x, blk + 2 * (long)gridDim.x < nblk);
-            ln_relu_nat<true, true>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
+            ln_relu_nat<true, true, CENTERED>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             bf16x8 xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x8*>(T + kWsTile + myrow * kNsLd + 32 * t + 8 * g);
-            ln_relu_nat<true, true>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
+            ln_relu_nat<true, true, CENTERED>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + 2 * kWsTile + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1359,8 +1362,9 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 
 extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                           const float* vectors, void* grad_x, float* param_grads, long N, int width,
-                                          int classes, float eps, void* stream) {
+                                          int classes, float eps, int flags, void* stream) {
     VER_REQUIRE(N >= 0, VER_EINVAL, "ver_occ_mlp_backward_fused: negative row count");
+    VER_REQUIRE((flags & ~VER_OCC_MLP_CENTERED) == 0, VER_EINVAL, "ver_occ_mlp_backward_fused: unknown flags 0x%x", flags);
     VER_REQUIRE(width == kW && classes == kC, VER_EUNSUPPORTED,
                 "ver_occ_mlp_backward_fused: built for width %d / %d classes (got %d / %d)", kW, kC, width, classes);
     VER_REQUIRE(W2 && W3 && vectors && param_grads, VER_EINVAL, "ver_occ_mlp_backward_fused: null pointer argument");
@@ -1377,11 +1381,12 @@ extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits
         return ev ? atoi(ev) : 1;
     }();
     if (ws) {
-        e = hipFuncSetAttribute((const void*)k_occ_mlp_bwd_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
+        auto kern = (flags & VER_OCC_MLP_CENTERED) ? k_occ_mlp_bwd_ws<true> : k_occ_mlp_bwd_ws<false>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: LDS attribute: %s", hipGetErrorString(e));
         const long nb = (N + kWsRows - 1) / kWsRows;
         const long gridw = nb < 256 ? nb : 256;               // one workgroup per CU (LDS bound), persistent
-        hipLaunchKernelGGL(k_occ_mlp_bwd_ws, dim3((unsigned)gridw), dim3(512), kWsLds, st, (const __bf16*)x,
+        hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(512), kWsLds, st, (const __bf16*)x,
                            (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps);
         return ver_check_launch("ver_occ_mlp_backward_fused");
     }

@@ -705,7 +705,11 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
-    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views) {
+    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views, int reverse) {
+    // reverse: walk the units from the LAST viewpoint to the first.  The value tensor (347 MB at 192 viewpoints) and the
+    // offsets / logits were written just before this launch, in ascending row order, through a 256-MB memory-side cache:
+    // reading them back in the SAME order finds the oldest lines already evicted, reading in the opposite order starts with
+    // the ones still resident.
     // head_major_views: 0 = value in the reference's layout [B, Ncam, Nk, heads, HD] (a tile row is HD elements inside a
     // heads*HD-wide token row); B > 0 = head-major [heads, B, Ncam, Nk, HD]: a (camera, head) tile is ONE contiguous block
     // of HBM -- every 1-KB LDS-DMA instruction then covers 8 whole 128-byte lines instead of ~11 partial ones, and no line
@@ -749,6 +753,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const int i_first = (q_first / CPR) / Nk, k_first = (q_first / CPR) - i_first * Nk;
     auto stage = [&](int i) {
         int r = u0 + i / heads_per;
+        if (reverse) r = units_total - 1 - r;
         const int hs = r % hsplit;
         r /= hsplit;
         r /= nchunks;
@@ -882,7 +887,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     __builtin_amdgcn_s_setprio(3);
 #endif
     for (int un = u0; un < u1; ++un) {
-        int r = un;
+        int r = reverse ? units_total - 1 - un : un;
         const int hs = r % hsplit;
         r /= hsplit;
         const int ck = r % nchunks;
@@ -1701,7 +1706,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
-    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs, int head_major_views) {
+    float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs, int head_major_views, int reverse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = 8, NT = HD / 16, KS = HD / 32, MI = 16 / NW;
     static_assert(HD % 32 == 0, "k-steps of 32 channels");
@@ -1717,6 +1722,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     // grad / offset / logit rows
     int bid = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (bid >= total_wgs) return;
+    // last viewpoint first: the grad rows (531 MB at 192 viewpoints) were written just before this launch in ascending row
+    // order through the 256-MB memory-side cache -- the end of the tensor is what is still resident (k_sca_fwd_cs: `reverse`)
+    if (reverse) bid = total_wgs - 1 - bid;
     const int h = bid % heads;
     bid /= heads;
     const int c = bid % Ncam, b = bid / Ncam;
@@ -2193,6 +2201,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             static const int cs_hsplit = env_int("VER_SCA_CS_HSPLIT", 8);
             static const int cs_upw = env_int("VER_SCA_CS_UNITS_PER_WG", 1);
             static const int cs_wgs_per_cu = env_int("VER_SCA_CS_WGS_PER_CU", 1);
+            static const int cs_reverse = env_int("VER_SCA_CS_REVERSE", 1);
             int pt = f32 ? cs_threads_f32 : cs_threads_bf16;
             if (pt % 64 != 0 || pt < 128 || pt > 1024) pt = f32 ? 512 : 256;
             const int nlp = (cs_nload >= 0 && cs_nload < pt / 64) ? cs_nload : 0;
@@ -2227,7 +2236,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                         return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(pt), ldsp, st, vptr, offsets, logits, uv, vis, fwd_list,
                                        fwd_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsp, units, upw,
-                                       nlp, head_major ? B : 0);
+                                       nlp, head_major ? B : 0, cs_reverse);
                     return ver_check_launch("ver_sca_forward");
                 };
                 const bool k196 = map_h * map_w == 196;                // plane offsets become immediates
@@ -2303,6 +2312,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
         if constexpr (P == 8 && HD % 32 == 0) {
             // bf16 value tiles: everything on the matrix cores, one kernel (VER_SCA_BWD_MM=0: the two-kernel path below)
             const bool use_mm = sca_bwd_use_mm();
+            static const int bwd_reverse = env_int("VER_SCA_BWD_REVERSE", 1);
             const int nk = map_h * map_w, mt = (nk + 15) / 16;
             const size_t tile_b = ((size_t)nk * HD * 2 + 15) & ~(size_t)15, ds_b = (size_t)nk * kMmDss * 4, g_b = (size_t)2 * 32 * HD * 2;
             // the last tile-row tile reads (16 mt - nk) rows past the tile / past DS: they must stay inside the allocation
@@ -2318,7 +2328,7 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
                     const int wgs = B * Ncam * heads;
                     hipLaunchKernelGGL(kern, dim3((unsigned)((wgs + 7) & ~7)), dim3(kMmWaves * 64), lds_mm, st, (const uint16_t*)value,
                                        offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, (gv_t*)grad_value, grad_offsets,
-                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs, head_major ? B : 0);
+                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs, head_major ? B : 0, bwd_reverse);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
                 };
                 if (grad_value_dtype == VER_BF16) {

@@ -771,7 +771,7 @@ class OccMLPFunction(Function):
         image = occ_mlp_pack(w1, w2, w3)
         vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
         ctx.save_for_backward(x, image, vec, w2.detach(), w3.detach())
-        ctx.eps = eps
+        ctx.eps, ctx.centered = eps, bool(centered)
         return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded, centered=centered)
 
     @staticmethod
@@ -788,7 +788,7 @@ class OccMLPFunction(Function):
             pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
             _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
                 _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
-                ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _stream()))
+                ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), 2 if ctx.centered else 0, _stream()))
             vecs = pg[:768].view(6, 128)
             dw3 = pg[768:768 + 2048].view(16, 128)
             db3 = pg[768 + 2048:768 + 2048 + 16]

@@ -110,7 +110,7 @@ def test_lift_equals_default_branch():
 
 # Largest single-element deviation of the bf16 head from the reference's fp32 logits, as MEASURED on MI355X (round 4, this
 # test with -s: see the printed line) plus a 1.5x margin; the north star's "1e-2 bf16" is held as relative L2 next to it.
-MAX_ABS_BF16_HEAD = 1e-1
+MAX_ABS_BF16_HEAD = 2.5e-2     # measured: max |d| 1.49e-2 (rel L2 5.2e-3, mean |d| 2.8e-3) on logits of rms 0.67, max 2.77
 
 
 def test_vocc_head_bf16_autocast_within_1e2():

@@ -97,7 +97,10 @@ def _device_plan(plan, device):
     for g in plan.groups:
         d = _Plan()
         d.n_rows, d.n_cols = g.gather.shape
-        d.k_aug = (d.n_cols + Z + 1 + 7) // 8 * 8
+        # operand width: a multiple of 64 (the library's macro-tile depth).  Measured on the 552 960-row GEMMs of the bench
+        # (scratch/r04/occproj_shapes.py, tuned solutions): K = 824 -> 832: 4.32 -> 3.49 ms forward, 728 -> 768: 3.93 -> 3.26,
+        # 776 -> 832: 4.12 -> 3.49 -- with K % 64 != 0 the library falls back to its stream-K kernel at 0.37 of the MFMA peak
+        d.k_aug = (d.n_cols + Z + 1 + 63) // 64 * 64
         # operand columns: data | b_up[chan(row,k)] k<Z | 1 | zero padding, as indices into
         # lat_aug = [lattice (L), up_bias (C), 1, 0]
         idx = np.full((d.n_rows, d.k_aug), L + C + 1, dtype=np.int64)
@@ -228,9 +231,9 @@ class _OccProjLattice(torch.autograd.Function):
                 # [rows, Z] product read all of `go` again for four output columns: 0.85 ms per group at 192 viewpoints,
                 # profiles/r04_gemm_ledger.csv); the run copies take the row pitch of the wider buffer as it is
                 from ..hipops import run_scatter
-                d_all = torch.mm(go, wa[:, :g.n_cols + Z])                           # [bs*n_rows, n_cols + Z]
+                d_all = torch.mm(go, wa)                                             # [bs*n_rows, k_aug] (pads: zero columns)
                 run_scatter(d_all, d_lat, g.run_start, g.n_rows, g.run_len)
-                d_const = d_all[:, g.n_cols:]
+                d_const = d_all[:, g.n_cols:g.n_cols + Z]
             else:
                 d_data = torch.mm(go, wa[:, :g.n_cols])                              # [bs*n_rows, n_cols]
                 d_lat.index_copy_(1, g.scatter, d_data.view(bs, g.n_rows * g.n_cols))

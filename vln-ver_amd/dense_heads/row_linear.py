@@ -5,8 +5,8 @@ Forward and d(input) are ordinary GEMMs.  d(weight) = G^T X is a [out x rows] x 
 product with out, in <= 128 and rows = 4e6..16e6: a GEMM library sees ONE or two output tiles
 and runs it on one or two CUs (measured 4.7 ms per layer for 8 viewpoints = 14 % of the step).
 ``row_linear`` splits the row dimension into chunks, runs them as one batched GEMM (thousands of
-workgroups) and adds the fp32 partials; the bias gradient is the same batched product with a
-row of ones.  Used on CUDA tensors only; CPU tensors take ``F.linear``.
+workgroups) and adds the fp32 partials; the bias gradient is a column sum.  Used on CUDA tensors only; CPU
+tensors take ``F.linear``.
 """
 import torch
 import torch.nn.functional as F
@@ -34,17 +34,16 @@ class _RowLinear(torch.autograd.Function):
         s = n // _CHUNK
         main = s * _CHUNK
         gw = x.new_zeros((o, x.shape[1]), dtype=torch.float32)
-        gb = x.new_zeros((o,), dtype=torch.float32) if ctx.has_bias else None
+        gb = None
         if s:
             g3 = g[:main].view(s, _CHUNK, o)
             gw += torch.bmm(g3.transpose(1, 2), x[:main].view(s, _CHUNK, -1)).sum(0, dtype=torch.float32)
-            if ctx.has_bias:
-                ones = g.new_ones((1, 1, _CHUNK)).expand(s, 1, _CHUNK)
-                gb += torch.bmm(ones, g3).sum((0, 1), dtype=torch.float32)
         if main < n:
             gw += (g[main:].t() @ x[main:]).float()
-            if ctx.has_bias:
-                gb += g[main:].sum(0, dtype=torch.float32)
+        if ctx.has_bias:
+            # (a column sum, not a batched product with a stride-0 row of ones: a GEMM with M = 1 buys nothing over the
+            #  reduction kernel, and stride-0 batch operands fault inside some hipBLASLt solutions when TunableOp tries them)
+            gb = g.sum(0, dtype=torch.float32)
         return gx, gw, gb
 
 

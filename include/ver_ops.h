@@ -84,10 +84,7 @@ int ver_msda_backward(const float* value, const int64_t* shapes_hw, const int64_
  *   VoxelCustomMSDeformableAttention.forward (bevformer/modules/voxel_decoder.py:312-313).
  *   shapes_dhw i64 [levels,3] = (D,H,W); loc f32 [B,Nq,heads,levels,points,3] = (x,y,z) in [0,1];
  *   flat key index = (z*H + y)*W + x; 5-D grid_sample semantics (pixel = loc*size - 0.5, zeros).
- *   Gradient buffers of the backward are caller-allocated and ZERO-INITIALISED: grad_value is either accumulated with
- *   atomics (general shapes) or, for one level with head_dim <= 96 and <= 8192 sampling events / 2048 keys per
- *   (batch, head), overwritten row by row by an atomic-free kernel (events counting-sorted by key in LDS); on a zeroed
- *   buffer the two are the same up to the order of a key's additions.
+ *   Gradient buffers of the backward are caller-allocated and ZERO-INITIALISED.
  */
 int ver_msda3d_forward(const float* value, const int64_t* shapes_dhw, const int64_t* level_start,
                        const float* loc, const float* attn_w, float* out,

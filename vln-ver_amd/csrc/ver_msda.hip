@@ -245,159 +245,6 @@ __global__ __launch_bounds__(256) void k_msda3d_bwd(const float* __restrict__ va
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Backward of the decoder's one-level trilinear op without global atomics (round 4).  The generic kernel above adds
-// every (query, point, corner, channel) product into grad_value with a global atomic: 157 M float atomics for
-// 64 viewpoints x 100 queries x 8 heads x 4 points (238 us per call, L2-atomic bound).  Here one workgroup owns a
-// (viewpoint, head): the grad rows of its queries sit in LDS, phase 1 computes d(loc) / d(attn) per sample and emits the
-// <= Nq*P*8 sampling events {key, weight x attention, query}, a counting sort by key (integer LDS atomics) groups them,
-// and phase 3 lets 32 lanes per key add up that key's events in registers and write the grad_value row with ONE plain
-// store.  The order of a key's events inside the sort is not fixed, so the last bit of grad_value may vary run to run
-// (as with the atomics).  grad_value is OVERWRITTEN for every key of the (viewpoint, head) -- the caller's zero fill
-// (mmcv contract) is harmless.
-constexpr int kM3Keys = 2048, kM3Events = 8192;
-
-template <int NC>
-__global__ __launch_bounds__(256) void k_msda3d_bwd_sorted(const float* __restrict__ value,
-                                                           const int64_t* __restrict__ shapes,
-                                                           const float* __restrict__ loc, const float* __restrict__ aw,
-                                                           const float* __restrict__ gout, float* __restrict__ gvalue,
-                                                           float* __restrict__ gloc, float* __restrict__ gaw, int Nk,
-                                                           int heads, int hd, int P, int Nq) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int E = Nq * P * 8;
-    float* gt = reinterpret_cast<float*>(smem3);                    // [Nq][hd] grad rows of this (viewpoint, head)
-    float* ev_w = gt + Nq * hd;                                     // [E]
-    float* so_w = ev_w + E;                                         // [E] sorted
-    int* cnt = reinterpret_cast<int*>(so_w + E);                    // [Nk + 1] histogram -> start offsets
-    int* cur = cnt + Nk + 1;                                        // [Nk] scatter cursors
-    unsigned short* ev_key = reinterpret_cast<unsigned short*>(cur + Nk);      // [E] (0xffff: dead event)
-    unsigned short* ev_q = ev_key + E;                              // [E]
-    unsigned short* so_q = ev_q + E;                                // [E] sorted
-    __shared__ int part[256];
-    const int h = blockIdx.x % heads, b = blockIdx.x / heads;
-    const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;   // 8 groups of 32 lanes
-    const int D = (int)shapes[0], H = (int)shapes[1], W = (int)shapes[2];
-    const long vstride = (long)heads * hd;
-    const long voff = (long)b * Nk * vstride + (long)h * hd;
-    for (int i = tid; i < Nq * hd; i += 256) {
-        const int q = i / hd, ch = i - q * hd;
-        gt[i] = gout[((long)b * Nq + q) * vstride + (long)h * hd + ch];
-    }
-    for (int i = tid; i <= Nk; i += 256) cnt[i] = 0;
-    __syncthreads();
-    // ---- phase 1: one (query, point) per group and pass: dots with the eight corner rows, d(loc), d(attn), events
-    for (int it = grp; it < Nq * P; it += 8) {
-        const int q = it / P, p = it - q * P;
-        const long gid = ((long)b * Nq + q) * heads + h;
-        const float* lq = loc + (gid * P + p) * 3;
-        Trilinear s;
-        trilinear_setup<true>(lq[0], lq[1], lq[2], D, H, W, s);
-        const float a = aw[gid * P + p];
-        float sa = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float d = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int ch = lane + 32 * i;
-                if (ch < hd) d += gt[q * hd + ch] * value[voff + (long)s.key[k] * vstride + ch];
-            }
-            sa += s.w[k] * d;
-            sx += s.gx[k] * d;
-            sy += s.gy[k] * d;
-            sz += s.gz[k] * d;
-        }
-        sa = group_sum<32>(sa);
-        sx = group_sum<32>(sx);
-        sy = group_sum<32>(sy);
-        sz = group_sum<32>(sz);
-        if (lane == 0) {
-            const long o = gid * P + p;
-            gaw[o] = sa;
-            gloc[o * 3] = (float)W * a * sx;
-            gloc[o * 3 + 1] = (float)H * a * sy;
-            gloc[o * 3 + 2] = (float)D * a * sz;
-        }
-        if (lane < 8) {
-            float wk = 0.0f;
-            int kk = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (lane == k) {
-                    wk = s.w[k] * a;
-                    kk = s.key[k];
-                }
-            const int e = it * 8 + lane;
-            const bool live = wk != 0.0f;
-            ev_key[e] = live ? (unsigned short)kk : (unsigned short)0xffff;
-            ev_w[e] = wk;
-            ev_q[e] = (unsigned short)q;
-            if (live) atomicAdd(&cnt[kk], 1);
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: exclusive scan of the histogram, then the counting-sort scatter
-    {
-        const int per = (Nk + 255) / 256;
-        int sum = 0;
-        for (int j = 0; j < per; ++j) {
-            const int k = tid * per + j;
-            if (k < Nk) sum += cnt[k];
-        }
-        part[tid] = sum;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const int add = tid >= d ? part[tid - d] : 0;
-            __syncthreads();
-            part[tid] += add;
-            __syncthreads();
-        }
-        int run = part[tid] - sum;
-        for (int j = 0; j < per; ++j) {
-            const int k = tid * per + j;
-            if (k < Nk) {
-                const int c = cnt[k];
-                cnt[k] = run;
-                cur[k] = run;
-                run += c;
-            }
-        }
-        if (tid == 255) cnt[Nk] = part[255];
-    }
-    __syncthreads();
-    for (int e = tid; e < E; e += 256) {
-        const unsigned short kk = ev_key[e];
-        if (kk != 0xffff) {
-            const int pos = atomicAdd(&cur[kk], 1);
-            so_w[pos] = ev_w[e];
-            so_q[pos] = ev_q[e];
-        }
-    }
-    __syncthreads();
-    // ---- phase 3: one key per group and pass: its events added up in registers, one plain store of the row
-    for (int k = grp; k < Nk; k += 8) {
-        float acc[NC];
-#pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = 0.0f;
-        const int e0 = cnt[k], e1 = cnt[k + 1];
-        for (int e = e0; e < e1; ++e) {
-            const float w = so_w[e];
-            const int q = so_q[e];
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-                const int ch = lane + 32 * i;
-                if (ch < hd) acc[i] += w * gt[q * hd + ch];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int ch = lane + 32 * i;
-            if (ch < hd) gvalue[voff + (long)k * vstride + ch] = acc[i];
-        }
-    }
-}
-
 namespace {
 
 template <typename F>
@@ -503,22 +350,6 @@ extern "C" int ver_msda3d_backward(const float* value, const int64_t* shapes_dhw
     VER_REQUIRE(grad_out && grad_value && grad_loc && grad_attn_w, VER_EINVAL,
                 "ver_msda3d_backward: null gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    // one level, <= 96 channels per head, a (viewpoint, head)'s events and keys in LDS: the sorted, atomic-free kernel
-    static const int use_sorted = [] {
-        const char* e = getenv("VER_MSDA3D_BWD_SORTED");
-        return e ? atoi(e) : 1;
-    }();
-    const long ev = (long)Nq * points * 8;
-    const size_t lds3 = (size_t)Nq * head_dim * 4 + (size_t)ev * 8 + ((size_t)2 * num_keys + 1) * 4 + (size_t)ev * 6;
-    if (use_sorted && levels == 1 && head_dim <= 96 && ev <= kM3Events && num_keys <= kM3Keys && num_keys < 0xffff &&
-        Nq < 0xffff && lds3 <= 160 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msda3d_bwd_sorted<3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_msda3d_backward: LDS attribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL((k_msda3d_bwd_sorted<3>), dim3((unsigned)(B * heads)), dim3(256), lds3, st, value, shapes_dhw, loc,
-                           attn_w, grad_out, grad_value, grad_loc, grad_attn_w, num_keys, heads, head_dim, points, Nq);
-        return ver_check_launch("ver_msda3d_backward/sorted");
-    }
     return dispatch_group(head_dim, [&](auto g, auto nc) {
         constexpr int G = decltype(g)::value, NC = decltype(nc)::value;
         const int gpb = 256 / G;

@@ -175,17 +175,18 @@ def build_model(args, dev):
     return pkg, syn, head.to(dev), n_train
 
 
-def gather_algorithmic_bytes(hit_counts, B, value_bytes, ncam=6, nk=196, c=768, heads=8, points=8):
+def gather_algorithmic_bytes(hit_counts, B, value_bytes, ncam=6, nk=196, c=768, heads=8, points=8, grad_slots_bytes=4):
     """SURVEY.md 8(d) with `s` = the bytes per element of each operand AS THE KERNEL SEES IT: per viewpoint and
     layer, forward = value once (6*196*768*s_v, s_v = 2 under bf16 autocast: value_proj emits bf16) +
     Sigma_n*(128 + 64 + 768)*4 (offsets, logits and the output row of every visible (camera, voxel) pair are fp32);
     backward = value read (s_v) + d(value) written (s_v too: the matrix-core backward writes bf16 for bf16 tiles,
-    fp32 for fp32 tiles) + Sigma_n*(768 + 2*192 + 192)*4.
+    fp32 for fp32 tiles) + Sigma_n*(768*s_g + (2*192 + 192)*4), s_g = bytes per element of the slots' gradient rows.
     (Round 1 priced the bf16 value tensor at 4 B/element: its 0.48 was 0.36 by this rule.)"""
     sn = float(hit_counts)
     nval = B * ncam * nk * c
     fwd = nval * value_bytes + sn * (heads * points * 2 + heads * points + c) * 4
-    bwd = nval * (value_bytes + value_bytes) + sn * 5376
+    # (round 4: under bf16 autocast the grad rows of the slots arrive in bf16 and are read as such -- priced at their size)
+    bwd = nval * (value_bytes + value_bytes) + sn * (c * grad_slots_bytes + (2 * 192 + 192) * 4)
     return fwd, bwd
 
 
@@ -557,7 +558,7 @@ def main():
         hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
         sigma_n = int(hit.vis_cnt.sum())
         vbytes = 2 if args.dtype == 'bf16' else 4          # value_proj emits bf16 under autocast
-        fwd_b, bwd_b = gather_algorithmic_bytes(sigma_n, B, vbytes)
+        fwd_b, bwd_b = gather_algorithmic_bytes(sigma_n, B, vbytes, grad_slots_bytes=2 if args.dtype == 'bf16' else 4)
         roof, others = None, []
         for name, byts, kernels in (('ver_sca_forward', fwd_b, ('k_sca_fwd', 'k_zero_rows')),
                                     ('ver_sca_backward', bwd_b, ('k_sca_bwd',))):

@@ -181,6 +181,11 @@ int ver_hits_from_mask(const uint8_t* bev_mask, int B, int Ncam, int Nq, int D,
  *   either way (the weight gradient of value_proj reads it as a plain [rows, heads*head_dim] matrix).
  */
 #define VER_SCA_VALUE_HEAD_MAJOR 2
+/*        VER_SCA_GRAD_SLOTS_BF16 (ver_sca_backward): `grad_slots` is bf16 [B, Nq, heads*head_dim] -- what the GEMM behind the
+ *   gather hands back under bf16 autocast -- and is used as it is, one bf16 term per element (the fp32 form is split into
+ *   bf16 hi + lo); only where ver_sca_backward_grad_dtype(...) == VER_BF16, with grad_value_dtype = VER_BF16.
+ */
+#define VER_SCA_GRAD_SLOTS_BF16 4
 int ver_sca_head_major_supported(int value_dtype, int head_dim, int points, int map_h, int map_w);
 int ver_sca_zero_rows(const int32_t* zero_list, const int32_t* zero_cnt, float* slots, int B, int Nq, int row_floats,
                       void* stream);
@@ -205,7 +210,7 @@ int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int points, int m
 int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                      const float* uv, const uint8_t* vis, const int32_t* vis_list,
                      const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
-                     const float* grad_slots,
+                     const void* grad_slots,
                      void* grad_value, int grad_value_dtype, float* grad_offsets, float* grad_logits,
                      int B, int Ncam, int Nq, int D, int heads, int head_dim, int points,
                      int map_h, int map_w, int flags, void* stream);
@@ -229,15 +234,19 @@ int ver_lattice_col2im(const void* grad_col, void* grad_src, const int* taps, in
 /* Generalised lattice gather / scatter used by the parity-class upsample layers.  Rows enumerate
  * (b, zr < Zr, y, x); tap t reads the source position (zr + dz_t, y + dy_t, x + dx_t) of a lattice
  * with Zs z-layers (zero outside) into col[r * col_stride + col_offset[t] .. + C) (elements; offsets
- * and stride multiples of 16 bytes; columns between tap blocks are left untouched -- the caller keeps
- * constant-pattern columns there); ntaps <= 64.  Source layouts (`layout`):
+ * and stride multiples of 16 bytes; columns between tap blocks are left untouched unless `const_rows` fills them);
+ * ntaps <= 64.  Source layouts (`layout`):
  *   0 plain [B,Zs,H,W,C]      1 planar: four planes [B,Zs,H/2,W/2,C], plane 2*pm+pn = positions
  *   (2y'+pm, 2x'+pn) of the combined (H, W) lattice      2 z-split [B,2,H,W,2,C] (Zs = 4): element
  *   (b,z,y,x) at row (b, z&1, y, x), channel block z>>1      3 planar z-split: four planes of layout 2.
  * scatter is the adjoint (gather form, no atomics): grad_src is overwritten in the source's layout.
  */
+/* const_rows (may be NULL): [Zr*H*W][const_blocks][const_width] elements, the constant-pattern blocks of one viewpoint's
+ * rows; the gather copies them to columns const_offset[0 .. const_blocks) of every viewpoint (whole 16-byte vectors).
+ */
 int ver_lattice_gather(const void* src, void* col, const int* taps, const long* col_offset, long col_stride,
-                       int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype, void* stream);
+                       int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype,
+                       const void* const_rows, const long* const_offset, int const_blocks, int const_width, void* stream);
 int ver_lattice_scatter(const void* grad_col, void* grad_src, const int* taps, const long* col_offset,
                         long col_stride, int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype,
                         void* stream);
@@ -286,6 +295,10 @@ int ver_ln_relu_backward(const void* x, const void* grad_y, const float* gamma, 
 int ver_focal_loss_blocks(long N, int C);
 int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,
                            float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream);
+/*   forward_grad: the forward pass that ALSO writes the unscaled gradient d loss[n,c] / d logits[n,c] (logits' dtype) to
+ *             `grad`, which may be the logits buffer itself -- for steps that need the loss and its gradient, not the logits */
+int ver_focal_loss_forward_grad(const void* logits, const int64_t* target, float* partial, void* grad, long N, int C,
+                                float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
 
@@ -386,9 +399,12 @@ int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* ima
 /*   flags: 0 or VER_OCC_MLP_CENTERED (the forward ran centred: W2 / b2 passed here are the centred ones, the recomputed
  *   LayerNorm-forward steps skip the mean pass).
  */
+/*   grad_scale: NULL, or a DEVICE scalar that multiplies grad_logits as it is read (the gradient of the loss sum that
+ *   `ver_focal_loss_forward_grad` left unscaled: the training loss then needs no backward pass over the logits).
+ */
 int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                const float* vectors, void* grad_x, float* param_grads, long N, int width,
-                               int classes, float eps, int flags, void* stream);
+                               int classes, float eps, const float* grad_scale, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Occupancy post-processing: VoxelFormerOccupancyHead.get_occupancy_prediction, focal-loss branch

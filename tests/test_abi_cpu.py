@@ -69,11 +69,11 @@ def test_argument_validation_of_the_head_entry_points():
     assert lib.ver_focal_loss_blocks(ctypes.c_long(0), 16) == 1
     taps = (ctypes.c_int * 3)(0, 0, 0)
     offs = (ctypes.c_long * 1)(8)
-    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(16), 1, 1, 1, 1, 3, 2, 8, 1, 0, None)
+    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(16), 1, 1, 1, 1, 3, 2, 8, 1, 0, None, None, 0, 0, None)
     assert rc == -1 and b'even' in lib.ver_last_error()                   # planar needs even H, W
-    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(12), 1, 1, 1, 1, 2, 2, 8, 0, 0, None)
+    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(12), 1, 1, 1, 1, 2, 2, 8, 0, 0, None, None, 0, 0, None)
     assert rc == -1 and b'outside the row' in lib.ver_last_error()        # tap block past the row end
-    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(16), 1, 1, 2, 3, 2, 2, 8, 2, 0, None)
+    rc = lib.ver_lattice_gather(buf, buf, taps, offs, ctypes.c_long(16), 1, 1, 2, 3, 2, 2, 8, 2, 0, None, None, 0, 0, None)
     assert rc == -2 and b'z-split' in lib.ver_last_error()                # z-split layouts: 4 z-layers
     rc = lib.ver_lattice_transpose(buf, buf, ctypes.c_long(3), 1, 1, 2, 2, 8, 0, 1, 0, None)
     assert rc == -1 and b'stride' in lib.ver_last_error()

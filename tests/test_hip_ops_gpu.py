@@ -846,6 +846,47 @@ def test_occ_mlp_fused_with_folded_first_linear(fused, monkeypatch):
                                first_linear=False).shape == (0, 16)
 
 
+def test_occ_mlp_focal_loss_fused_equals_the_two_ops():
+    """``OccMLPFocalLossFunction`` (the occupancy term of a training step as ONE autograd Function: MLP forward, focal
+    forward that leaves the unscaled gradient in the logits buffer, MLP backward reading it with the scalar factor) against
+    ``occ_mlp`` followed by ``sigmoid_focal_loss_sum``: the same loss bit for bit (the same two forward kernels), the same
+    gradients up to one extra bf16 rounding of d(logits) -- including a non-trivial upstream factor and a bad label's NaN."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    p = _occ_mlp_params(gen)
+    n = 64 * 400 + 9
+    a1 = (torch.randn(n, 128, generator=gen) * 1.5).bfloat16()
+    tgt = torch.randint(0, 17, (n,), generator=gen)
+    keys = ('g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+    res = {}
+    for fused in (True, False):
+        pd = {k: p[k].to(DEV).requires_grad_(True) for k in keys}
+        xd = a1.to(DEV).requires_grad_(True)
+        if fused:
+            s = hip.occ_mlp_focal_loss_sum(xd, *(pd[k] for k in keys), tgt.to(DEV))
+        else:
+            s = hip.sigmoid_focal_loss_sum(hip.occ_mlp(xd, None, None, *(pd[k] for k in keys)), tgt.to(DEV))
+        (s * 0.37 / 1234.0).backward()
+        res[fused] = (float(s), xd.grad.float().cpu(), {k: v.grad.float().cpu() for k, v in pd.items()})
+    assert res[True][0] == res[False][0]
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    assert rel(res[True][1], res[False][1]) < 1e-2
+    for k in keys:
+        assert rel(res[True][2][k], res[False][2][k]) < 1e-2, (k, rel(res[True][2][k], res[False][2][k]))
+    flag = hip.LabelRangeFlag.of(torch.device(DEV))
+    flag.reset()
+    try:
+        bad = tgt.clone()
+        bad[77] = 99
+        assert torch.isnan(hip.occ_mlp_focal_loss_sum(a1.to(DEV), *(p[k].to(DEV) for k in keys), bad.to(DEV)))
+        with pytest.raises(RuntimeError, match='outside'):
+            flag.poll(sync=True)
+    finally:
+        flag.reset()
+
+
 def test_occ_mlp_centered_equals_plain_and_the_fp64_chain():
     """VER_OCC_MLP_CENTERED (include/ver_ops.h): with the hidden Linears centred over their output axis
     (W <- W - mean_o W, b <- b - mean b) every LayerNorm input has zero row mean and the kernels skip the mean pass.

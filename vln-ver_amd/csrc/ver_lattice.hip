@@ -86,10 +86,20 @@ __device__ __forceinline__ void lattice_decode(long r, int B, int Zs, int H, int
 
 // One workgroup walks rows; inside a row the (tap, vector) index advances without divisions
 // (the first version decoded every 16-byte vector from a flat index: five runtime divisions each).
+// Constant-pattern blocks of a tap matrix (the columns BETWEEN the tap blocks: 0/1 boundary patterns + a 1 per parity class,
+// the same for every viewpoint): `rows` [rows_per_sample][nblk][wv] 16-byte vectors, copied to the column offsets off[].
+// Filled by the gather itself (round 4) -- as 16 strided torch copies per step they cost 0.8 ms.
+struct ConstBlocks {
+    const uint4* rows;
+    long rows_per_sample;
+    int nblk, wv;
+    int off[8];
+};
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict__ src, uint4* __restrict__ col,
                                                         TapListEx taps, long stride_v, int B, int Zr, int Zs, int H,
-                                                        int W, int CV) {
+                                                        int W, int CV, ConstBlocks cb) {
     // per row: the source vector index of every tap (clamped into the lattice) and whether the tap is inside, computed
     // once by the first taps.n threads into LDS (two tables, by row parity: one barrier per row); the copy loop is then
     // a table look-up, a 16-byte load and a nontemporal 16-byte store per vector -- the tap matrix is written once and
@@ -135,6 +145,15 @@ __global__ __launch_bounds__(256) void k_lattice_gather(const uint4* __restrict_
             if (v >= CV) {
                 v -= CV;
                 ++t;
+            }
+        }
+        if (cb.rows) {
+            const uint4* cs = cb.rows + (row % cb.rows_per_sample) * (long)(cb.nblk * cb.wv);
+            for (int i = threadIdx.x; i < cb.nblk * cb.wv; i += 256) {
+                const int bk = i / cb.wv, vv = i - bk * cb.wv;
+                const uint4 val = cs[i];
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u32x4_t{val.x, val.y, val.z, val.w}, reinterpret_cast<u32x4_t*>(dst + cb.off[bk] + vv));
             }
         }
     }
@@ -388,6 +407,7 @@ unsigned lattice_blocks(long total) {
 
 extern "C" int ver_lattice_gather(const void* src, void* col, const int* taps, const long* col_offset, long col_stride,
                                   int ntaps, int B, int Zr, int Zs, int H, int W, int C, int layout, int dtype,
+                                  const void* const_rows, const long* const_offset, int const_blocks, int const_width,
                                   void* stream) {
     int rc = check_lattice(src, col, B, Zs, H, W, C, dtype);
     if (rc) return rc;
@@ -403,9 +423,25 @@ extern "C" int ver_lattice_gather(const void* src, void* col, const int* taps, c
     const long stride_v = col_stride * esize / 16;
     const unsigned blocks = (unsigned)(rows < 256L * 32 ? rows : 256L * 32);
     hipStream_t st = (hipStream_t)stream;
+    ConstBlocks cb = {};
+    if (const_rows) {
+        VER_REQUIRE(const_offset && const_blocks > 0 && const_blocks <= 8 && const_width > 0 && (const_width * esize) % 16 == 0 &&
+                        ((uintptr_t)const_rows & 15) == 0,
+                    VER_EINVAL, "ver_lattice_gather: constant blocks: 1..8 blocks of whole 16-byte vectors from an aligned table");
+        cb.rows = (const uint4*)const_rows;
+        cb.rows_per_sample = (long)Zr * H * W;
+        cb.nblk = const_blocks;
+        cb.wv = const_width * esize / 16;
+        for (int i = 0; i < const_blocks; ++i) {
+            VER_REQUIRE(const_offset[i] >= 0 && (const_offset[i] * esize) % 16 == 0 && const_offset[i] + const_width <= col_stride,
+                        VER_EINVAL, "ver_lattice_gather: constant block %d at column %ld does not fit the 16-byte grid", i,
+                        const_offset[i]);
+            cb.off[i] = (int)(const_offset[i] * esize / 16);
+        }
+    }
 #define VER_GATHER(L)                                                                                                 \
     hipLaunchKernelGGL(k_lattice_gather<L>, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)col, tl, stride_v, \
-                       B, Zr, Zs, H, W, CV)
+                       B, Zr, Zs, H, W, CV, cb)
     if (layout == 0) VER_GATHER(0);
     else if (layout == 1) VER_GATHER(1);
     else if (layout == 2) VER_GATHER(2);

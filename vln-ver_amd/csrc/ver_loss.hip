@@ -72,10 +72,15 @@ __device__ __forceinline__ uint32_t to_bf16(float f) {   // round to nearest eve
 }
 }  // namespace
 
-template <bool BF16, bool G2>
-__global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logits, const int64_t* __restrict__ target,
+// WG (ver_focal_loss_forward_grad): the same pass also writes the UNSCALED gradient d loss[n,c] / d logits[n,c] (in the
+// logits' dtype) to `grad`, which may be the logits buffer itself (a thread reads its eight logits before it writes their
+// gradients): a training step that needs the loss value and the gradient, not the logits, then has no separate backward
+// pass over the [N, C] tensor -- the consumer applies the scalar d(total) / d(loss sum) when it reads the gradient.
+template <bool BF16, bool G2, bool WG = false>
+__global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int64_t* __restrict__ target,
                                                    float* __restrict__ partial, long nvec, int vec_per_row,
-                                                   float gamma, float alpha, int* __restrict__ bad_labels) {
+                                                   float gamma, float alpha, int* __restrict__ bad_labels,
+                                                   void* grad = nullptr) {
     __shared__ float red[4];
     float acc = 0.0f;
     bool bad = false;
@@ -86,8 +91,26 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* __restrict__ logi
         const int tgt = (int)t64;
         float x[8];
         load_x8<BF16>(logits, v, x);
+        float g[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += focal_term<G2, BF16>(x[j], tgt == c0 + j, gamma, alpha).loss;
+        for (int j = 0; j < 8; ++j) {
+            const Term t = focal_term<G2, BF16>(x[j], tgt == c0 + j, gamma, alpha);
+            acc += t.loss;
+            g[j] = t.grad;
+        }
+        if constexpr (WG) {
+            if (BF16) {
+                uint4 t;
+                t.x = to_bf16(g[0]) | (to_bf16(g[1]) << 16);
+                t.y = to_bf16(g[2]) | (to_bf16(g[3]) << 16);
+                t.z = to_bf16(g[4]) | (to_bf16(g[5]) << 16);
+                t.w = to_bf16(g[6]) | (to_bf16(g[7]) << 16);
+                reinterpret_cast<uint4*>(grad)[v] = t;
+            } else {
+                reinterpret_cast<float4*>(grad)[2 * v] = make_float4(g[0], g[1], g[2], g[3]);
+                reinterpret_cast<float4*>(grad)[2 * v + 1] = make_float4(g[4], g[5], g[6], g[7]);
+            }
+        }
         // a label outside [0, C] (F.one_hot raises on it) poisons the sum: the loss comes out NaN instead of silently
         // counting the row as background -- checked here, in the pass that reads the labels anyway, so the host needs no
         // device->host synchronisation per step to be loud about it
@@ -169,6 +192,29 @@ extern "C" int ver_focal_loss_forward(const void* logits, const int64_t* target,
     }
 #undef VER_FOCAL_FWD
     return ver_check_launch("ver_focal_loss_forward");
+}
+
+extern "C" int ver_focal_loss_forward_grad(const void* logits, const int64_t* target, float* partial, void* grad, long N,
+                                           int C, float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream) {
+    int rc = check_focal("ver_focal_loss_forward_grad", logits, target, N, C, dtype);
+    if (rc) return rc;
+    VER_REQUIRE(partial, VER_EINVAL, "ver_focal_loss_forward_grad: null partial-sum buffer");
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(grad && ((uintptr_t)grad & 15) == 0, VER_EINVAL, "ver_focal_loss_forward_grad: grad must be a 16-byte aligned buffer");
+    const int blocks = ver_focal_loss_blocks(N, C);
+    const long nvec = N * (long)(C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const bool g2 = gamma == 2.0f;
+#define VER_FOCAL_FWG(BF, G2)                                                                                         \
+    hipLaunchKernelGGL((k_focal_fwd<BF, G2, true>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, C / 8, \
+                       gamma, alpha, bad_labels, grad)
+    if (dtype == VER_BF16) {
+        if (g2) VER_FOCAL_FWG(true, true); else VER_FOCAL_FWG(true, false);
+    } else {
+        if (g2) VER_FOCAL_FWG(false, true); else VER_FOCAL_FWG(false, false);
+    }
+#undef VER_FOCAL_FWG
+    return ver_check_launch("ver_focal_loss_forward_grad");
 }
 
 extern "C" int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,

@@ -1066,8 +1066,10 @@ template <bool CENTERED>
 __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ vec, __bf16* __restrict__ dx,
-                                                        float* __restrict__ pgrad, long N, float eps) {
+                                                        float* __restrict__ pgrad, long N, float eps,
+                                                        const float* __restrict__ grad_scale) {
     constexpr int OT = 2, RT = 4, KS = 2;
+    const float gscale = grad_scale ? grad_scale[0] : 1.0f;        // scalar factor of d(logits) (device-side, may be null)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __bf16* const tiles = reinterpret_cast<__bf16*>(smem);              // [set][4] tiles, then the shared d(h1) tile
     __bf16* const T4 = tiles + 8 * kWsTile;
@@ -1116,7 +1118,15 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             bf16x8 xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xr[t] = st.okn ? st.xn[t] : z8;
-            if (g < 2) *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = st.okn ? st.dln : z8;
+            if (g < 2) {
+                bf16x8 dl = st.okn ? st.dln : z8;
+                if (gscale != 1.0f) {            // (wave-uniform) d(logits) arrives unscaled: ver_focal_loss_forward_grad
+                    const f32x4 lo = __builtin_convertvector(__builtin_shufflevector(dl, dl, 0, 1, 2, 3), f32x4) * gscale;
+                    const f32x4 hi = __builtin_convertvector(__builtin_shufflevector(dl, dl, 4, 5, 6, 7), f32x4) * gscale;
+                    dl = pack8(lo, hi);
+                }
+                *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = dl;
+            }
             prefetch(st, blk + 2 * (long)gridDim.x, blk + 2 * (long)gridDim.x < nblk);
             ln_relu_nat<true, true, CENTERED>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
 #pragma unroll
@@ -1362,7 +1372,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 
 extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                           const float* vectors, void* grad_x, float* param_grads, long N, int width,
-                                          int classes, float eps, int flags, void* stream) {
+                                          int classes, float eps, const float* grad_scale, int flags, void* stream) {
     VER_REQUIRE(N >= 0, VER_EINVAL, "ver_occ_mlp_backward_fused: negative row count");
     VER_REQUIRE((flags & ~VER_OCC_MLP_CENTERED) == 0, VER_EINVAL, "ver_occ_mlp_backward_fused: unknown flags 0x%x", flags);
     VER_REQUIRE(width == kW && classes == kC, VER_EUNSUPPORTED,
@@ -1387,9 +1397,10 @@ extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits
         const long nb = (N + kWsRows - 1) / kWsRows;
         const long gridw = nb < 256 ? nb : 256;               // one workgroup per CU (LDS bound), persistent
         hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(512), kWsLds, st, (const __bf16*)x,
-                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps);
+                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps, grad_scale);
         return ver_check_launch("ver_occ_mlp_backward_fused");
     }
+    VER_REQUIRE(!grad_scale, VER_EUNSUPPORTED, "ver_occ_mlp_backward_fused: grad_scale needs the wave-specialised kernel");
     static const int nw = [] {
         const char* ev = getenv("VER_OCC_MLP_NS_WAVES");       // 8: 128-row blocks, two waves per SIMD; 4: 64-row blocks
         const int v = ev ? atoi(ev) : 8;

@@ -1701,15 +1701,20 @@ __device__ __forceinline__ void mm_split(const float (&f)[8], mm_bf16x8& hi, mm_
 
 // GVT: d(value) is written as float or as bf16 (uint16_t).  NW waves per workgroup: the first four carry the scalar phases
 // (256 threads = 32 voxels x 8 points), all NW share the matrix phases, the zero fill and the tile staging.
-template <int HD, int NKT, typename GVT, int NW>
+// GST: dtype of grad_slots.  float: the rows are split into bf16 hi + lo (16 mantissa bits).  uint16_t (bf16, what the
+// output_proj GEMM hands back under bf16 autocast -- VER_SCA_GRAD_SLOTS_BF16): the rows are used as they are, ONE bf16 term
+// (exact except for the 1/3, 1/5, ... camera-count factors of voxels seen by 3+ cameras, which round to bf16): half the bytes
+// of the largest operand, no lo fragments, a third fewer MFMAs.
+template <int HD, int NKT, typename GVT, int NW, typename GST = float>
 __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     const uint16_t* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
-    const int* __restrict__ fwd_cnt, const float* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
+    const int* __restrict__ fwd_cnt, const GST* __restrict__ gslots, GVT* __restrict__ gvalue, float* goffs,
     float* glogits, int Ncam, int Nq, int D, int heads, int mh, int mw, int total_wgs, int head_major_views, int reverse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int P = 8, NT = HD / 16, KS = HD / 32, MI = 16 / NW;
     static_assert(HD % 32 == 0, "k-steps of 32 channels");
+    constexpr bool GBF = sizeof(GST) == 2;             // grad rows given in bf16: single-term operands
     const int Nk = NKT ? NKT : mh * mw;
     const int MT = (Nk + 15) >> 4;                    // tile-row tiles of 16 (the last one reads past the tile: see below)
     uint16_t* tile = reinterpret_cast<uint16_t*>(smem);                                   // [Nk][HD] bf16
@@ -1780,11 +1785,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
         o.lg = logits[qh * P + p];
         o.of = *reinterpret_cast<const float2*>(offs + (qh * P + p) * 2);
         o.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + ad) * 2);
-        const float* grow = gslots + qh * HD + p * SEG;
+        const GST* grow = gslots + qh * HD + p * SEG;
 #pragma unroll
         for (int i = 0; i < SEG / 4; ++i) {
-            const float4 t4 = *reinterpret_cast<const float4*>(grow + 4 * i);
-            o.gf[4 * i] = t4.x; o.gf[4 * i + 1] = t4.y; o.gf[4 * i + 2] = t4.z; o.gf[4 * i + 3] = t4.w;
+            if constexpr (GBF) {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(grow + 4 * i);
+                o.gf[4 * i] = __uint_as_float(t2.x << 16); o.gf[4 * i + 1] = __uint_as_float(t2.x & 0xffff0000u);
+                o.gf[4 * i + 2] = __uint_as_float(t2.y << 16); o.gf[4 * i + 3] = __uint_as_float(t2.y & 0xffff0000u);
+            } else {
+                const float4 t4 = *reinterpret_cast<const float4*>(grow + 4 * i);
+                o.gf[4 * i] = t4.x; o.gf[4 * i + 1] = t4.y; o.gf[4 * i + 2] = t4.z; o.gf[4 * i + 3] = t4.w;
+            }
         }
         return o;
     };
@@ -1816,7 +1827,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
                     lo[j] = (__bf16)(gs - (float)hi[j]);
                 }
                 *reinterpret_cast<uint2*>(gh + 4 * i) = *reinterpret_cast<const uint2*>(hi);
-                *reinterpret_cast<uint2*>(gl + 4 * i) = *reinterpret_cast<const uint2*>(lo);
+                if constexpr (!GBF) *reinterpret_cast<uint2*>(gl + 4 * i) = *reinterpret_cast<const uint2*>(lo);
             }
         }
         // next chunk's operands and the id after that: in flight during the rest of this chunk
@@ -1839,7 +1850,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     gbh[nt][ks] = *reinterpret_cast<const mm_bf16x8*>(Gh + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
-                    gbl[nt][ks] = *reinterpret_cast<const mm_bf16x8*>(Gl + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
+                    if constexpr (!GBF) gbl[nt][ks] = *reinterpret_cast<const mm_bf16x8*>(Gl + (nt * 16 + cc) * HD + ks * 32 + 8 * g);
+                    else gbl[nt][ks] = gbh[nt][ks];
                 }
             // (unrolled: the 7 tiles of a wave are independent accumulation chains for the scheduler to interleave;
             //  a chain of 2 KS dependent MFMAs per tile was 780 cycles per tile when executed one tile at a time)
@@ -1857,7 +1869,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
                         const mm_bf16x8 a = *reinterpret_cast<const mm_bf16x8*>(tile + (size_t)(mt * 16 + cc) * HD + ks * 32 + 8 * g);
                         const mm_bf16x8 bhh = nt ? gbh[1][ks] : gbh[0][ks], bll = nt ? gbl[1][ks] : gbl[0][ks];
                         d[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bhh, d[ui], 0, 0, 0);
-                        d[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bll, d[ui], 0, 0, 0);
+                        if constexpr (!GBF) d[ui] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bll, d[ui], 0, 0, 0);
                     }
                 }
             }
@@ -1933,10 +1945,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
             for (int nt = 0; nt < NT; ++nt) {
                 const mm_s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gh + toff + nt * 16));
                 const mm_s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gh + toff + nt * 16 + 4 * HD));
-                const mm_s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16));
-                const mm_s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16 + 4 * HD));
                 bh[nt] = __builtin_bit_cast(mm_bf16x8, (mm_s16x8)__builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                bl[nt] = __builtin_bit_cast(mm_bf16x8, (mm_s16x8)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (!GBF) {
+                    const mm_s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16));
+                    const mm_s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((mm_s16x4 __attribute__((address_space(3)))*)(Gl + toff + nt * 16 + 4 * HD));
+                    bl[nt] = __builtin_bit_cast(mm_bf16x8, (mm_s16x8)__builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    bl[nt] = bh[nt];
+                }
             }
         }
 #pragma unroll
@@ -1953,7 +1969,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mi][nt], 0, 0, 0);
-                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mi][nt], 0, 0, 0);
+                    if constexpr (!GBF) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mi][nt], 0, 0, 0);
                     acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mi][nt], 0, 0, 0);
                 }
             }
@@ -2278,16 +2294,20 @@ extern "C" int ver_sca_backward_grad_dtype(int value_dtype, int head_dim, int po
 extern "C" int ver_sca_backward(const void* value, int value_dtype, const float* offsets, const float* logits,
                                 const float* uv, const uint8_t* vis, const int32_t* vis_list,
                                 const int32_t* vis_cnt, const int32_t* fwd_list, const int32_t* fwd_cnt,
-                                const float* grad_slots, void* grad_value, int grad_value_dtype,
+                                const void* grad_slots_v, void* grad_value, int grad_value_dtype,
                                 float* grad_offsets, float* grad_logits, int B, int Ncam, int Nq, int D,
                                 int heads, int head_dim, int points, int map_h, int map_w, int flags, void* stream) {
+    const float* grad_slots = reinterpret_cast<const float*>(grad_slots_v);     // (bf16 with VER_SCA_GRAD_SLOTS_BF16)
     int rc = check_sca(value, value_dtype, offsets, logits, uv, vis, vis_list, vis_cnt, B, Ncam, Nq, D, heads,
                        head_dim, points, map_h, map_w);
     if (rc) return rc;
     VER_REQUIRE(grad_slots && grad_value && grad_offsets && grad_logits && fwd_list && fwd_cnt, VER_EINVAL,
                 "ver_sca_backward: null pointer argument");
-    VER_REQUIRE((flags & ~VER_SCA_VALUE_HEAD_MAJOR) == 0, VER_EINVAL, "ver_sca_backward: unknown flags 0x%x", flags);
-    const bool head_major = flags & VER_SCA_VALUE_HEAD_MAJOR;
+    VER_REQUIRE((flags & ~(VER_SCA_VALUE_HEAD_MAJOR | VER_SCA_GRAD_SLOTS_BF16)) == 0, VER_EINVAL,
+                "ver_sca_backward: unknown flags 0x%x", flags);
+    const bool head_major = flags & VER_SCA_VALUE_HEAD_MAJOR, grad_bf16 = flags & VER_SCA_GRAD_SLOTS_BF16;
+    VER_REQUIRE(!grad_bf16 || ver_sca_backward_grad_dtype(value_dtype, head_dim, points, map_h, map_w) == VER_BF16,
+                VER_EUNSUPPORTED, "ver_sca_backward: bf16 grad_slots are read by the matrix-core kernel only");
     VER_REQUIRE(!head_major || (ver_sca_head_major_supported(value_dtype, head_dim, points, map_h, map_w) &&
                                 ver_sca_backward_grad_dtype(value_dtype, head_dim, points, map_h, map_w) == VER_BF16),
                 VER_EUNSUPPORTED, "ver_sca_backward: the head-major value layout is read by the matrix-core kernel only");
@@ -2319,24 +2339,31 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
             const bool slack_ok = (size_t)(16 * mt - nk) * HD * 2 <= ds_b && (size_t)(16 * mt - nk) * kMmDss * 4 <= g_b;
             if (use_mm && value_dtype == VER_BF16 && mt <= 16 && slack_ok && tile_b + ds_b + g_b <= kMaxLds) {
                 const size_t lds_mm = tile_b + ds_b + g_b;
-                auto launch_mm = [&](auto kern, auto gptr) {
+                auto launch_mm = [&](auto kern, auto gptr, auto sptr) {
                     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mm);
                     if (e2 != hipSuccess)
                         return ver_fail(VER_ELAUNCH, "ver_sca_backward: LDS attribute: %s", hipGetErrorString(e2));
                     typedef std::remove_pointer_t<decltype(gptr)> gv_t;
+                    typedef std::remove_cv_t<std::remove_pointer_t<decltype(sptr)>> gs_t;
                     const int wgs = B * Ncam * heads;
                     hipLaunchKernelGGL(kern, dim3((unsigned)((wgs + 7) & ~7)), dim3(kMmWaves * 64), lds_mm, st, (const uint16_t*)value,
-                                       offsets, logits, uv, vis, fwd_list, fwd_cnt, grad_slots, (gv_t*)grad_value, grad_offsets,
-                                       grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs, head_major ? B : 0, bwd_reverse);
+                                       offsets, logits, uv, vis, fwd_list, fwd_cnt, (const gs_t*)(const void*)grad_slots,
+                                       (gv_t*)grad_value, grad_offsets, grad_logits, Ncam, Nq, D, heads, map_h, map_w, wgs,
+                                       head_major ? B : 0, bwd_reverse);
                     return ver_check_launch("ver_sca_backward/k_sca_bwd_mm");
                 };
-                if (grad_value_dtype == VER_BF16) {
-                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t, kMmWaves>, (uint16_t*)nullptr);
-                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t, kMmWaves>, (uint16_t*)nullptr);
+                if (grad_bf16) {
+                    VER_REQUIRE(grad_value_dtype == VER_BF16, VER_EUNSUPPORTED, "ver_sca_backward: bf16 grad_slots go with bf16 grad_value");
+                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t, kMmWaves, uint16_t>, (uint16_t*)nullptr, (const uint16_t*)nullptr);
+                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t, kMmWaves, uint16_t>, (uint16_t*)nullptr, (const uint16_t*)nullptr);
                 }
-                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, float, kMmWaves>, (float*)nullptr);
-                return launch_mm(k_sca_bwd_mm<HD, 0, float, kMmWaves>, (float*)nullptr);
+                if (grad_value_dtype == VER_BF16) {
+                    if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, uint16_t, kMmWaves>, (uint16_t*)nullptr, (const float*)nullptr);
+                    return launch_mm(k_sca_bwd_mm<HD, 0, uint16_t, kMmWaves>, (uint16_t*)nullptr, (const float*)nullptr);
+                }
+                if (nk == 196) return launch_mm(k_sca_bwd_mm<HD, 196, float, kMmWaves>, (float*)nullptr, (const float*)nullptr);
+                return launch_mm(k_sca_bwd_mm<HD, 0, float, kMmWaves>, (float*)nullptr, (const float*)nullptr);
             }
         }
         // everything below writes d(value) as fp32 (twice the bytes of a bf16 buffer): never fall through with one

@@ -419,11 +419,34 @@ def _from_plain(e, layout):
             ZS_SPLIT: plain_to_zs, ZS_PLANAR_SPLIT: lambda t: plain_to_planar_zs(t).contiguous()}[layout](e)
 
 
-def _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc):
-    """rows (b, zl, y, x); tap (dz in {0,2}, dy, dx) reads input layer zl + dz."""
+_CONST_ROWS4 = {}
+
+
+def _const_rows_z4(ci, hc, wc, device, dtype):
+    """The constant-pattern blocks of one viewpoint's rows of a Z = 4 lattice layer, as the gather kernel copies them:
+    [2*hc*wc, 4 classes, 2*_PW] = per class [P_lo | P_hi], and their column offsets."""
+    key = (ci, hc, wc, str(device), dtype)
+    if key not in _CONST_ROWS4:
+        pats = _class_patterns(4, hc, wc, device, dtype)
+        blocks = []
+        for pat in pats:
+            halves = pat.view(2, 2 * hc * wc, _PW)                  # output z = zl (lower), zl + 2 (upper)
+            blocks.append(torch.cat([halves[0], halves[1]], 1))
+        table = torch.stack(blocks, 1).contiguous()                 # [2hw, 4, 2*_PW]
+        _CONST_ROWS4[key] = (table, [_const_offset4(pm, pn, ci) for pm, pn in _CLASSES])
+    return _CONST_ROWS4[key]
+
+
+def _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=False):
+    """rows (b, zl, y, x); tap (dz in {0,2}, dy, dx) reads input layer zl + dz.  ``with_const`` (GPU): the kernel also writes
+    the constant-pattern blocks of the four parity classes (else the caller fills them)."""
     if e.is_cuda:
         from ..hipops import lattice_gather
-        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2)
+        if with_const:
+            table, coffs = _const_rows_z4(ci, hc, wc, e.device, e.dtype)
+            lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2, const_rows=table, const_offset=coffs)
+        else:
+            lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2)
         return
     src = _to_plain(e, layout)
     b = src.shape[0]
@@ -599,14 +622,16 @@ class _LatticeLayerZ4(torch.autograd.Function):
         plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, e.device)
         m = b * 2 * hc * wc
         a_mat = e.new_empty(m, kt)
-        _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc)
-        pats = _class_patterns(4, hc, wc, e.device, dt)
-        a3 = a_mat.view(b, 2 * hc * wc, kt)
-        for (pm, pn), pat in zip(_CLASSES, pats):
-            o = _const_offset4(pm, pn, ci)
-            halves = pat.view(2, 2 * hc * wc, _PW)                  # output z = zl (lower), zl + 2 (upper)
-            a3[:, :, o:o + _PW] = halves[0]
-            a3[:, :, o + _PW:o + _PW2] = halves[1]
+        on_gpu = e.is_cuda and dt in (torch.float32, torch.bfloat16)
+        _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=on_gpu)
+        if not on_gpu:
+            pats = _class_patterns(4, hc, wc, e.device, dt)
+            a3 = a_mat.view(b, 2 * hc * wc, kt)
+            for (pm, pn), pat in zip(_CLASSES, pats):
+                o = _const_offset4(pm, pn, ci)
+                halves = pat.view(2, 2 * hc * wc, _PW)              # output z = zl (lower), zl + 2 (upper)
+                a3[:, :, o:o + _PW] = halves[0]
+                a3[:, :, o + _PW:o + _PW2] = halves[1]
         v = torch.matmul(prev_bias.to(dt), k)                                     # [75, Co]
         vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
         rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug,

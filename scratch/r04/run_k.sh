@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_hip_ops_gpu.py -x -q -k "sca_gather or launch_modes or sca_backward" 2>&1 | tail -5
+for B in 64 128 192; do
+  VER_BENCH_PREZERO=1 timeout 300 python scratch/bench_gather.py $B 4x15x15 bf16 2>&1 | grep -v amdgpu.ids
+done
+timeout 300 python scratch/bench_gather.py 32 4x15x15 2>&1 | grep -v amdgpu.ids

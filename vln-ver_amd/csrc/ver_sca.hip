@@ -700,12 +700,23 @@ __device__ float g_sca_dummy_row[256 * 256];        // one 1-KiB slice per (bloc
 // HM (head-major value, head_major_views > 0): the tile is one contiguous block of HBM and is staged as it lies, ROW-major in
 // LDS (a tile row = HD elements); the corner rows (r, r+1, r+14, r+15) of a 14-wide map of 192-byte rows still fall on four
 // disjoint 64-byte bank groups (0, 192, 128, 64 mod 256; profiles/r02_ubench_lds.txt), so the gather stays conflict free.
+// Division of the unit / tile indices by the launch's (run-time) small divisors.  A general integer division is ~25
+// instructions and the prologue of a workgroup held fifteen of them (two in 64 bits) -- ~40 % of the launch's scalar
+// instructions (35 M per 192-viewpoint launch in round 3's counters), executed by every wave in front of its first DMA request.
+// The host passes floor(2^32 / d) + 1 per divisor: one s_mul_hi_u32, exact for n < 2^32 / d (checked by the launcher).
+struct CsMagic {
+    unsigned hsplit, nchunks, ncam, hper, ncons;
+};
+__host__ __device__ __forceinline__ unsigned cs_magic(int d) { return d > 1 ? (unsigned)(0x100000000ull / (unsigned)d) + 1u : 0u; }
+__device__ __forceinline__ int cs_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
+
 template <int HD, typename VT, int NKT, int MATH = 0, bool HM = false>
 __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
-    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views, int reverse) {
+    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views, int reverse,
+    int heads_per, CsMagic mg) {
     // reverse: walk the units from the LAST viewpoint to the first.  The value tensor (347 MB at 192 viewpoints) and the
     // offsets / logits were written just before this launch, in ascending row order, through a 256-MB memory-side cache:
     // reading them back in the SAME order finds the oldest lines already evicted, reading in the opposite order starts with
@@ -730,7 +741,6 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const unsigned plane = HM ? 32u * (unsigned)sizeof(VT) : (unsigned)Nk * RB;      // bytes between a row's 32-channel groups
     const unsigned tile_bytes = ((unsigned)(NV * Nk * 32 * sizeof(VT)) + 15u) & ~15u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int heads_per = heads / hsplit;
     const size_t rstride = (size_t)heads * HD;
     // XCD-aware placement: workgroup b runs on XCD b % 8 and every XCD has its own L2, so the grid is dealt to the
     // XCDs in contiguous blocks -- the heads of one (viewpoint, camera) share its voxel lists, visibility, uv and the
@@ -752,13 +762,13 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const int jc = q_first % CPR;
     const int i_first = (q_first / CPR) / Nk, k_first = (q_first / CPR) - i_first * Nk;
     auto stage = [&](int i) {
-        int r = u0 + i / heads_per;
+        const int iu = cs_div(i, heads_per, mg.hper);
+        int r = u0 + iu;
         if (reverse) r = units_total - 1 - r;
-        const int hs = r % hsplit;
-        r /= hsplit;
-        r /= nchunks;
-        const int c = r % Ncam, b = r / Ncam;
-        const int h = hs * heads_per + i % heads_per;
+        const int rq = cs_div(r, hsplit, mg.hsplit), hs = r - rq * hsplit;
+        r = cs_div(rq, nchunks, mg.nchunks);
+        const int b = cs_div(r, Ncam, mg.ncam), c = r - b * Ncam;
+        const int h = hs * heads_per + (i - iu * heads_per);
         VT* dst = reinterpret_cast<VT*>(smem + (nbuf == 2 ? (i & 1) : 0) * tile_bytes);
 #ifdef VER_ABL_NODMA
         if (i >= 0) return;
@@ -888,18 +898,17 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
 #endif
     for (int un = u0; un < u1; ++un) {
         int r = reverse ? units_total - 1 - un : un;
-        const int hs = r % hsplit;
-        r /= hsplit;
-        const int ck = r % nchunks;
-        r /= nchunks;
-        const int c = r % Ncam, b = r / Ncam;
+        const int rq = cs_div(r, hsplit, mg.hsplit), hs = r - rq * hsplit;
+        r = cs_div(rq, nchunks, mg.nchunks);
+        const int ck = rq - r * nchunks;
+        const int b = cs_div(r, Ncam, mg.ncam), c = r - b * Ncam;
         const int h0 = hs * heads_per;
         const int n_single = fwd_cnt[(b * Ncam + c) * 2], n_multi = fwd_cnt[(b * Ncam + c) * 2 + 1];
         const int w_start = ck * chunk;
         const int s_n = max(0, min(n_single - w_start, chunk)), m_n = max(0, min(n_multi - w_start, chunk));
         const int s_n2 = (s_n + 1) & ~1, s_pairs = s_n2 >> 1;
         const int TP = s_pairs + ((m_n + 1) >> 1);
-        const int p_lo = (int)((long)wave * TP / ncons), p_hi = (int)((long)(wave + 1) * TP / ncons);
+        const int p_lo = cs_div(wave * TP, ncons, mg.ncons), p_hi = cs_div((wave + 1) * TP, ncons, mg.ncons);   // < 2^28: TP < 2^24
         const int iters = (p_hi - p_lo + 3) >> 2;
         const int* list = fwd_list + ((size_t)b * Ncam + c) * Nq;
         // list entry of this lane in wave iteration `it`; dead entries (pad, odd tail, pairs of other waves) return
@@ -2240,7 +2249,9 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
             const bool cs_addr_ok = (size_t)Nq * row_b < ((size_t)1 << 32) &&
                                     (size_t)Nq * heads * points * 8 < ((size_t)1 << 32) &&
                                     (size_t)Nq * D * 8 < ((size_t)1 << 32) && row_b < ((size_t)1 << 24) &&
-                                    (size_t)heads * points * 8 < ((size_t)1 << 24) && Nq < (1 << 24);
+                                    (size_t)heads * points * 8 < ((size_t)1 << 24) && Nq < (1 << 24) &&
+                                    // unit indices go through 32-bit magic divisions (cs_div): exact below 2^32 / divisor
+                                    (size_t)B * Ncam * nchunks * heads < ((size_t)1 << 24);
             if (use_cs && ldsp <= kMaxLds && cs_addr_ok) {
                 int hsp = 1;
                 while (hsp < cs_hsplit && hsp < heads && heads % (hsp * 2) == 0) hsp *= 2;
@@ -2255,6 +2266,8 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                     upw = (units + slots_wg - 1) / slots_wg;
                 }
                 const int grid = ((units + upw - 1) / upw + 7) & ~7;     // multiple of 8: dealt to the XCDs in blocks
+                const CsMagic mg = {cs_magic(hsp), cs_magic(nchunks), cs_magic(Ncam), cs_magic(heads / hsp),
+                                    cs_magic(pt / 64 - nlp)};
                 auto launch_cs = [&](auto kern, auto vptr) {
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
@@ -2262,7 +2275,7 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                         return ver_fail(VER_ELAUNCH, "ver_sca_forward: LDS attribute: %s", hipGetErrorString(e));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(pt), ldsp, st, vptr, offsets, logits, uv, vis, fwd_list,
                                        fwd_cnt, slots, Ncam, Nq, D, heads, map_h, map_w, nchunks, kFwdChunk, hsp, units, upw,
-                                       nlp, head_major ? B : 0, cs_reverse);
+                                       nlp, head_major ? B : 0, cs_reverse, heads / hsp, mg);
                     return ver_check_launch("ver_sca_forward");
                 };
                 const bool k196 = map_h * map_w == 196;                // plane offsets become immediates

@@ -19,9 +19,12 @@ mkdir -p profiles; cp $R/r04_bench_pmc_fetch_write.csv profiles/   # bench.py re
 rm -f $R/r04_bench_pmc_mfma.csv
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/pmc_mfma -o pmc -- python3 $CMD > $R/pmc_mfma.json 2> $R/pmc_mfma.err; echo "pmc mfma $?"
 python scratch/r04/mfma_summary.py $R/pmc_mfma/pmc_results.db $R/r04_bench_pmc_mfma.csv; rm -rf $R/pmc_mfma
+rm -f $R/r04_gather_sq_counters.csv
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/pmc_sq -o pmc -- python3 $CMD > $R/pmc_sq.json 2> $R/pmc_sq.err; echo "pmc sq $?"
+python scratch/prof_summary.py pmc $R/pmc_sq/pmc_results.db $R/r04_gather_sq_counters.csv; rm -rf $R/pmc_sq
 FT="bench.py --workload vocc_full_train --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= --host-fed-steps 0"
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/trace_ft -o trace -- python3 $FT > $R/trace_ft.json 2> $R/trace_ft.err; echo "trace full_train $?"
 python scratch/prof_summary.py kernels $R/trace_ft/trace_results.db $R/r04_full_train_kernel_stats.csv; rm -rf $R/trace_ft
-timeout 900 python bench.py --steps 6 --warmup 2 > $R/r04_bench_default.json 2> $R/bench.err; echo "bench $?"
+T0=$(date +%s); timeout 900 python bench.py > $R/r04_bench_default.json 2> $R/bench.err; echo "bench $? wall $(( $(date +%s) - T0 )) s (the driver's command: no flags)"
 cat $R/r04_bench_default.json | cut -c1-1500
-grep "k_sca\|k_zero" $R/r04_bench_pmc_fetch_write.csv; grep "k_sca\|k_zero\|k_occ" $R/r04_bench_kernel_stats.csv; grep "k_msda3d" $R/r04_full_train_kernel_stats.csv
+grep "k_sca\|k_zero" $R/r04_bench_pmc_fetch_write.csv; grep "k_sca_fwd" $R/r04_gather_sq_counters.csv; grep "k_sca\|k_zero\|k_occ" $R/r04_bench_kernel_stats.csv; grep "k_msda3d" $R/r04_full_train_kernel_stats.csv

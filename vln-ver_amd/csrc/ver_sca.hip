@@ -710,13 +710,20 @@ struct CsMagic {
 __host__ __device__ __forceinline__ unsigned cs_magic(int d) { return d > 1 ? (unsigned)(0x100000000ull / (unsigned)d) + 1u : 0u; }
 __device__ __forceinline__ int cs_div(int n, int d, unsigned m) { return d == 1 ? n : (int)__umulhi((unsigned)n, m); }
 
-template <int HD, typename VT, int NKT, int MATH = 0, bool HM = false>
+// ONE: the launch shape that ships (one tile per workgroup, no loader waves, one voxel chunk) as compile-time constants --
+// the unit / head loops, the loader path and their registers (63 spilled SGPRs in the general form) fold away.
+#ifndef VER_CS_DMA_AUX
+#define VER_CS_DMA_AUX 0        // cache policy bits of the reference-layout tile DMA (experiment hook; 2 = non-temporal: measured no better)
+#endif
+template <int HD, typename VT, int NKT, int MATH = 0, bool HM = false, bool ONE = false>
 __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
     const VT* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ uv, const uint8_t* __restrict__ vis, const int* __restrict__ fwd_list,
     const int* __restrict__ fwd_cnt, float* slots, int Ncam, int Nq, int D, int heads, int mh, int mw,
-    int nchunks, int chunk, int hsplit, int units_total, int units_per_wg, int nload, int head_major_views, int reverse,
-    int heads_per, CsMagic mg) {
+    int nchunks_a, int chunk, int hsplit, int units_total, int units_per_wg_a, int nload_a, int head_major_views, int reverse,
+    int heads_per_a, CsMagic mg) {
+    const int nchunks = ONE ? 1 : nchunks_a, units_per_wg = ONE ? 1 : units_per_wg_a, nload = ONE ? 0 : nload_a;
+    const int heads_per = ONE ? 1 : heads_per_a;
     // reverse: walk the units from the LAST viewpoint to the first.  The value tensor (347 MB at 192 viewpoints) and the
     // offsets / logits were written just before this launch, in ascending row order, through a 256-MB memory-side cache:
     // reading them back in the SAME order finds the oldest lines already evicted, reading in the opposite order starts with
@@ -789,7 +796,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
             if (q0 + lane < total_chunks) {
                 const VT* g = src + (size_t)pk * rstride + pi * 32;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)q0 * EPC), 16, 0, VER_CS_DMA_AUX);
             }
             pk += rows_per_step;
             while (pk >= Nk) {
@@ -953,8 +960,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
             auto load_sample = [&](int n) -> Sample {
                 Sample sm;
                 const unsigned nn = (unsigned)(n < 0 ? -n - 1 : n);          // < 2^24 voxels (checked by the host wrapper)
-                const unsigned mv = (unsigned)vis_base[nn];
-                sm.m = n < 0 ? 0u : mv;
+                sm.m = (unsigned)vis_base[nn];           // raw: a dead entry's mask is cleared where the record is used
                 sm.lg = *reinterpret_cast<const float*>(lg_base + (__umul24(nn, hp4) + (unsigned)l8 * 4u));
                 sm.of = *reinterpret_cast<const float2*>(of_base + (__umul24(nn, hp4) * 2u + (unsigned)l8 * 8u));
                 sm.u = *reinterpret_cast<const float2*>(uv_base + (__umul24(nn, d8) + (unsigned)ad * 8u));
@@ -987,7 +993,7 @@ __global__ __launch_bounds__(1024) void k_sca_fwd_cs(
                 const Sample s1 = load_sample(n1);
                 const int n3 = load_id(it + 3);
                 // ---------------- phase A: lane = sampling point l8 of voxel (s4, v2)
-                const unsigned m = s0.m;
+                const unsigned m = n0 < 0 ? 0u : s0.m;
                 float w[4];
                 unsigned k[4];
                 int cnt;                              // live samples of this lane's voxel
@@ -2286,7 +2292,11 @@ extern "C" int ver_sca_forward(const void* value, int value_dtype, const float* 
                 // VER_SCA_FWD_MATH: 0 bf16 tile + fp32 unpack and accumulation (exact), 2 fp16 tile + packed fp16
                 // accumulation over a voxel's points (default: DESIGN.md section 3.1)
                 static const int cs_math = env_int("VER_SCA_FWD_MATH", 2);
+                static const int cs_one = env_int("VER_SCA_CS_ONE", 1);          // 0: the general form for every launch shape
+                const bool one = cs_one && nlp == 0 && upw == 1 && hsp == heads && nchunks == 1;
+                if (head_major && one) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2, true, true>, (const uint16_t*)value);
                 if (head_major) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2, true>, (const uint16_t*)value);
+                if (k196 && cs_math == 2 && one) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2, false, true>, (const uint16_t*)value);
                 if (k196 && cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196, 2>, (const uint16_t*)value);
                 if (k196) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 196>, (const uint16_t*)value);
                 if (cs_math == 2) return launch_cs(k_sca_fwd_cs<HD, uint16_t, 0, 2>, (const uint16_t*)value);

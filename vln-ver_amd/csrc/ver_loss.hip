@@ -26,12 +26,34 @@ struct Term {
 // log1pf -- its 1e-7 absolute error only shows where exp(-|x|) < 1e-5, i.e. |x| > 11.5.
 template <bool G2, bool FAST>
 __device__ __forceinline__ Term focal_term(float x, bool pos, float gamma, float alpha) {
+    if constexpr (FAST && G2) {
+        // the bf16 / gamma = 2 form of the step, ~28 instructions per element: with s = 1 + exp(-|x|), p and q = 1 - p are
+        // 1/s and e/s in the order the sign of x says (no subtraction), softplus(-x) = softplus(x) - x, and both branches are
+        // c u^2 sp and +-c u^2 (u + 2 w sp) of (u, w, sp, c) = (q, p, softplus(-x), alpha) | (p, q, softplus(x), 1 - alpha)
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+        const float s1 = 1.0f + e;
+        const float inv = __builtin_amdgcn_rcpf(s1), einv = e * inv;
+        const bool nonneg = x >= 0.0f;
+        const float pp = nonneg ? inv : einv, qq = nonneg ? einv : inv;
+        const float sp_pos = fmaxf(x, 0.0f) + 0.6931471805599453f * __builtin_amdgcn_logf(s1);
+        const float u = pos ? qq : pp, w = pos ? pp : qq;
+        const float sp = pos ? sp_pos - x : sp_pos;
+        const float cu2 = (pos ? alpha : 1.0f - alpha) * (u * u);
+        Term t;
+        t.loss = cu2 * sp;
+        const float tt = __builtin_fmaf(w + w, sp, u);
+        t.grad = (pos ? -cu2 : cu2) * tt;
+        return t;
+    }
     // log p = -softplus(-x), log(1-p) = -softplus(x); softplus(z) = max(z,0) + log1p(exp(-|z|))
-    const float e = __expf(-fabsf(x));
-    const float l1p = FAST ? __logf(1.0f + e) : log1pf(e);
+    // FAST: the bare v_exp_f32 / v_log_f32 (the library forms wrap them in denormal-range scaling: a compare, a select and
+    // an ldexp each): exp(-|x|) below 2^-126 flushes to zero, where it is far under the bf16 tolerance; 1 + e is in [1, 2]
+    const float e = FAST ? __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x)) : __expf(-fabsf(x));
+    const float l1p = FAST ? 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e) : log1pf(e);
     const float sp_pos = fmaxf(x, 0.0f) + l1p;    // softplus(x)  = -log(1-p)
     const float sp_neg = fmaxf(-x, 0.0f) + l1p;   // softplus(-x) = -log(p)
-    const float inv = 1.0f / (1.0f + e);
+    // (FAST: the hardware reciprocal, 1 ulp, instead of the ~10-instruction IEEE division sequence)
+    const float inv = FAST ? __builtin_amdgcn_rcpf(1.0f + e) : 1.0f / (1.0f + e);
     const float p = x >= 0.0f ? inv : e * inv;
     const float q = 1.0f - p;
     Term t;
@@ -70,6 +92,14 @@ __device__ __forceinline__ uint32_t to_bf16(float f) {   // round to nearest eve
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+// two floats -> one packed bf16 pair, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction for what to_bf16
+// spells out in six per element)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 }  // namespace
 
 // WG (ver_focal_loss_forward_grad): the same pass also writes the UNSCALED gradient d loss[n,c] / d logits[n,c] (in the
@@ -80,17 +110,16 @@ template <bool BF16, bool G2, bool WG = false>
 __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int64_t* __restrict__ target,
                                                    float* __restrict__ partial, long nvec, int vec_per_row,
                                                    float gamma, float alpha, int* __restrict__ bad_labels,
-                                                   void* grad = nullptr) {
+                                                   void* grad = nullptr, int row_shift = -1) {
     __shared__ float red[4];
     float acc = 0.0f;
     bool bad = false;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
-        const long row = v / vec_per_row;
+    // row of a 16-byte vector: a shift when the row holds a power of two of them (16 classes: two) -- the general form is a
+    // 64-bit division per vector, as many instructions as the eight focal terms it addresses
+    auto row_of = [&](long v) -> long { return row_shift >= 0 ? (v >> row_shift) : v / vec_per_row; };
+    auto one = [&](long v, long row, int64_t t64, const float (&x)[8]) {
         const int c0 = (int)(v - row * vec_per_row) * 8;
-        const int64_t t64 = target[row];
         const int tgt = (int)t64;
-        float x[8];
-        load_x8<BF16>(logits, v, x);
         float g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -101,10 +130,10 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int
         if constexpr (WG) {
             if (BF16) {
                 uint4 t;
-                t.x = to_bf16(g[0]) | (to_bf16(g[1]) << 16);
-                t.y = to_bf16(g[2]) | (to_bf16(g[3]) << 16);
-                t.z = to_bf16(g[4]) | (to_bf16(g[5]) << 16);
-                t.w = to_bf16(g[6]) | (to_bf16(g[7]) << 16);
+                t.x = pack_bf16(g[0], g[1]);
+                t.y = pack_bf16(g[2], g[3]);
+                t.z = pack_bf16(g[4], g[5]);
+                t.w = pack_bf16(g[6], g[7]);
                 reinterpret_cast<uint4*>(grad)[v] = t;
             } else {
                 reinterpret_cast<float4*>(grad)[2 * v] = make_float4(g[0], g[1], g[2], g[3]);
@@ -118,6 +147,29 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int
             acc = __builtin_nanf("");
             bad = true;
         }
+    };
+    // four vectors per thread in flight: one request per thread and trip left the pass latency bound (0.36 of the HBM peak)
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * 256;
+    long v = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; v + (U - 1) * stride < nvec; v += U * stride) {
+        long row[U];
+        int64_t t64[U];
+        float x[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            row[u] = row_of(v + u * stride);
+            t64[u] = target[row[u]];
+            load_x8<BF16>(logits, v + u * stride, x[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(v + u * stride, row[u], t64[u], x[u]);
+    }
+    for (; v < nvec; v += stride) {
+        const long row = row_of(v);
+        float x[8];
+        load_x8<BF16>(logits, v, x);
+        one(v, row, target[row], x);
     }
     // ... and raises a sticky device-side flag: callers that clean NaNs out of their losses (the head's nan_to_num,
     // as in the reference) still learn about it, from an asynchronous copy of one int
@@ -131,10 +183,10 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int
 template <bool BF16, bool G2>
 __global__ __launch_bounds__(256) void k_focal_bwd(const void* __restrict__ logits, const int64_t* __restrict__ target,
                                                    const float* __restrict__ scale, void* __restrict__ grad, long nvec,
-                                                   int vec_per_row, float gamma, float alpha) {
+                                                   int vec_per_row, float gamma, float alpha, int row_shift) {
     const float s = scale[0];
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
-        const long row = v / vec_per_row;
+        const long row = row_shift >= 0 ? (v >> row_shift) : v / vec_per_row;
         const int c0 = (int)(v - row * vec_per_row) * 8;
         const int tgt = (int)target[row];
         float x[8], g[8];
@@ -143,10 +195,10 @@ __global__ __launch_bounds__(256) void k_focal_bwd(const void* __restrict__ logi
         for (int j = 0; j < 8; ++j) g[j] = s * focal_term<G2, BF16>(x[j], tgt == c0 + j, gamma, alpha).grad;
         if (BF16) {
             uint4 t;
-            t.x = to_bf16(g[0]) | (to_bf16(g[1]) << 16);
-            t.y = to_bf16(g[2]) | (to_bf16(g[3]) << 16);
-            t.z = to_bf16(g[4]) | (to_bf16(g[5]) << 16);
-            t.w = to_bf16(g[6]) | (to_bf16(g[7]) << 16);
+            t.x = pack_bf16(g[0], g[1]);
+            t.y = pack_bf16(g[2], g[3]);
+            t.z = pack_bf16(g[4], g[5]);
+            t.w = pack_bf16(g[6], g[7]);
             reinterpret_cast<uint4*>(grad)[v] = t;
         } else {
             reinterpret_cast<float4*>(grad)[2 * v] = make_float4(g[0], g[1], g[2], g[3]);
@@ -156,6 +208,11 @@ __global__ __launch_bounds__(256) void k_focal_bwd(const void* __restrict__ logi
 }
 
 namespace {
+int row_shift_of(int vec_per_row) {      // log2 when the row holds a power of two of 16-byte vectors, else -1
+    int sh = 0;
+    while ((1 << sh) < vec_per_row) ++sh;
+    return (1 << sh) == vec_per_row ? sh : -1;
+}
 int check_focal(const char* who, const void* logits, const int64_t* target, long N, int C, int dtype) {
     VER_REQUIRE(N >= 0 && C > 0, VER_EINVAL, "%s: bad shape N=%ld C=%d", who, N, C);
     VER_REQUIRE(C % 8 == 0, VER_EUNSUPPORTED, "%s: class count %d is not a multiple of 8", who, C);
@@ -184,7 +241,7 @@ extern "C" int ver_focal_loss_forward(const void* logits, const int64_t* target,
     const bool g2 = gamma == 2.0f;
 #define VER_FOCAL_FWD(BF, G2)                                                                                   \
     hipLaunchKernelGGL((k_focal_fwd<BF, G2>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, C / 8, \
-                       gamma, alpha, bad_labels)
+                       gamma, alpha, bad_labels, (void*)nullptr, row_shift_of(C / 8))
     if (dtype == VER_BF16) {
         if (g2) VER_FOCAL_FWD(true, true); else VER_FOCAL_FWD(true, false);
     } else {
@@ -207,7 +264,7 @@ extern "C" int ver_focal_loss_forward_grad(const void* logits, const int64_t* ta
     const bool g2 = gamma == 2.0f;
 #define VER_FOCAL_FWG(BF, G2)                                                                                         \
     hipLaunchKernelGGL((k_focal_fwd<BF, G2, true>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, C / 8, \
-                       gamma, alpha, bad_labels, grad)
+                       gamma, alpha, bad_labels, grad, row_shift_of(C / 8))
     if (dtype == VER_BF16) {
         if (g2) VER_FOCAL_FWG(true, true); else VER_FOCAL_FWG(true, false);
     } else {
@@ -230,7 +287,7 @@ extern "C" int ver_focal_loss_backward(const void* logits, const int64_t* target
     const bool g2 = gamma == 2.0f;
 #define VER_FOCAL_BWD(BF, G2)                                                                                       \
     hipLaunchKernelGGL((k_focal_bwd<BF, G2>), dim3(blocks), dim3(256), 0, st, logits, target, scale, grad, nvec, C / 8, \
-                       gamma, alpha)
+                       gamma, alpha, row_shift_of(C / 8))
     if (dtype == VER_BF16) {
         if (g2) VER_FOCAL_BWD(true, true); else VER_FOCAL_BWD(true, false);
     } else {

@@ -1,6 +1,7 @@
 """CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every
 symbol include/ver_ops.h declares; the Python side fails loudly without a GPU."""
 import ctypes
+import numpy as np
 import os
 import re
 
@@ -122,3 +123,21 @@ def test_host_launchers_under_address_sanitizer():
     assert 'AddressSanitizer' not in proc.stderr and 'AddressSanitizer' not in proc.stdout, proc.stderr[-3000:]
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     assert '4 passed' in proc.stdout, proc.stdout[-500:]
+
+
+def test_magic_division_of_the_gather_launcher_is_exact_in_its_range():
+    """csrc/ver_sca.hip `cs_magic` / `cs_div`: n // d == mulhi(n, floor(2^32 / d) + 1) for every unit index the launcher lets
+    through (n < 2^24 units, wave * pairs < 2^28 for ncons <= 16) -- the bound the launcher's `cs_addr_ok` check relies on."""
+    rng = np.random.default_rng(0)
+    for d in list(range(2, 65)) + [96, 128, 255, 256]:
+        m = (1 << 32) // d + 1
+        lim = min(1 << 24, (1 << 32) // d)
+        n = np.concatenate([np.arange(0, 4096), rng.integers(0, lim, 20000), np.array([lim - 1, lim - 2])]).astype(np.uint64)
+        # multiples of d and their predecessors: where a truncated reciprocal would first go wrong
+        k = rng.integers(1, max(2, lim // d), 2000).astype(np.uint64) * np.uint64(d)
+        n = np.concatenate([n, k[k < lim], k[k < lim] - np.uint64(1)])
+        assert np.array_equal((n * np.uint64(m)) >> np.uint64(32), n // np.uint64(d)), d
+    for d in range(2, 17):                                  # the pair split: wave * TP < 2^28
+        m = (1 << 32) // d + 1
+        n = np.concatenate([rng.integers(0, 1 << 28, 50000), np.array([(1 << 28) - 1])]).astype(np.uint64)
+        assert np.array_equal((n * np.uint64(m)) >> np.uint64(32), n // np.uint64(d)), d

@@ -444,6 +444,8 @@ def test_sca_gather_launch_modes(tmp_path):
         'loaders2': {'VER_SCA_FWD_MATH': '2', 'VER_SCA_CS_NLOAD': '2', 'VER_SCA_CS_THREADS_BF16': '512', 'VER_SCA_CS_THREADS_F32': '1024',
                      'VER_SCA_CS_HSPLIT': '1', 'VER_SCA_CS_UNITS_PER_WG': '3'},
         'multi_unit': {'VER_SCA_FWD_MATH': '0', 'VER_SCA_CS_HSPLIT': '4', 'VER_SCA_CS_UNITS_PER_WG': '5', 'VER_SCA_CS_THREADS_BF16': '512'},
+        # the shipped kernel is the compile-time specialisation of the default launch shape: this is its general form
+        'general_form': {'VER_SCA_CS_ONE': '0'},
     }
     res = {}
     for name, env in modes.items():
@@ -453,7 +455,11 @@ def test_sca_gather_launch_modes(tmp_path):
     for name in modes:
         for key in res['default'].files:
             d = float(np.abs(res[name][key] - res['default'][key]).max())
-            if name in ('f16_acc', 'loaders2') and key.endswith('_bf16'):
+            if name == 'general_form':
+                # same arithmetic as the specialised kernel: equal up to the order of the float atomics on shared voxels
+                dd = float(np.abs(res[name][key] - res['f16_acc'][key]).max())
+                assert dd < 2e-5, (name, key, dd)
+            elif name in ('f16_acc', 'loaders2') and key.endswith('_bf16'):
                 # packed fp16 accumulation: inside the bf16 bound of the north star, and only on bf16 tiles
                 rel = float(np.linalg.norm(res[name][key] - res['default'][key]) / np.linalg.norm(res['default'][key]))
                 assert d < 1e-2 and rel < 2e-3, (name, key, d, rel)

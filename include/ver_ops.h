@@ -291,6 +291,10 @@ int ver_ln_relu_backward(const void* x, const void* grad_y, const float* gamma, 
  *             head does, can still be loud about it without a synchronisation per step
  *   backward: grad[n,c] = scale[0] * d loss[n,c] / d logits[n,c]   (scale: device scalar; grad in
  *             the logits' dtype)
+ *   arithmetic: fp32 per element.  f32 logits: log1p / exact division (1e-4 parity with the reference's
+ *             fp32 formulas).  bf16 logits: the hardware exp2 / log2 / reciprocal (1 ulp each; exp(-|x|)
+ *             below 2^-126 flushes to zero) -- the error stays far below the bf16 rounding of the inputs
+ *             and of the gradient that is written back
  */
 int ver_focal_loss_blocks(long N, int C);
 int ver_focal_loss_forward(const void* logits, const int64_t* target, float* partial, long N, int C,

@@ -96,6 +96,7 @@ def flops(name, shapes):
 rows = collections.OrderedDict()
 other = collections.Counter()
 other_ops = collections.Counter()
+other_cnt = collections.Counter()
 total_gpu = sum(k['dur'] for k in kernels)
 for k in kernels:
     nm = k['name']
@@ -105,6 +106,7 @@ for k in kernels:
         la = launches.get(k['args'].get('correlation'))
         op = owner(la, True) if la else None
         other_ops[(op['name'] if op else '?', json.dumps(op['args'].get('Input Dims'))[:90] if op else '')] += k['dur']
+        other_cnt[(op['name'] if op else '?', nm[:50])] += 1
         continue
     la = launches.get(k['args'].get('correlation'))
     op = owner(la) if la else None
@@ -126,6 +128,8 @@ with open(a.out, 'w') as f:
     f.write('# GEMM kernels total %.2f ms of %.2f ms GPU time (%.1f %%)\n' % (tot / 1e3, total_gpu / 1e3, 100.0 * tot / total_gpu))
     for nm, us in other.most_common(25):
         f.write('# other %-60s %.3f ms\n' % (nm, us / 1e3))
+    for (opn, kn), n in other_cnt.most_common(60):
+        f.write('# launches-by-op %-44s %-52s %d\n' % (opn, kn, n))
     for (nm, dims), us in other_ops.most_common(40):
         f.write('# other-by-op %-40s %-92s %.3f ms\n' % (nm, dims, us / 1e3))
 print(open(a.out).read()[:6000])

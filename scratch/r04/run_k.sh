@@ -1,7 +1,9 @@
 #!/bin/bash
+cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_hip_ops_gpu.py tests/test_encoder_gpu.py -x -q -k "sca or spatial or encoder" 2>&1 | tail -3
-for B in 64 192; do
-  VER_BENCH_PREZERO=1 VER_BENCH_RING=1 timeout 300 python scratch/bench_gather.py $B 4x15x15 bf16 2>&1 | grep -v amdgpu.ids
-done
-timeout 300 python scratch/bench_gather.py 32 4x15x15 2>&1 | grep -v amdgpu.ids
+R=gpurun_out/r04k; mkdir -p $R
+timeout 900 python -m pytest tests/test_hip_ops_gpu.py -x -q -k "run_gather or lattice or occ_proj" 2>&1 | tail -2
+CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= --host-fed-steps 0 --sub-records="
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/trace -o trace -- python3 $CMD > $R/trace_bench.json 2> $R/trace.err; echo "trace $?"
+python scratch/prof_summary.py kernels $R/trace/trace_results.db $R/kernel_stats.csv; rm -rf $R/trace
+grep "k_run_copy\|k_lattice\|k_focal" $R/kernel_stats.csv | cut -c1-60,120-260

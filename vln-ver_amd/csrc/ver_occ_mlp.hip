@@ -58,9 +58,24 @@ __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// fp32 -> bf16 (round to nearest even) as PAIRS: the compiler splits a 4-wide conversion into single-value
+// v_cvt_pk_bf16_f32 (second source zero) and merges the halves with v_perm_b32 -- three instructions per two values; a 2-wide
+// conversion is the one packed instruction
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ bf16x4 pack4(f32x4 v) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t r = {pack2(v.x, v.y), pack2(v.z, v.w)};
+    return __builtin_bit_cast(bf16x4, r);
+}
 __device__ __forceinline__ bf16x8 pack8(f32x4 lo, f32x4 hi) {
-    bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t r = {pack2(lo.x, lo.y), pack2(lo.z, lo.w), pack2(hi.x, hi.y), pack2(hi.z, hi.w)};
+    return __builtin_bit_cast(bf16x8, r);
 }
 // ReLU AFTER the bf16 pack: a bf16 bit pattern orders like an int16 on its sign, so max(x, 0) on the packed pairs is one
 // v_pk_max_i16 per TWO values (gfx950 has no packed fp32 max: the fp32 form is one v_max_f32 per value).  -0.0 and negative
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const long r = r0 + rt * 16 + c;
-            if (r < N) *reinterpret_cast<bf16x4*>(logits + r * kC + 4 * g) = __builtin_convertvector(lo[rt], bf16x4);
+            if (r < N) *reinterpret_cast<bf16x4*>(logits + r * kC + 4 * g) = pack4(lo[rt]);
         }
     }
 }
@@ -901,7 +916,7 @@ __global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __rest
             }
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot)
-                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(acc[ot], bf16x4);
+                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = pack4(acc[ot]);
             __builtin_amdgcn_sched_barrier(0);         // (keeps the operand reads of the next row tiles from piling up in registers)
         }
         __syncthreads();
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __rest
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
                 const f32x4 d = mfma(wa3[ot], b, zero4);
-                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(d, bf16x4);
+                *reinterpret_cast<bf16x4*>(T1 + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = pack4(d);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -978,7 +993,7 @@ __global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __rest
                 for (int kt = 0; kt < OT; ++kt) acc[kt] = mfma(wb2[kt][ks], b, acc[kt]);
             }
 #pragma unroll
-            for (int kt = 0; kt < OT; ++kt) dh1[rt][kt] = __builtin_convertvector(acc[kt], bf16x4);
+            for (int kt = 0; kt < OT; ++kt) dh1[rt][kt] = pack4(acc[kt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -1244,7 +1259,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             }
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot)
-                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(acc[ot], bf16x4);
+                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = pack4(acc[ot]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1255,7 +1270,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
                 const f32x4 d = mfma(wa3[ot], b, zero4);
-                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = __builtin_convertvector(d, bf16x4);
+                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = pack4(d);
             }
         }
 #pragma unroll
@@ -1300,7 +1315,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             }
 #pragma unroll
             for (int kt = 0; kt < OT; ++kt)
-                *reinterpret_cast<bf16x4*>(T4 + (16 * rt + c) * kNsLd + f0 + 16 * kt + 4 * g) = __builtin_convertvector(acc[kt], bf16x4);
+                *reinterpret_cast<bf16x4*>(T4 + (16 * rt + c) * kNsLd + f0 + 16 * kt + 4 * g) = pack4(acc[kt]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };

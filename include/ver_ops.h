@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 23
+#define VER_ABI_VERSION 24
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -424,6 +424,25 @@ int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const flo
 long ver_occ_predict_blocks(long N);
 int  ver_occ_predict(const void* logits, int dtype, long N, int C, float threshold, int32_t* block_work,
                      int64_t* pairs, int64_t* count, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight gradient of the head's GEMM layers with ROWS on the contraction axis (ABI 24):
+ *     out[Ka, N] = A[M, Ka]^T G[M, N]
+ * A = the operand of the forward GEMM (tap matrix of a lattice layer / gathered occ_proj rows), G = the gradient of
+ * its output; replaces the `a.t() @ g` of dense_heads/upsample.py::rows_tn, i.e. the d(weight) of the reference's
+ * ConvTranspose3d stack and occ_proj (voxelformer_occupancy_head.py:251-258, :560, :571) as autograd forms it.
+ *   a          bf16 [M, lda]  (the first Ka columns are used; a column range of a wider matrix is passed by pointer)
+ *   g          bf16 [M, ldg]  (first N columns)
+ *   out        bf16 | f32 [Ka, ldo]  (out_dtype VER_BF16 | VER_F32), written
+ *   workspace  f32 [splits, Ka, N]: the row axis is split into `splits` chunks (0: ver_wgrad_tn_splits), every
+ *              chunk's product stays fp32 until the chunks are added up (no bf16 rounding of partial sums)
+ * Requirements: a, g 16-byte aligned, lda % 8 == 0, ldg % 8 == 0, N % 4 == 0, ldo % 4 == 0, M % (16 splits) == 0.
+ * flags: bits 0-2 = prefetch distance in 16-row slabs (3..6; 0 = default).
+ */
+int  ver_wgrad_tn_splits(long M, int Ka, int N);
+long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits);
+int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int Ka, int N, void* out, long ldo,
+                  int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

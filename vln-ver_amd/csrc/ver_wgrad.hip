@@ -1,0 +1,333 @@
+// Weight-gradient product of the occupancy head's GEMM layers on gfx950 matrix cores:
+//     dW[Ka, N] = A[M, Ka]^T * G[M, N]        (bf16 operands, fp32 accumulation, rows on the contraction axis)
+// A is the tap matrix / gathered occ_proj operand of the forward GEMM (possibly a column range of a wider row-major
+// matrix), G the gradient of the GEMM's output: dense_heads/upsample.py::rows_tn, i.e. the d(weight) of the reference's
+// three ConvTranspose3d and of occ_proj (voxelformer_occupancy_head.py:251-258, :560, :571).
+//
+// Both operands are row-major with the CONTRACTION index on the slow axis, which is the one layout class the library
+// answers with depth-32 macro-tiles (0.35-0.43 of the bf16 peak).  Here:
+//   * rows are streamed in slabs of 16 (one k-step of v_mfma_f32_32x32x16_bf16) straight into LDS by LDS-DMA
+//     (buffer_load_dwordx4 ... lds): a wave instruction moves 8 rows x 128 B, i.e. whole 128-byte lines of the source;
+//   * the MFMA fragments (8 consecutive k of ONE column per lane) come out of that row-major image through
+//     ds_read_b64_tr_b16, two per fragment; the 16-byte chunks of a 128-byte line are XOR-ed by bit 1 of the row on the
+//     SOURCE address (the LDS-DMA destination is lane-linear), which makes every transposing read conflict free;
+//   * a workgroup of 8 waves (2 x 4, wave tile 128 x 64 = 4 x 2 MFMA tiles, 128 accumulator registers) owns a
+//     256 x 256 output tile of one row chunk; the two wave groups (wr = 0 / 1, one wave of each per SIMD) run
+//     half a phase apart: while one issues its 12 fragment reads + 2 LDS-DMA pieces of the slab PF phases ahead, the
+//     other issues its 8 MFMAs (ring of 8 slabs = 128 KB, counted vmcnt, raw s_barrier);
+//   * split over row chunks: block b runs on XCD b % 8 and XCD x works on chunks x, x + 8, ...: the rows of a chunk are
+//     fetched into ONE L2, where the ~32 tiles of the XCD that are in flight share them; fp32 partial tiles go to a
+//     workspace and k_wgrad_reduce adds them up in fp32 (no bf16 rounding of partial sums).
+#include "ver_common.h"
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kTile = 256;                  // output tile edge
+constexpr int kSlabRows = 16;               // rows per slab = k of one MFMA
+constexpr int kSlabBytes = 2 * kSlabRows * kTile * 2;   // A part + G part
+constexpr int kRing = 8;
+constexpr int kLdsBytes = kRing * kSlabBytes;           // 128 KiB
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ds_read_b64_tr_b16 as inline asm: behind the builtin the compiler waits for vmcnt(0) in front of every LDS read
+// that follows an LDS-DMA (it cannot tell the ring slots apart), which would serialise the whole pipeline.  The
+// results are only valid behind the s_waitcnt lgkmcnt(0) of phase() (the compiler does not count these reads).
+template <int OFF>
+__device__ __forceinline__ i32x2 tr_read(int addr) {
+    i32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8 frag(i32x2 lo, i32x2 hi) {
+    return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+
+struct WgradArgs {
+    const __bf16* A;
+    const __bf16* G;
+    float* ws;          // [S][Ka][N] fp32 partial products
+    long lda, ldg, M, Mc;
+    int S, Ka, N, tiles_n, T;
+};
+
+// One phase: fragments of slab `p` (ring slot SLOT) -> registers, LDS-DMA of slab p + PF, 8 MFMAs.
+template <int SLOT, int PF>
+__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], int offA0, int offA1, int offB0, int offB1,
+                                      __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, int voA, int voG,
+                                      int& soA, int& soG, int stepA, int stepG, int dmaoff) {
+    // (the offset field of a DS instruction has 16 bits: slots 4-7 go through base registers 64 KiB up)
+    constexpr int SB = (SLOT & 3) * kSlabBytes;
+    if constexpr (SLOT >= 4) {
+        offA0 += 65536;
+        offA1 += 65536;
+        offB0 += 65536;
+        offB1 += 65536;
+    }
+    i32x2 al[4], ah[4], bl[2], bh[2];
+    al[0] = tr_read<SB>(offA0);
+    ah[0] = tr_read<SB + 512>(offA0);
+    bl[0] = tr_read<SB>(offB0);
+    bh[0] = tr_read<SB + 512>(offB0);
+    al[1] = tr_read<SB>(offA1);
+    ah[1] = tr_read<SB + 512>(offA1);
+    bl[1] = tr_read<SB>(offB1);
+    bh[1] = tr_read<SB + 512>(offB1);
+    al[2] = tr_read<SB + 1024>(offA0);
+    ah[2] = tr_read<SB + 1536>(offA0);
+    al[3] = tr_read<SB + 1024>(offA1);
+    ah[3] = tr_read<SB + 1536>(offA1);
+    constexpr int DS = (SLOT + PF) % kRing;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS * kSlabBytes + dmaoff), 16, voA, soA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + DS * kSlabBytes + kSlabBytes / 2 + dmaoff), 16, voG, soG, 0, 0);
+    soA += stepA;
+    soG += stepG;
+    // this wave's pieces of the NEXT slab have landed (everything younger stays in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    // the fragment halves pass through the wait as operands: whatever the compiler does to them (copies into the
+    // MFMA's register tuples) is ordered behind it
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
+                   "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                 :
+                 : "memory");
+    bf16x8 a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = frag(al[i], ah[i]);
+    b[0] = frag(bl[0], bh[0]);
+    b[1] = frag(bl[1], bh[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+            acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[jt], acc[it][jt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int PF>
+__global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int chunk, tile;
+    {
+        const int b = blockIdx.x;
+        if ((p.S & 7) == 0) {               // block b runs on XCD b % 8: an XCD keeps to its own row chunks
+            const int xcd = b & 7, idx = b >> 3;
+            chunk = xcd + 8 * (idx / p.T);
+            tile = idx % p.T;
+        } else {
+            chunk = b / p.T;
+            tile = b % p.T;
+        }
+    }
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const long row0 = (long)chunk * p.Mc;
+    const long rows = min(p.Mc, p.M - row0);
+    const int nslab = (int)(rows / kSlabRows);
+
+    // LDS-DMA: wave w moves piece (row group w >> 2, 64-column block w & 3) of the A part and of the G part
+    const __bf16* ab = p.A + row0 * p.lda + (long)mt * kTile;
+    const __bf16* gb = p.G + row0 * p.ldg + (long)nt * kTile;
+    const long abytes = ((p.M - row0) * p.lda - (long)mt * kTile) * 2, gbytes = ((p.M - row0) * p.ldg - (long)nt * kTile) * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)min(abytes, 0xFFFFFFFFL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, (int)min(gbytes, 0xFFFFFFFFL), 0x00020000);
+    const int prow = lane >> 3, pch = (lane & 7) ^ (((prow >> 1) & 1) << 2);
+    const int voA = (int)(((8 * (wave >> 2) + prow) * p.lda + 64 * (wave & 3)) * 2) + pch * 16;
+    const int voG = (int)(((8 * (wave >> 2) + prow) * p.ldg + 64 * (wave & 3)) * 2) + pch * 16;
+    const int stepA = (int)(kSlabRows * p.lda * 2), stepG = (int)(kSlabRows * p.ldg * 2);
+    const int dmaoff = wave * 1024;
+    int soA = 0, soG = 0;
+
+    // transposing fragment reads: 16-lane group q = (k half, column half), lane c of it addresses row c >> 2,
+    // columns 4 (c & 3) .. + 3 and receives column c of the group's 4 x 16 block
+    const int q = lane >> 4, c = lane & 15;
+    const int lowch = (2 * (q & 1) + ((c & 3) >> 1)) ^ (((c >> 3) & 1) << 2);
+    const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const int rowoff = lbase + ((q >> 1) * 32 + (c >> 2)) * 128 + lowch * 16 + (c & 1) * 8;
+    const int offA0 = rowoff + 2 * wr * 1024, offA1 = offA0 ^ 64;
+    const int offB0 = rowoff + wc * 1024 + kSlabBytes / 2, offB1 = offB0 ^ 64;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.0f;
+
+    // prologue: slabs 0 .. PF-1 in flight, slab 0 landed
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + dmaoff), 16, voA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + dmaoff), 16, voG, soG, 0, 0);
+        soA += stepA;
+        soG += stepG;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave group runs half a phase behind
+
+    int s = 0;
+    for (; s + kRing <= nslab; s += kRing) {
+        phase<0, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<1, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<2, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<3, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<4, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<5, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<6, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+        phase<7, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    }
+    const int rem = nslab - s;                          // < 8 slabs left: same phases, wave-uniform exits
+    if (rem > 0) phase<0, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 1) phase<1, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 2) phase<2, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 3) phase<3, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 4) phase<4, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 5) phase<5, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (rem > 6) phase<6, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two groups match again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead pieces nobody reads
+
+    // partial tile -> workspace: register r of tile (it, jt) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+    float* out = p.ws + (long)chunk * p.Ka * p.N;
+    const int i0 = mt * kTile + 128 * wr + 4 * (lane >> 5), j0 = nt * kTile + 64 * wc + (lane & 31);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int j = j0 + 32 * jt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 32 * it + (r & 3) + 8 * (r >> 2);
+                if (i < p.Ka && j < p.N) out[(long)i * p.N + j] = acc[it][jt][r];
+            }
+        }
+}
+
+// out[i][j] (bf16 or fp32, row pitch ldo) = sum over the S partial products, fp32; 4 elements per thread
+template <typename OT>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ ws, OT* __restrict__ out, long ldo, int S,
+                                                      int Ka, int N) {
+    const long n4 = (long)Ka * N / 4;
+    const long stride = (long)Ka * N;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 acc = *reinterpret_cast<const float4*>(ws + 4 * e);
+        for (int s = 1; s < S; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + s * stride + 4 * e);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+        const long i = (4 * e) / N, j = (4 * e) - i * N;
+        OT* o = out + i * ldo + j;
+        if constexpr (sizeof(OT) == 4) {
+            *reinterpret_cast<float4*>(o) = acc;
+        } else {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 v;
+            v.x = (__bf16)acc.x;
+            v.y = (__bf16)acc.y;
+            v.z = (__bf16)acc.z;
+            v.w = (__bf16)acc.w;
+            *reinterpret_cast<bf16x4*>(o) = v;
+        }
+    }
+}
+
+int pick_splits(long M, int Ka, int N) {
+    const long tiles = (long)((Ka + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
+    // a multiple of 8 chunks (an XCD keeps to its own chunks), >= ~8 rounds of 256 workgroups, chunks of >= 2048 rows
+    int s = 8;
+    while (s < 64 && tiles * s < 8 * 256 && M / (2 * s) >= 2048) s *= 2;
+    while (s > 1 && M % (16L * s)) s /= 2;
+    return s;
+}
+
+template <int PF>
+void launch_tn(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
+    auto kern = k_wgrad_tn<PF>;
+    e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
+}
+}  // namespace
+
+extern "C" int ver_wgrad_tn_splits(long M, int Ka, int N) {
+    if (M <= 0 || Ka <= 0 || N <= 0) return 1;
+    return pick_splits(M, Ka, N);
+}
+
+extern "C" long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits) {
+    if (Ka <= 0 || N <= 0) return 0;
+    if (splits <= 0) splits = ver_wgrad_tn_splits(M, Ka, N);
+    return (long)splits * Ka * N * (long)sizeof(float);
+}
+
+extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int Ka, int N, void* out, long ldo,
+                            int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VER_REQUIRE(M >= 0 && Ka > 0 && N > 0, VER_EINVAL, "ver_wgrad_tn: bad sizes M=%ld Ka=%d N=%d", M, Ka, N);
+    VER_REQUIRE(a && g && out && workspace, VER_EINVAL, "ver_wgrad_tn: null pointer argument");
+    VER_REQUIRE(out_dtype == VER_F32 || out_dtype == VER_BF16, VER_EINVAL, "ver_wgrad_tn: out_dtype %d", out_dtype);
+    VER_REQUIRE(lda >= Ka && ldg >= N && ldo >= N, VER_EINVAL, "ver_wgrad_tn: row pitch smaller than the row");
+    VER_REQUIRE(lda % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)g & 15) == 0, VER_EUNSUPPORTED,
+                "ver_wgrad_tn: operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
+                "ver_wgrad_tn: N and the output pitch must be multiples of 4");
+    const int S = splits > 0 ? splits : pick_splits(M, Ka, N);
+    VER_REQUIRE(M % (16L * S) == 0, VER_EUNSUPPORTED, "ver_wgrad_tn: M=%ld is not a multiple of 16 x %d row chunks", M, S);
+    const long Mc = M / S;
+    VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0x7FFFFFFFL, VER_EUNSUPPORTED,
+                "ver_wgrad_tn: a row chunk exceeds the 2-GiB buffer range");
+    VER_REQUIRE(workspace_bytes >= (long)S * Ka * N * (long)sizeof(float), VER_EINVAL, "ver_wgrad_tn: workspace of %ld bytes, %ld needed",
+                workspace_bytes, (long)S * Ka * N * (long)sizeof(float));
+    WgradArgs p;
+    p.A = (const __bf16*)a;
+    p.G = (const __bf16*)g;
+    p.ws = (float*)workspace;
+    p.lda = lda;
+    p.ldg = ldg;
+    p.M = M;
+    p.Mc = Mc;
+    p.S = S;
+    p.Ka = Ka;
+    p.N = N;
+    p.tiles_n = (N + kTile - 1) / kTile;
+    p.T = ((Ka + kTile - 1) / kTile) * p.tiles_n;
+    hipError_t e = hipSuccess;
+    if (M > 0) {
+        switch (flags & 7) {
+            case 3: launch_tn<3>(p, p.T * S, st, e); break;
+            case 4: launch_tn<4>(p, p.T * S, st, e); break;
+            case 6: launch_tn<6>(p, p.T * S, st, e); break;
+            default: launch_tn<5>(p, p.T * S, st, e); break;
+        }
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn: LDS attribute: %s", hipGetErrorString(e));
+    } else {
+        e = hipMemsetAsync(workspace, 0, (size_t)S * Ka * N * sizeof(float), st);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn: memset: %s", hipGetErrorString(e));
+    }
+    const long n4 = (long)Ka * N / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (out_dtype == VER_F32)
+        hipLaunchKernelGGL(k_wgrad_reduce<float>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, (float*)out, ldo, S, Ka, N);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce<__bf16>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, (__bf16*)out, ldo, S, Ka, N);
+    return ver_check_launch("ver_wgrad_tn");
+}

@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
@@ -24,7 +24,8 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
-           'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict')
+           'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
+           'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn')
 
 _lib = None
 
@@ -48,6 +49,7 @@ def lib():
         handle.ver_last_error.restype = ctypes.c_char_p
         handle.ver_occ_mlp_image_bytes.restype = ctypes.c_long
         handle.ver_occ_predict_blocks.restype = ctypes.c_long
+        handle.ver_wgrad_tn_workspace.restype = ctypes.c_long
         if handle.ver_abi_version() != ABI_VERSION:
             raise HipLibraryError('libver_hip.so ABI %d != expected %d: rebuild'
                                   % (handle.ver_abi_version(), ABI_VERSION))
@@ -1041,3 +1043,36 @@ def occ_predict(logits, threshold=0.25):
     _launch('ver_occ_predict', lambda: lib().ver_occ_predict(
         _p(logits), dt, ctypes.c_long(n), c, ctypes.c_float(threshold), _p(work), _p(pairs), _p(count), _stream()))
     return pairs[:int(count.item())]
+
+
+# ------------------------------------------------------------------------------------------
+def wgrad_tn_supported(a, g):
+    """Shapes / strides ``wgrad_tn`` takes: bf16 GPU matrices, unit column stride, 16-byte aligned rows."""
+    return (a.is_cuda and g.is_cuda and a.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and a.dim() == 2
+            and g.dim() == 2 and a.shape[0] == g.shape[0] and a.stride(1) == 1 and g.stride(1) == 1
+            and a.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0
+            and g.shape[1] % 4 == 0 and a.shape[0] % 128 == 0)
+
+
+def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0):
+    """``a.t() @ g`` for tall bf16 operands with the ROWS on the contraction axis (ver_wgrad_tn): a [M, Ka] (may be a
+    column range of a wider row-major matrix), g [M, N] -> [Ka, N] in ``out_dtype`` (default: a's dtype), fp32
+    accumulation over all rows.  The weight gradient of a lattice layer / of occ_proj (dense_heads/upsample.py::rows_tn)."""
+    if not wgrad_tn_supported(a, g):
+        raise RuntimeError('wgrad_tn: unsupported operands %s %s / %s %s' % (tuple(a.shape), a.stride(), tuple(g.shape), g.stride()))
+    m, ka = a.shape
+    n = g.shape[1]
+    out_dtype = out_dtype or a.dtype
+    if out_dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError('wgrad_tn: out_dtype must be bf16 or fp32')
+    L = lib()
+    if splits <= 0:
+        splits = L.ver_wgrad_tn_splits(ctypes.c_long(m), ka, n)
+    nbytes = L.ver_wgrad_tn_workspace(ctypes.c_long(m), ka, n, splits)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
+    out = torch.empty(ka, n, dtype=out_dtype, device=a.device)
+    _launch('ver_wgrad_tn', lambda: L.ver_wgrad_tn(
+        _p(a), ctypes.c_long(a.stride(0)), _p(g), ctypes.c_long(g.stride(0)), ctypes.c_long(m), ka, n, _p(out),
+        ctypes.c_long(n), 1 if out_dtype == torch.bfloat16 else 0, int(splits), int(flags), _p(ws), ctypes.c_long(nbytes),
+        _stream()), meta=dict(flops=2.0 * m * ka * n))
+    return out

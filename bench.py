@@ -575,6 +575,35 @@ def main():
                     roof = obj
                 else:
                     others.append(obj)
+        # the dense part ("MFMA utilisation for the dense part"): the head's GEMMs -- the three lattice layers
+        # and occ_proj, forward / d(input) through hipBLASLt, d(weight) through ver_wgrad_tn -- bracketed by HIP events on
+        # the launch stream in the timed region; flops = 2 m k n of every GEMM AS EXECUTED (with the constant / pad columns
+        # the operands carry, ~3 % over the useful count).  `whole_step` prices the USEFUL multiply-adds of one step
+        # (473.9 GFLOP per viewpoint forward, x 3 with the two backward products) on the step time.
+        classes = (('head_gemm_fwd', 'hipBLASLt N x N'), ('head_gemm_dgrad', 'hipBLASLt N x T'),
+                   ('ver_wgrad_tn', 'ver_wgrad_tn (csrc/ver_wgrad.hip)'))
+        tot_f = tot_ms = 0.0
+        for name, impl in classes:
+            if name in kt and kt[name]['ms'] > 0:
+                tf = kt[name]['flops'] / (kt[name]['ms'] * 1e-3) / 1e12
+                tot_f += kt[name]['flops']
+                tot_ms += kt[name]['ms']
+                others.append(dict(kernel=name, implementation=impl, bound='mfma', achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF,
+                                   unit='TFLOP/s', frac=round(tf / MFMA_BF16_PEAK_TF, 4), launches=kt[name]['count'],
+                                   ms_per_step=round(kt[name]['ms'] / args.steps, 3),
+                                   tflop_per_step=round(kt[name]['flops'] / args.steps / 1e12, 3)))
+        if tot_ms > 0 and args.dtype == 'bf16':
+            tf = tot_f / (tot_ms * 1e-3) / 1e12
+            others.append(dict(kernel='head_gemms', bound='mfma', achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s',
+                               frac=round(tf / MFMA_BF16_PEAK_TF, 4), ms_per_step=round(tot_ms / args.steps, 3),
+                               tflop_per_step=round(tot_f / args.steps / 1e12, 3),
+                               note='lattice layers 1-3 + occ_proj: forward, d(input), d(weight); HIP events, flops as executed'))
+        if train and not full and args.dtype == 'bf16' and args.workload == 'vocc_c2f_train' and args.config is None:
+            useful = 3 * 473.9e9 * B * args.steps                       # fwd + dgrad + wgrad of every GEMM of the path
+            tf = useful / elapsed / 1e12
+            others.append(dict(kernel='whole_step', bound='mfma', achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TF, unit='TFLOP/s',
+                               frac=round(tf / MFMA_BF16_PEAK_TF, 4),
+                               note='useful multiply-adds of the step (473.9 GFLOP per viewpoint forward x 3) / step time'))
         total_vp = B * world * args.steps
         line = {
             'metric': 'viewpoints/sec (multi-view->voxel fwd+bwd), vocc.py config' if train

@@ -436,7 +436,7 @@ int  ver_occ_predict(const void* logits, int dtype, long N, int C, float thresho
  *   out        bf16 | f32 [Ka, ldo]  (out_dtype VER_BF16 | VER_F32), written
  *   workspace  f32 [splits, Ka, N]: the row axis is split into `splits` chunks (0: ver_wgrad_tn_splits), every
  *              chunk's product stays fp32 until the chunks are added up (no bf16 rounding of partial sums)
- * Requirements: a, g 16-byte aligned, lda % 8 == 0, ldg % 8 == 0, N % 4 == 0, ldo % 4 == 0, M % (16 splits) == 0.
+ * Requirements: a, g 16-byte aligned, lda % 8 == 0, ldg % 8 == 0, N % 4 == 0, ldo % 4 == 0; any M (M = 0: zeros).
  * flags: bits 0-2 = prefetch distance in 16-row slabs (3..6; 0 = default).
  */
 int  ver_wgrad_tn_splits(long M, int Ka, int N);

@@ -31,7 +31,8 @@ if 'check' in what:
     torch.manual_seed(0)
     for (M, Ka, ld, c0, N, ldg, S) in [(2048, 256, 256, 0, 256, 256, 1), (4096, 480, 640, 64, 384, 384, 2),
                                        (16384, 224, 1024, 128, 260, 264, 8), (32768, 1000, 1024, 0, 772, 776, 16),
-                                       (128 * 40, 256, 256, 0, 256, 256, 8)]:
+                                       (128 * 40, 256, 256, 0, 256, 256, 8), (1800, 300, 304, 0, 132, 136, 0), (14400 + 7, 520, 520, 0, 256, 256, 3),
+                                       (50000, 64, 64, 0, 64, 64, 0)]:
         Af = torch.randn(M, ld, device=dev).to(torch.bfloat16)
         Gf = torch.randn(M, ldg, device=dev).to(torch.bfloat16)
         A, G = Af[:, c0:c0 + Ka], Gf[:, :N]
@@ -62,7 +63,7 @@ if 'big' in what or 'sweep' in what:
         ref = lib_tn(A, G).float()
         row = dict(shape=name, M=M, Ka=Ka, N=N, gflop=gf, lib_ms=round(ms0, 3), lib_tf=round(gf / ms0, 1))
         print(name, 'library bmm x8: %.3f ms = %.0f TFLOP/s' % (ms0, gf / ms0), flush=True)
-        combos = [(0, 0)] if 'sweep' not in what else [(s, f) for s in (8, 16, 32) for f in (3, 4, 5, 6)]
+        combos = [(0, 0)] if 'sweep' not in what else [(s, f) for s in (8, 16, 24, 32) for f in (3, 4, 5, 6)]
         for s, f in combos:
             try:
                 ms = timeit(lambda: hip.wgrad_tn(A, G, splits=s, flags=f))

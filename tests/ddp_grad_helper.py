@@ -2,6 +2,8 @@
 
     python ddp_grad_helper.py single <data_rank> <out.pt>        one process, the data of `data_rank`, gradients saved
     torchrun --nproc-per-node 2 ddp_grad_helper.py ddp <out.pt>  two gloo ranks on the one GPU, rank 0 saves ITS gradients
+    torchrun --nproc-per-node 1 ddp_grad_helper.py rccl <out.pt> ONE rank on an RCCL ('nccl') communicator with the bf16
+                                                                 compression hook bench.py uses for N > 1
 
 Both run ONE step of bench.py's LiftTrainer (the real HIP path: custom autograd Functions, frozen parameters,
 gradient_as_bucket_view) in fp32 with dropout p = 0 at two viewpoints per rank, from the same seeded weights."""
@@ -24,8 +26,12 @@ def main():
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(0)
     rank, world = 0, 1
-    if mode == 'ddp':
-        dist.init_process_group('gloo')
+    if mode in ('ddp', 'rccl'):
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if mode == 'rccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group('gloo')
         rank, world = dist.get_rank(), dist.get_world_size()
         data_rank, out = rank, sys.argv[2]
     else:
@@ -36,7 +42,9 @@ def main():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     model = bench.LiftTrainer(head, 2, 'fp32').to(dev).train()
-    net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=False) if mode == 'ddp' else model
+    net = model
+    if mode != 'single':        # (bench.py: bf16_gradients = backend == 'nccl')
+        net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=mode == 'rccl')
     B = 2
     w2p_np, org_np = syn.camera_batch(B, seed=1 + data_rank)
     feats = torch.from_numpy(syn.vit_features(B, seed=100 + data_rank)).to(dev).permute(1, 0, 2, 3).contiguous()
@@ -48,7 +56,7 @@ def main():
     if rank == 0:
         torch.save(dict(loss=float(loss), grads={k: p.grad.detach().float().cpu() for k, p in model.named_parameters()
                                                  if p.requires_grad and p.grad is not None}), out)
-    if mode == 'ddp':
+    if mode != 'single':
         dist.barrier()
         dist.destroy_process_group()
 

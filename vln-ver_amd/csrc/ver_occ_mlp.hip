@@ -1416,6 +1416,8 @@ extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits
         return ver_check_launch("ver_occ_mlp_backward_fused");
     }
     VER_REQUIRE(!grad_scale, VER_EUNSUPPORTED, "ver_occ_mlp_backward_fused: grad_scale needs the wave-specialised kernel");
+    // (VER_OCC_MLP_CENTERED is a hint, not a contract: this kernel's LayerNorm always computes the row mean, which is
+    //  ~0 on centred rows -- same results, no skipped pass)
     static const int nw = [] {
         const char* ev = getenv("VER_OCC_MLP_NS_WAVES");       // 8: 128-row blocks, two waves per SIMD; 4: 64-row blocks
         const int v = ev ? atoi(ev) : 8;

@@ -136,15 +136,18 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     }
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const long row0 = (long)chunk * p.Mc;
-    const long rows = min(p.Mc, p.M - row0);
-    const int nslab = (int)(rows / kSlabRows);
+    const long rows = max(0L, min(p.Mc, p.M - row0));
+    const int nslab = (int)((rows + kSlabRows - 1) / kSlabRows);        // rows past M read as zeros (buffer range)
 
     // LDS-DMA: wave w moves piece (row group w >> 2, 64-column block w & 3) of the A part and of the G part
     const __bf16* ab = p.A + row0 * p.lda + (long)mt * kTile;
     const __bf16* gb = p.G + row0 * p.ldg + (long)nt * kTile;
-    const long abytes = ((p.M - row0) * p.lda - (long)mt * kTile) * 2, gbytes = ((p.M - row0) * p.ldg - (long)nt * kTile) * 2;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)min(abytes, 0xFFFFFFFFL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, (int)min(gbytes, 0xFFFFFFFFL), 0x00020000);
+    // buffer ranges end with the last valid element of the operand (column Ka / N of row M - 1): what lies behind reads
+    // as zero, what lies beside a row (other columns of a wider matrix) only reaches outputs that are never stored
+    const long abytes = ((p.M - row0 - 1) * p.lda + p.Ka - (long)mt * kTile) * 2;
+    const long gbytes = ((p.M - row0 - 1) * p.ldg + p.N - (long)nt * kTile) * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, (int)max(0L, min(gbytes, 0xFFFFFFFFL)), 0x00020000);
     const int prow = lane >> 3, pch = (lane & 7) ^ (((prow >> 1) & 1) << 2);
     const int voA = (int)(((8 * (wave >> 2) + prow) * p.lda + 64 * (wave & 3)) * 2) + pch * 16;
     const int voG = (int)(((8 * (wave >> 2) + prow) * p.ldg + 64 * (wave & 3)) * 2) + pch * 16;
@@ -252,10 +255,11 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 int pick_splits(long M, int Ka, int N) {
     const long tiles = (long)((Ka + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    // a multiple of 8 chunks (an XCD keeps to its own chunks), >= ~8 rounds of 256 workgroups, chunks of >= 2048 rows
-    int s = 8;
-    while (s < 64 && tiles * s < 8 * 256 && M / (2 * s) >= 2048) s *= 2;
-    while (s > 1 && M % (16L * s)) s /= 2;
+    // >= ~8 rounds of 256 workgroups, but the fp32 partial tiles (8 B of traffic per element and chunk) must stay
+    // small against the product itself: chunks of >= 12 000 rows.  From 8 chunks on an XCD keeps to its own chunks.
+    int s = 1;
+    while (s < 64 && tiles * s < 8 * 256 && M / (2 * s) >= 12000) s *= 2;
+    while (s < 1024 && M / s > 45000) s *= 2;            // a chunk stays inside the 4-GiB range of a buffer offset
     return s;
 }
 
@@ -290,10 +294,10 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
     VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
                 "ver_wgrad_tn: N and the output pitch must be multiples of 4");
     const int S = splits > 0 ? splits : pick_splits(M, Ka, N);
-    VER_REQUIRE(M % (16L * S) == 0, VER_EUNSUPPORTED, "ver_wgrad_tn: M=%ld is not a multiple of 16 x %d row chunks", M, S);
-    const long Mc = M / S;
-    VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0x7FFFFFFFL, VER_EUNSUPPORTED,
-                "ver_wgrad_tn: a row chunk exceeds the 2-GiB buffer range");
+    VER_REQUIRE(S <= 1024, VER_EINVAL, "ver_wgrad_tn: %d row chunks", S);
+    const long Mc = ((M + S - 1) / S + kSlabRows - 1) / kSlabRows * kSlabRows;      // rows per chunk, whole slabs
+    VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0xFFFFFFFFL, VER_EUNSUPPORTED,
+                "ver_wgrad_tn: a row chunk exceeds the 4-GiB range of a buffer offset (more splits)");
     VER_REQUIRE(workspace_bytes >= (long)S * Ka * N * (long)sizeof(float), VER_EINVAL, "ver_wgrad_tn: workspace of %ld bytes, %ld needed",
                 workspace_bytes, (long)S * Ka * N * (long)sizeof(float));
     WgradArgs p;

@@ -69,17 +69,25 @@ class FocalLoss(nn.Module):
             # (hipops.LabelRangeFlag; `check_labels()` below waits for it); the host-side range check with its
             # immediate, readable message costs a device->host sync and a reduction over every label, so it runs on
             # the first fused call of a module only (VER_FOCAL_CHECK=2: every call, 0: never).
-            if target.numel() and (_FOCAL_CHECK >= 2 or (_FOCAL_CHECK == 1 and not self._labels_checked)):
-                self._labels_checked = True
-                lo, hi = torch.aminmax(target)
-                lo, hi = torch.stack((lo, hi)).tolist()
-                if lo < 0 or hi > pred.size(1):
-                    raise RuntimeError('FocalLoss: target labels must be in [0, %d], got [%d, %d]' % (pred.size(1), lo, hi))
+            self.check_label_range(target, pred.size(1))
             from ..hipops import sigmoid_focal_loss_sum
             return self.loss_weight * (sigmoid_focal_loss_sum(pred, target, self.gamma, self.alpha) / avg_factor)
         return self.loss_weight * sigmoid_focal_loss(pred, target, weight, self.gamma, self.alpha,
                                                      reduction, avg_factor)
 
+
+    def check_label_range(self, target, classes):
+        """Host-side range check of the fused paths (this module's forward and the head's fused MLP + focal-loss
+        Function): raises at once, like F.one_hot in the reference, on a module's first fused call
+        (VER_FOCAL_CHECK=2: every call, 0: never); not under stream capture (a device -> host read)."""
+        if not target.numel() or torch.cuda.is_current_stream_capturing():
+            return
+        if _FOCAL_CHECK >= 2 or (_FOCAL_CHECK == 1 and not self._labels_checked):
+            self._labels_checked = True
+            lo, hi = torch.aminmax(target)
+            lo, hi = torch.stack((lo, hi)).tolist()
+            if lo < 0 or hi > classes:
+                raise RuntimeError('FocalLoss: target labels must be in [0, %d], got [%d, %d]' % (classes, lo, hi))
 
     @staticmethod
     def check_labels(device=None):

@@ -28,7 +28,7 @@ geometry by brute force from the definition of the two raw views, so they hold f
 import numpy as np
 import torch
 
-from .upsample import rows_tn
+from .upsample import gemm_timed, rows_tn
 
 _PLAN_CACHE = {}
 
@@ -202,7 +202,8 @@ class _OccProjLattice(torch.autograd.Function):
             pad = g.k_aug - g.n_cols - Z - 1
             wa = torch.cat([w.index_select(1, g.cols), s.to(dt), bias.to(dt)[:, None],
                             w.new_zeros(out_dim, pad)], 1)
-            torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
+            with gemm_timed('head_gemm_fwd', a.shape[0], a.shape[1], wa.shape[0]):
+                torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
             operands.append(a)
             weights.append(wa)
         ctx.plan, ctx.shape, ctx.layout, ctx.e_shape = plan, (bs, Z, Hl, Wl, C), layout, tuple(e.shape)
@@ -231,7 +232,8 @@ class _OccProjLattice(torch.autograd.Function):
                 # [rows, Z] product read all of `go` again for four output columns: 0.85 ms per group at 192 viewpoints,
                 # profiles/r04_gemm_ledger.csv); the run copies take the row pitch of the wider buffer as it is
                 from ..hipops import run_scatter
-                d_all = torch.mm(go, wa)                                             # [bs*n_rows, k_aug] (pads: zero columns)
+                with gemm_timed('head_gemm_dgrad', go.shape[0], go.shape[1], wa.shape[1]):
+                    d_all = torch.mm(go, wa)                                         # [bs*n_rows, k_aug] (pads: zero columns)
                 run_scatter(d_all, d_lat, g.run_start, g.n_rows, g.run_len)
                 d_const = d_all[:, g.n_cols:g.n_cols + Z]
             else:
@@ -240,7 +242,7 @@ class _OccProjLattice(torch.autograd.Function):
                 d_const = torch.mm(go, wa[:, g.n_cols:g.n_cols + Z].contiguous())     # [bs*n_rows, Z]
             d_up.index_add_(0, g.chan, d_const.reshape(bs, -1).sum(0, dtype=acc))
             # d(W_aug^T) = go^T a
-            d_wa = rows_tn(a, go).t().to(acc)                                        # [out, k_aug]
+            d_wa = rows_tn(go, a, out_dtype=acc)                                     # [out, k_aug], fp32 sums
             d_weight.index_add_(1, g.cols, d_wa[:, :g.n_cols])
             for k, n in enumerate(g.ncols_by_token):
                 d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]

@@ -504,7 +504,8 @@ class _Layer0Z4(torch.autograd.Function):
         _gather_z4(x, ZS_PLAIN, a_mat, taps, offs, ci, h, w)
         rows = k.reshape(75 * ci, co)
         wmat = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)        # [50 ci, 2 co]
-        out = torch.addmm(torch.cat([bias, bias]).to(x.dtype), a_mat, wmat)
+        with gemm_timed('head_gemm_fwd', a_mat.shape[0], a_mat.shape[1], wmat.shape[1]):
+            out = torch.addmm(torch.cat([bias, bias]).to(x.dtype), a_mat, wmat)
         ctx.save_for_backward(a_mat, wmat)
         ctx.geom = (tuple(x.shape), ci, co, h, w)
         return out.view(b, 2, h, w, 2, co)
@@ -515,7 +516,9 @@ class _Layer0Z4(torch.autograd.Function):
         shape, ci, co, h, w = ctx.geom
         taps, offs, lo, hi = _layer0_z4_plan(ci, a_mat.device)
         g = grad_out.contiguous().view(-1, 2 * co)
-        d_x = _scatter_z4(torch.mm(g, wmat.t()), ZS_PLAIN, shape, taps, offs, ci, h, w)
+        with gemm_timed('head_gemm_dgrad', g.shape[0], g.shape[1], wmat.shape[0]):
+            d_a = torch.mm(g, wmat.t())
+        d_x = _scatter_z4(d_a, ZS_PLAIN, shape, taps, offs, ci, h, w)
         d_w = rows_tn(a_mat, g)                                                            # [50 ci, 2 co]
         d_lo = d_w.new_zeros(75 * ci, co)
         d_hi = d_w.new_zeros(75 * ci, co)
@@ -641,7 +644,8 @@ class _LatticeLayerZ4(torch.autograd.Function):
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, lohi = plan[cls]
             w = rows.index_select(0, lohi).view(c1 - c0, 2 * co)          # [W_lo | W_hi], one gather
-            torch.mm(a_mat[:, c0:c1], w, out=out[p])
+            with gemm_timed('head_gemm_fwd', m, c1 - c0, 2 * co):
+                torch.mm(a_mat[:, c0:c1], w, out=out[p])
             ws.append(w)
         # the class weight matrices are kept for the backward pass (0.17 GB per layer at Co = 768) instead of being
         # gathered again there: weight-side work does not shrink with the batch (config.latency)
@@ -665,10 +669,11 @@ class _LatticeLayerZ4(torch.autograd.Function):
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, _ = plan[cls]
             w = ws[p]
-            if p == 0:                                          # class (0,0): initialises every tap block
-                torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
-            else:
-                torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
+            with gemm_timed('head_gemm_dgrad', m, 2 * co, c1 - c0):
+                if p == 0:                                      # class (0,0): initialises every tap block
+                    torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
+                else:
+                    torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
             d_w = rows_tn(a_mat[:, c0:c1], g[p])
             d_lo.index_copy_(0, lo, d_w[:, :co])
             d_hi.index_copy_(0, hi, d_w[:, co:])
@@ -686,18 +691,27 @@ class _LatticeLayerZ4(torch.autograd.Function):
         return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None
 
 
-def rows_tn(a, g):
-    """a^T g for tall operands (a [M,K] may be a column range of a wider matrix, g [M,N] contiguous).
-    The library runs this K x N output with M = 1e5..2e5 as a stream-K GEMM at ~0.75 PFLOP/s; split
-    into 8 row chunks as ONE batched GEMM (strided views, no copies) and summed in fp32 it reaches
-    ~1.05 PFLOP/s (scratch/exp_wgrad.py)."""
-    m = a.shape[0]
-    if not a.is_cuda or a.dtype == torch.float64 or m % 8 or m < 8 * 2048:
-        return torch.mm(a.t(), g)
-    s = 8
-    a3 = a.unflatten(0, (s, m // s))
-    g3 = g.unflatten(0, (s, m // s))
-    return torch.bmm(a3.transpose(1, 2), g3).sum(0, dtype=torch.float32).to(a.dtype)
+def gemm_timed(name, m, k, n):
+    """HIP-event bracket around one library GEMM of the head ([m, k] x [k, n]) for bench.py's dense-part roofline entry
+    (hipops.timed: free unless a KernelTimer is set)."""
+    from ..hipops import timed
+    return timed(name, 2.0 * m * k * n)
+
+
+def rows_tn(a, g, out_dtype=None):
+    """a^T g for tall operands (a [M,K] may be a column range of a wider matrix, g [M,N]): the weight gradient of a GEMM
+    layer, rows on the contraction axis.  bf16 GPU operands run on ``ver_wgrad_tn`` (csrc/ver_wgrad.hip: both
+    operands streamed row-major into LDS, fragments through transposing LDS reads, fp32 partial sums over row chunks
+    added up in fp32: 1.3 PFLOP/s where the library's T x N class reaches 1.05); everything else
+    (fp32 / fp64, CPU tensors of the algebra tests) is a plain matmul."""
+    if a.is_cuda and a.dtype == torch.bfloat16 and g.dtype == torch.bfloat16:
+        from ..hipops import wgrad_tn, wgrad_tn_supported
+        if g.stride(-1) != 1 or g.stride(0) % 8:
+            g = g.contiguous()
+        if wgrad_tn_supported(a, g):
+            return wgrad_tn(a, g, out_dtype=out_dtype)
+    out = torch.mm(a.t(), g)
+    return out if out_dtype is None else out.to(out_dtype)
 
 
 def _compute_dtype(x):

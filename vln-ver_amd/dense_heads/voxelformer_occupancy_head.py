@@ -222,8 +222,12 @@ class VoxelFormerOccupancyHead(BaseModule):
         """The occupancy term is mmdet's sigmoid FocalLoss with mean reduction (vocc.py:190-195): the form the fused
         MLP + focal-loss Function evaluates."""
         from .losses import FocalLoss
+        from ..hipops import occ_mlp_backward_takes_grad_scale
         lo = self.loss_occupancy
-        return self.fuse_occ_mlp_loss and isinstance(lo, FocalLoss) and lo.use_sigmoid and lo.reduction == 'mean'
+        # (the fused Function hands the backward kernel a device-side scale of d(logits): only the wave-specialised
+        #  kernel takes one -- under the A/B switch VER_OCC_MLP_WS=0 the loss goes through the logits as two ops)
+        return (self.fuse_occ_mlp_loss and isinstance(lo, FocalLoss) and lo.use_sigmoid and lo.reduction == 'mean'
+                and occ_mlp_backward_takes_grad_scale())
 
     def occupancy_from_volume(self, voxel_embed, rows_only=False, loss_targets=None):
         """voxel_embed [bs, Nq, C] (per-sample contiguous Nq*C buffer = the reference's
@@ -324,6 +328,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         gt = voxels_to_rows(gt, plan, bs).reshape(-1)
         avg = (gt < self.occupancy_classes).sum() * 1.0
         lo = self.loss_occupancy
+        lo.check_label_range(gt, self.occupancy_classes)      # (the same first-call host check as FocalLoss.forward)
         with torch.autocast('cuda', enabled=False):
             w2c, b2c = self._centered(l2.weight.float(), l2.bias.float())
             s = occ_mlp_focal_loss_sum(x.to(torch.bfloat16), n1.weight, n1.bias, w2c, b2c, n2.weight, n2.bias,
@@ -767,12 +772,15 @@ class VoxelFormerOccupancyHead(BaseModule):
         arg-max -> sparse ``(voxel index, class)`` pairs of the occupied voxels."""
         logits = occ_results['occupancy_preds'].reshape(-1, self.occupancy_classes)
         if logits.is_cuda and self.occupancy_classes % 8 == 0:
-            # on the device: one classification + ordered compaction (ver_occ_predict), same pairs bit for bit
+            # on the device: one classification + ordered compaction (ver_occ_predict).  The kernel evaluates the sigmoid
+            # in fp32 whatever the logits' dtype: the reference's pairs bit for bit on fp32 logits; on bf16 logits it is
+            # the classification of `logits.float()` (a bf16 sigmoid would round the probabilities to 8 bits before
+            # the threshold compare and the arg-max, and flip rows near the threshold or with near-equal classes)
             from ..hipops import occ_predict
             occ_results['occupancy_preds'] = occ_predict(logits, occ_threshold)
             occ_results['flow_preds'] = None
             return occ_results
-        p = logits.sigmoid()
+        p = logits.float().sigmoid()                     # fp32 like the kernel and the (fp32) reference
         p = torch.cat((p, torch.ones_like(p)[:, :1] * occ_threshold), dim=-1)
         occ_class = p.argmax(dim=-1)
         occ_index, = torch.where(occ_class < self.occupancy_classes)

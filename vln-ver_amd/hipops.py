@@ -74,9 +74,11 @@ class KernelTimer:
         torch.cuda.synchronize()
         out = {}
         for name, e0, e1, meta in self.records:
-            d = out.setdefault(name, dict(count=0, ms=0.0, meta=meta))
+            d = out.setdefault(name, dict(count=0, ms=0.0, flops=0.0, meta=meta))
             d['count'] += 1
             d['ms'] += e0.elapsed_time(e1)
+            if meta and 'flops' in meta:
+                d['flops'] += meta['flops']
         return out
 
 
@@ -95,6 +97,29 @@ def _launch(name, fn, meta=None):
     e1.record()
     timer.records.append((name, e0, e1, meta))
     return _check(rc, name)
+
+
+class timed:
+    """``with timed('head_gemm_fwd', flops): torch.mm(...)`` -- the same HIP-event bracket as ``_launch`` for work that is
+    not a C-ABI call (the library GEMMs of the head), so that bench.py can put the dense part's achieved TFLOP/s next to
+    the gather's GB/s.  Free when no timer is set."""
+
+    def __init__(self, name, flops=0.0):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        self.timer = KERNEL_TIMER
+        if self.timer is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.timer.records.append((self.name, self.e0, e1, dict(flops=self.flops)))
+        return False
 
 
 def _p(t):
@@ -344,7 +369,8 @@ def sca_head_major_supported(dtype, head_dim, points, map_h, map_w):
 
 class HeadMajorLinearFunction(Function):
     """``value_proj`` writing the head-major layout: x bf16 [M, C_in], weight [heads*hd, C_in], bias [heads*hd] ->
-    [heads, M, hd] as ONE batched GEMM over the heads (x is the stride-0 batch operand, no copies).  The gradient comes
+    [heads, M, hd]: one plain GEMM per head into its slab of the output (no stride-0 batch operand: those fault inside
+    some hipBLASLt solutions when TunableOp tries them, dense_heads/row_linear.py).  The gradient comes
     back as the permuted view of a reference-layout [M, heads*hd] buffer (SCAGatherFunction.backward), so d(weight) is a
     plain split-row GEMM over [M, heads*hd]; d(x) likewise when it is needed."""
 
@@ -353,8 +379,11 @@ class HeadMajorLinearFunction(Function):
         m, c_in = x.shape
         w = weight.to(x.dtype)
         hd = w.shape[0] // heads
-        out = torch.baddbmm(bias.to(x.dtype).view(heads, 1, hd), x.unsqueeze(0).expand(heads, m, c_in),
-                            w.view(heads, hd, c_in).transpose(1, 2))
+        out = x.new_empty(heads, m, hd)
+        b = bias.to(x.dtype).view(heads, hd)
+        w3 = w.view(heads, hd, c_in)
+        for h in range(heads):
+            torch.addmm(b[h], x, w3[h].t(), out=out[h])
         ctx.save_for_backward(x, w)
         ctx.heads = heads
         return out
@@ -634,12 +663,13 @@ class LabelRangeFlag:
         self.event.record()
 
     def poll(self, sync=False):
-        if self.event is None:
-            return
+        if torch.cuda.is_current_stream_capturing():
+            return                                          # (no event queries / host reads inside a capture)
         if sync:
-            self.event.synchronize()
-            self.host.copy_(self.dev)                       # (the mirror may predate the offending call)
-        elif not self.event.query():
+            # always the blocking read: fused calls under stream capture never queued a mirror copy (mirror() is a
+            # no-op there), and a queued mirror may predate the offending call
+            self.host.copy_(self.dev)
+        elif self.event is None or not self.event.query():
             return
         if int(self.host[0]) != 0:
             raise RuntimeError('FocalLoss: a target label outside [0, %s] reached the fused focal loss on %s (the loss of '
@@ -751,6 +781,12 @@ def _rows_tn(a, b, chunk=8000, with_colsum=True):
         if with_colsum:
             colsum += a[main:].sum(0, dtype=torch.float32)
     return prod, colsum
+
+
+def occ_mlp_backward_takes_grad_scale():
+    """True when ``ver_occ_mlp_backward_fused`` runs the wave-specialised kernel, the one that takes ``grad_scale``
+    (VER_OCC_MLP_WS, read once by the library too: 0 selects the phase-locked N-split kernel, which rejects it)."""
+    return os.environ.get('VER_OCC_MLP_WS', '1') not in ('0',)
 
 
 _FRAG_ORDER = {}
@@ -1051,7 +1087,7 @@ def wgrad_tn_supported(a, g):
     return (a.is_cuda and g.is_cuda and a.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and a.dim() == 2
             and g.dim() == 2 and a.shape[0] == g.shape[0] and a.stride(1) == 1 and g.stride(1) == 1
             and a.stride(0) % 8 == 0 and g.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0
-            and g.shape[1] % 4 == 0 and a.shape[0] % 128 == 0)
+            and g.shape[1] % 4 == 0)
 
 
 def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0):

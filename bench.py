@@ -69,6 +69,10 @@ def parse():
     ap.add_argument('--graph-max-batch', type=int, default=4,
                     help='config.latency records of the full multi-task workload up to this many viewpoints per step replay '
                          'the head as hipGraphs (one rank only; 0: always eager)')
+    ap.add_argument('--graph-full-train', type=int, default=1,
+                    help='config.full_train sub-record (64 viewpoints per step, one rank): 1 = the head\'s forward and backward '
+                         'are replayed as two hipGraphs (vln-ver_amd/graphs.py; the eager step is bound by the host\'s launch '
+                         'rate: ~4 000 launches, 127 ms of GPU work in a 150-ms step), 0 = eager')
     ap.add_argument('--host-fed-steps', type=int, default=3,
                     help='steps of the config.host_fed record: the same step with the features handed over in (pinned) HOST '
                          'memory, as the detector does, the PCIe copy inside the timed region; 0: none')
@@ -311,9 +315,16 @@ def sub_record(base, name, dev, rank, world, distributed):
         net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=base.backend == 'nccl')
     params = [prm for prm in model.parameters() if prm.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    graphed = None
+    if full and not distributed and base.graph_full_train:
+        # same kernels, same arithmetic, replayed: Hungarian targets, loss terms, clip and AdamW stay eager (graphs.py)
+        graphed = importlib.import_module('vln-ver_amd.graphs').GraphedHead(head, feats, w2p, org, autocast_dtype=torch.bfloat16)
 
     def step():
-        loss = net(feats, w2p, org, gt, *extra)
+        if graphed is not None:
+            loss = sum(head.loss(extra[0], extra[1], gt, graphed(feats, w2p, org)).values())
+        else:
+            loss = net(feats, w2p, org, gt, *extra)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 300.0)
         opt.step()
@@ -336,10 +347,11 @@ def sub_record(base, name, dev, rank, world, distributed):
     assert torch.isfinite(last).all(), 'non-finite loss in sub-record %s' % name
     ms = float(dt) / base.sub_steps * 1e3
     rec = dict(workload=a.workload, dtype=a.dtype, viewpoints_per_gpu_per_step=B, head_micro_batch=(None if full else a.micro),
-               steps=base.sub_steps, warmup=1, ms_per_step=round(ms, 3), viewpoints_per_s=round(B * world / ms * 1e3, 2),
+               steps=base.sub_steps, warmup=1, graphed=graphed is not None, ms_per_step=round(ms, 3),
+               viewpoints_per_s=round(B * world / ms * 1e3, 2),
                trainable_params=sum(prm.numel() for prm in params),
                peak_hbm_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
-    del opt, net, model, head, last
+    del opt, net, model, head, last, graphed, step
     torch.cuda.empty_cache()
     return rec
 

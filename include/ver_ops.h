@@ -380,6 +380,12 @@ int ver_occ_mlp_vector_floats(void);
 int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W3, void* image, void* stream);
 int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits,
                         long N, int width, int classes, float eps, int first_linear, void* stream);
+/*   the same, also writing the reciprocal standard deviation of both LayerNorms per row (ABI 24):
+ *     rstd f32 [N, 2]  (may be NULL: plain forward).  ver_occ_mlp_backward_fused_stats reads it back, so that its two
+ *     recomputed LayerNorm-forward steps need no statistics (elementwise; VER_OCC_MLP_CENTERED rows only).
+ */
+int ver_occ_mlp_forward_stats(const void* x, const void* image, const float* vectors, void* logits, float* rstd,
+                              long N, int width, int classes, float eps, int first_linear, void* stream);
 /*   backward: re-computes the forward from x, then
  *     grad_x  bf16 [N,128]                      d loss / d x
  *     grad_a1, grad_a2 bf16 [N,128]             gradients w.r.t. the outputs of Linear 1 / Linear 2
@@ -409,6 +415,11 @@ int ver_occ_mlp_backward(const void* x, const void* grad_logits, const void* ima
 int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                const float* vectors, void* grad_x, float* param_grads, long N, int width,
                                int classes, float eps, const float* grad_scale, int flags, void* stream);
+/*   the same with the statistics ver_occ_mlp_forward_stats saved (rstd f32 [N, 2], may be NULL; used with
+ *   VER_OCC_MLP_CENTERED only, ignored otherwise) */
+int ver_occ_mlp_backward_fused_stats(const void* x, const void* grad_logits, const float* W2, const float* W3,
+                                     const float* vectors, const float* rstd, void* grad_x, float* param_grads, long N,
+                                     int width, int classes, float eps, const float* grad_scale, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Occupancy post-processing: VoxelFormerOccupancyHead.get_occupancy_prediction, focal-loss branch
@@ -437,7 +448,7 @@ int  ver_occ_predict(const void* logits, int dtype, long N, int C, float thresho
  *   workspace  f32 [splits, Ka, N]: the row axis is split into `splits` chunks (0: ver_wgrad_tn_splits), every
  *              chunk's product stays fp32 until the chunks are added up (no bf16 rounding of partial sums)
  * Requirements: a, g 16-byte aligned, lda % 8 == 0, ldg % 8 == 0, N % 4 == 0, ldo % 4 == 0; any M (M = 0: zeros).
- * flags: bits 0-2 = prefetch distance in 16-row slabs (3..6; 0 = default).
+ * flags (experiments; 0 = default): bits 0-2 = prefetch distance in 16-row slabs, bit 3 = two slabs per phase.
  */
 int  ver_wgrad_tn_splits(long M, int Ka, int N);
 long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits);

@@ -943,6 +943,51 @@ def test_occ_mlp_centered_equals_plain_and_the_fp64_chain():
     assert float(res[True][1]['w2'].sum(0).abs().max()) < 1e-3 * float(res[True][1]['w2'].abs().max()) * 128
 
 
+@pytest.mark.parametrize('n', [1, 65, 64 * 3 + 5, 64 * 256 + 1, 64 * 1027 + 33])
+def test_occ_mlp_backward_with_saved_statistics_equals_the_recomputing_kernel(n, monkeypatch):
+    """ver_occ_mlp_forward_stats / ver_occ_mlp_backward_fused_stats (round 5): on centred rows the forward kernel saves
+    1/std of both LayerNorms per row and the wave-specialised backward reads them back instead of recomputing the
+    statistics (its two LayerNorm-forward steps become elementwise).  The saved values are what the recomputation yields
+    (to fp32 rounding for LayerNorm 1; for LayerNorm 2 up to the bf16 rounding of a2 between the kernel's two views: a
+    relative 1e-4 of 1/std), so d(x) and every parameter gradient must agree with the recomputing form far inside the
+    distance either has from the fp64 chain; the statistics themselves are checked against torch."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(300 + n % 89)
+    p = _occ_mlp_params(gen)
+    keys = ('g1', 'be1', 'w2', 'b2', 'g2', 'be2', 'w3', 'b3')
+    x0 = torch.randn(n, 128, generator=gen) * 1.5
+    gy = (torch.randn(n, 16, generator=gen) * 0.1).bfloat16()
+    from util import rel_l2
+
+    def center(w, b):
+        return w - w.mean(0, keepdim=True), b - b.mean()
+    res = {}
+    for saved in (True, False):
+        monkeypatch.setattr(hip, '_OCC_MLP_SAVE_RSTD', saved)
+        pd = {k: p[k].to(DEV).requires_grad_(True) for k in ('w1', 'b1') + keys}
+        w1, b1 = center(pd['w1'], pd['b1'])
+        w2, b2 = center(pd['w2'], pd['b2'])
+        a1 = (x0.to(DEV) @ w1.t() + b1).bfloat16().detach().requires_grad_(True)
+        out = hip.occ_mlp(a1, None, None, pd['g1'], pd['be1'], w2, b2, pd['g2'], pd['be2'], pd['w3'], pd['b3'], centered=True)
+        out.backward(gy.to(DEV))
+        res[saved] = (out.detach().float().cpu(), a1.grad.float().cpu(), {k: pd[k].grad.float().cpu() for k in keys})
+    assert torch.equal(res[True][0], res[False][0])                  # the forward arithmetic is untouched
+    assert rel_l2(res[True][1], res[False][1]) < 5e-3, rel_l2(res[True][1], res[False][1])
+    for k in keys:
+        assert rel_l2(res[True][2][k], res[False][2][k]) < 5e-3, (k, rel_l2(res[True][2][k], res[False][2][k]))
+    # the statistics the forward kernel wrote: LayerNorm 1 on the loaded rows (no mean pass on centred rows)
+    pd = {k: p[k].to(DEV) for k in ('w1', 'b1') + keys}
+    w1, b1 = center(pd['w1'], pd['b1'])
+    w2, b2 = center(pd['w2'], pd['b2'])
+    a1 = (x0.to(DEV) @ w1.t() + b1).bfloat16()
+    image = hip.occ_mlp_pack(w2, w2, pd['w3'])
+    vec = hip.occ_mlp_vectors(torch.zeros(128, device=DEV), pd['g1'], pd['be1'], b2, pd['g2'], pd['be2'], pd['b3'])
+    _, rstd = hip.occ_mlp_forward(a1, image, vec, 1e-5, first_linear=False, centered=True, want_rstd=True)
+    want1 = torch.rsqrt(a1.float().pow(2).mean(1) + 1e-5)
+    assert rstd.shape == (n, 2) and float(((rstd[:, 0] - want1) / want1).abs().max()) < 1e-5
+    assert bool(torch.isfinite(rstd).all()) and float(rstd[:, 1].min()) > 0
+
+
 @pytest.mark.parametrize('n', [1, 63, 64, 65, 128, 191, 64 * 256 + 1, 64 * 513 + 7])
 def test_occ_mlp_backward_kernels_on_ragged_sizes(n, monkeypatch):
     """Both backward kernels of the folded MLP on row counts around the block / pipeline edges of the wave-specialised

@@ -172,9 +172,12 @@ namespace {
 // KEEP: also return the normalised values (bf16) and form the output from those rounded values (backward pass).
 // QUAD: the four lanes that share a row are a quad (lane = 4 row + chunk) instead of the same column of the four 16-lane rows
 // (lane = row + 16 chunk): the row statistics are then two DPP quad permutes instead of two ds_bpermute round trips.
-template <bool KEEP, bool QUAD = false, bool CENTERED = false>
+// GIVEN_RS (CENTERED only): `rstd_out` holds the row's 1/std on entry (saved by the forward kernel, ver_occ_mlp_forward_stats):
+// no sum of squares, no cross-lane reduction -- the step is elementwise.
+template <bool KEEP, bool QUAD = false, bool CENTERED = false, bool GIVEN_RS = false>
 __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, const float* bet, float eps,
                                             bf16x8 (&xh)[4], float& rstd_out) {
+    static_assert(!GIVEN_RS || CENTERED, "a saved 1/std replaces the statistics only when there is no mean pass");
     f32x4 v[4][2];
     float s = 0.0f;
 #pragma unroll
@@ -200,16 +203,22 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if constexpr (!CENTERED) v[t][h] -= mu;
-            q += (v[t][h].x * v[t][h].x + v[t][h].y * v[t][h].y) + (v[t][h].z * v[t][h].z + v[t][h].w * v[t][h].w);
+            if constexpr (!GIVEN_RS)
+                q += (v[t][h].x * v[t][h].x + v[t][h].y * v[t][h].y) + (v[t][h].z * v[t][h].z + v[t][h].w * v[t][h].w);
         }
-    if constexpr (QUAD) {
-        q = group_sum<4>(q);
+    float rs;
+    if constexpr (GIVEN_RS) {
+        rs = rstd_out;
     } else {
-        q += xor16(q);
-        q += xor32(q);
+        if constexpr (QUAD) {
+            q = group_sum<4>(q);
+        } else {
+            q += xor16(q);
+            q += xor32(q);
+        }
+        rs = rsqrtf(q * (1.0f / kW) + eps);
+        rstd_out = rs;
     }
-    const float rs = rsqrtf(q * (1.0f / kW) + eps);
-    rstd_out = rs;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (KEEP) {
@@ -243,10 +252,11 @@ __device__ __forceinline__ void ln_relu_nat(bf16x8 (&x)[4], const float* gam, co
 // LayerNorm in the natural fragment layout; the image was packed with W2 in W1's place, so section kF1 holds W2 with the
 // natural k order that layout needs (and kB1, in the backward kernel, W2's dgrad with natural-order output rows).
 // CENTERED (flags bit 1): every LayerNorm input has zero row mean by construction (see ln_relu_tile).
-template <int RT, bool L1, bool CENTERED = false>
+// STATS: also write 1/std of both LayerNorms per row (rstd f32 [N, 2]; 32-bit buffer addressing: N < 2^28 rows).
+template <int RT, bool L1, bool CENTERED = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict__ x, const __bf16* __restrict__ img,
                                                         const float* __restrict__ vec, __bf16* __restrict__ logits,
-                                                        long N, float eps) {
+                                                        long N, float eps, float* __restrict__ rstd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                       // [kFwdFrags][64]
     float* sv = reinterpret_cast<float*>(smem + kFwdFrags * 1024);        // vectors
@@ -256,6 +266,8 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const long nblk = (N + 16 * RT - 1) / (16 * RT);
+    // (stores beyond row N - 1, and those of the lanes g != 0 -- sent there on purpose -- fall outside the range and are dropped)
+    const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rstd, 0, STATS ? (int)(N * 8) : 0, 0x00020000);
     for (long blk = (long)blockIdx.x * 4 + wave; blk < nblk; blk += (long)gridDim.x * 4) {
         const long r0 = blk * (16 * RT);
         // the weight fragments are loop invariant: hide that from LICM, which would otherwise hoist
@@ -281,6 +293,10 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
                 float rs;
                 bf16x8 unused[4];
                 ln_relu_nat<false, false, CENTERED>(bf[rt], sv_n + kW, sv_n + 2 * kW, eps, unused, rs);
+                // (1/std of both LayerNorms per row for the backward kernel, which then recomputes them elementwise)
+                if constexpr (STATS)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rs), rs_rsrc,
+                                                          g == 0 ? (int)(r0 + rt * 16 + c) * 8 : -8, 0, 0);
             }
         }
 #pragma unroll
@@ -303,6 +319,9 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
             for (int rt = 0; rt < RT; ++rt) {
                 float rs;
                 ln_relu_tile<false, CENTERED>(acc[rt], bias + kW, bias + 2 * kW, eps, bf[rt], rs);
+                if constexpr (STATS)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rs), rs_rsrc,
+                                                          g == 0 ? (int)(r0 + rt * 16 + c) * 8 + 4 * layer : -8, 0, 0);
             }
         }
         // layer 3: classes 4g..4g+3 of row c
@@ -665,6 +684,11 @@ extern "C" int ver_occ_mlp_pack(const float* W1, const float* W2, const float* W
 
 extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float* vectors, void* logits, long N,
                                    int width, int classes, float eps, int first_linear, void* stream) {
+    return ver_occ_mlp_forward_stats(x, image, vectors, logits, nullptr, N, width, classes, eps, first_linear, stream);
+}
+
+extern "C" int ver_occ_mlp_forward_stats(const void* x, const void* image, const float* vectors, void* logits, float* rstd,
+                                         long N, int width, int classes, float eps, int first_linear, void* stream) {
     int rc = check_common("ver_occ_mlp_forward", x, image, vectors, N, width, classes);
     if (rc) return rc;
     if (N == 0) return VER_OK;
@@ -676,15 +700,19 @@ extern "C" int ver_occ_mlp_forward(const void* x, const void* image, const float
     // = every LayerNorm input has zero row mean by construction, the mean pass is skipped
     VER_REQUIRE((first_linear & ~3) == 0, VER_EINVAL, "ver_occ_mlp_forward: unknown flags 0x%x", first_linear);
     const bool l1 = first_linear & 1, centered = first_linear & 2;
-    auto kern = l1 ? (centered ? k_occ_mlp_fwd<RT, true, true> : k_occ_mlp_fwd<RT, true, false>)
-                   : (centered ? k_occ_mlp_fwd<RT, false, true> : k_occ_mlp_fwd<RT, false, false>);
+    VER_REQUIRE(!rstd || (N < (1L << 28) && ((uintptr_t)rstd & 7) == 0), VER_EUNSUPPORTED,
+                "ver_occ_mlp_forward_stats: rstd needs N < 2^28 rows and 8-byte alignment");
+    auto kern = l1 ? (centered ? (rstd ? k_occ_mlp_fwd<RT, true, true, true> : k_occ_mlp_fwd<RT, true, true, false>)
+                               : (rstd ? k_occ_mlp_fwd<RT, true, false, true> : k_occ_mlp_fwd<RT, true, false, false>))
+                   : (centered ? (rstd ? k_occ_mlp_fwd<RT, false, true, true> : k_occ_mlp_fwd<RT, false, true, false>)
+                               : (rstd ? k_occ_mlp_fwd<RT, false, false, true> : k_occ_mlp_fwd<RT, false, false, false>));
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_forward: LDS attribute: %s", hipGetErrorString(e));
     const long nblk = (N + 16 * RT - 1) / (16 * RT);
     long grid = (nblk + 3) / 4;
     if (grid > 512) grid = 512;                            // 2 workgroups per CU, persistent
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, (const __bf16*)x,
-                       (const __bf16*)image, vectors, (__bf16*)logits, N, eps);
+                       (const __bf16*)image, vectors, (__bf16*)logits, N, eps, rstd);
     return ver_check_launch("ver_occ_mlp_forward");
 }
 
@@ -1077,12 +1105,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // CENTERED: the forward ran with VER_OCC_MLP_CENTERED (zero-mean LayerNorm inputs by construction): the two recomputed
 // LayerNorm-forward steps of the row team skip the mean pass as the forward kernel does.
-template <bool CENTERED>
+// RSTD (with CENTERED): the forward kernel saved 1/std of both LayerNorms per row (`rstd` f32 [N, 2]): the two recomputed
+// LayerNorm-forward steps are elementwise -- no sum of squares, no cross-lane reduction in the middle of the slot's chain.
+template <bool CENTERED, bool RSTD = false>
 __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ vec, __bf16* __restrict__ dx,
                                                         float* __restrict__ pgrad, long N, float eps,
-                                                        const float* __restrict__ grad_scale) {
+                                                        const float* __restrict__ grad_scale,
+                                                        const float* __restrict__ rstd) {
     constexpr int OT = 2, RT = 4, KS = 2;
     const float gscale = grad_scale ? grad_scale[0] : 1.0f;        // scalar factor of d(logits) (device-side, may be null)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1127,6 +1158,16 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int t = 0; t < 4; ++t) st.xn[t] = *reinterpret_cast<const bf16x8*>(x + rc * kW + 32 * t + 8 * g);
             st.dln = *reinterpret_cast<const bf16x8*>(dlog + rc * kC + 8 * (g & 1));
         };
+        // RSTD: the saved 1/std pair of a block goes straight into rs1 / rs2, requested when the previous block of this
+        // state has used them for the last time (end of its step 6, two slots before the new block's step 0)
+        auto prefetch_rs = [&](RowState& st, long blk) {
+            if constexpr (RSTD) {
+                const long rn = blk * kWsRows + myrow;
+                const float2 v = *reinterpret_cast<const float2*>(rstd + 2 * (rn < N ? rn : N - 1));
+                st.rs1 = v.x;
+                st.rs2 = v.y;
+            }
+        };
         auto r0 = [&](RowState& st, __bf16* T, __bf16* DL, long blk) {          // x -> LN1 + ReLU -> h1 (T0); stage d(logits)
             st.r = blk * kWsRows + myrow;
             st.ok = st.r < N;
@@ -1143,7 +1184,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 *reinterpret_cast<bf16x8*>(DL + myrow * kNsDlLd + 8 * g) = dl;
             }
             prefetch(st, blk + 2 * (long)gridDim.x, blk + 2 * (long)gridDim.x < nblk);
-            ln_relu_nat<true, true, CENTERED>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
+            ln_relu_nat<true, true, CENTERED, RSTD>(xr, sv_n + kW, sv_n + 2 * kW, eps, st.xh1, st.rs1);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1151,7 +1192,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             bf16x8 xr[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x8*>(T + kWsTile + myrow * kNsLd + 32 * t + 8 * g);
-            ln_relu_nat<true, true, CENTERED>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
+            ln_relu_nat<true, true, CENTERED, RSTD>(xr, sv_n + 4 * kW, sv_n + 5 * kW, eps, st.xh2, st.rs2);
 #pragma unroll
             for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(T + 2 * kWsTile + myrow * kNsLd + 32 * t + 8 * g) = xr[t];
         };
@@ -1166,7 +1207,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             ns_ln_relu_bwd<true, true>(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 2 * kWsTile + myrow * kNsLd + 8 * g, T + kWsTile + myrow * kNsLd + 8 * g, true);
         };
-        auto r6 = [&](RowState& st, __bf16* T) {                                  // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
+        auto r6 = [&](RowState& st, __bf16* T, long blk_next) {                   // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
             f32x4 d[8];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1176,11 +1217,14 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             }
             ns_ln_relu_bwd<true, true>(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 3 * kWsTile + myrow * kNsLd + 8 * g, st.ok);
+            prefetch_rs(st, blk_next < nblk ? blk_next : nblk - 1);
         };
         __bf16* const TA = tiles;
         __bf16* const TB = tiles + 4 * kWsTile;
         prefetch(sa, blockIdx.x, blockIdx.x < nblk);
         prefetch(sb, blockIdx.x + (long)gridDim.x, blockIdx.x + (long)gridDim.x < nblk);
+        prefetch_rs(sa, blockIdx.x < nblk ? (long)blockIdx.x : nblk - 1);
+        prefetch_rs(sb, blockIdx.x + (long)gridDim.x < nblk ? blockIdx.x + (long)gridDim.x : nblk - 1);
         for (long k = 0; k < rounds; ++k) {
             const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
             const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
@@ -1190,7 +1234,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #else
             if (va) r0(sa, TA, DLs, blk_a);
             lds_barrier();
-            if (vp) r6(sb, TB);
+            if (vp) r6(sb, TB, blk_b);
             lds_barrier();
             if (va) r2(sa, TA);
             lds_barrier();
@@ -1200,7 +1244,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             lds_barrier();
             if (vb) r2(sb, TB);
             lds_barrier();
-            if (va) r6(sa, TA);
+            if (va) r6(sa, TA, blk_a + 2 * (long)gridDim.x);
             lds_barrier();
             if (vb) r4(sb, TB);
             lds_barrier();
@@ -1388,6 +1432,14 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits, const float* W2, const float* W3,
                                           const float* vectors, void* grad_x, float* param_grads, long N, int width,
                                           int classes, float eps, const float* grad_scale, int flags, void* stream) {
+    return ver_occ_mlp_backward_fused_stats(x, grad_logits, W2, W3, vectors, nullptr, grad_x, param_grads, N, width, classes,
+                                            eps, grad_scale, flags, stream);
+}
+
+extern "C" int ver_occ_mlp_backward_fused_stats(const void* x, const void* grad_logits, const float* W2, const float* W3,
+                                                const float* vectors, const float* rstd, void* grad_x, float* param_grads,
+                                                long N, int width, int classes, float eps, const float* grad_scale, int flags,
+                                                void* stream) {
     VER_REQUIRE(N >= 0, VER_EINVAL, "ver_occ_mlp_backward_fused: negative row count");
     VER_REQUIRE((flags & ~VER_OCC_MLP_CENTERED) == 0, VER_EINVAL, "ver_occ_mlp_backward_fused: unknown flags 0x%x", flags);
     VER_REQUIRE(width == kW && classes == kC, VER_EUNSUPPORTED,
@@ -1406,13 +1458,17 @@ extern "C" int ver_occ_mlp_backward_fused(const void* x, const void* grad_logits
         return ev ? atoi(ev) : 1;
     }();
     if (ws) {
-        auto kern = (flags & VER_OCC_MLP_CENTERED) ? k_occ_mlp_bwd_ws<true> : k_occ_mlp_bwd_ws<false>;
+        // (the saved statistics replace the recomputation only on centred rows; otherwise they are ignored)
+        const bool use_rstd = rstd && (flags & VER_OCC_MLP_CENTERED);
+        auto kern = (flags & VER_OCC_MLP_CENTERED) ? (use_rstd ? k_occ_mlp_bwd_ws<true, true> : k_occ_mlp_bwd_ws<true, false>)
+                                                   : k_occ_mlp_bwd_ws<false, false>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: LDS attribute: %s", hipGetErrorString(e));
         const long nb = (N + kWsRows - 1) / kWsRows;
         const long gridw = nb < 256 ? nb : 256;               // one workgroup per CU (LDS bound), persistent
         hipLaunchKernelGGL(kern, dim3((unsigned)gridw), dim3(512), kWsLds, st, (const __bf16*)x,
-                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps, grad_scale);
+                           (const __bf16*)grad_logits, W2, W3, vectors, (__bf16*)grad_x, param_grads, N, eps, grad_scale,
+                           use_rstd ? rstd : nullptr);
         return ver_check_launch("ver_occ_mlp_backward_fused");
     }
     VER_REQUIRE(!grad_scale, VER_EUNSUPPORTED, "ver_occ_mlp_backward_fused: grad_scale needs the wave-specialised kernel");

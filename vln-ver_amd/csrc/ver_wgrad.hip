@@ -58,66 +58,102 @@ struct WgradArgs {
     int S, Ka, N, tiles_n, T;
 };
 
-// One phase: fragments of slab `p` (ring slot SLOT) -> registers, LDS-DMA of slab p + PF, 8 MFMAs.
-template <int SLOT, int PF>
-__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], int offA0, int offA1, int offB0, int offB1,
-                                      __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, int voA, int voG,
-                                      int& soA, int& soG, int stepA, int stepG, int dmaoff) {
+struct WgradLane {          // per-lane constants of the main loop
+    int offA0, offA1, offB0, offB1;     // LDS byte addresses of the fragment reads in ring slot 0
+    int voA, voG;                       // per-lane source offsets of the two LDS-DMA pieces this wave moves
+    int stepA, stepG;                   // bytes per slab of the sources
+    int dmaoff;                         // offset of this wave's piece inside the A / G part of a slab
+};
+
+// Fragments of ring slot SLOT -> registers (12 transposing reads: A tiles 0..3, G tiles 0..1, lo and hi k halves).
+template <int SLOT>
+__device__ __forceinline__ void read_slab(const WgradLane& c, i32x2 (&al)[4], i32x2 (&ah)[4], i32x2 (&bl)[2], i32x2 (&bh)[2]) {
     // (the offset field of a DS instruction has 16 bits: slots 4-7 go through base registers 64 KiB up)
     constexpr int SB = (SLOT & 3) * kSlabBytes;
-    if constexpr (SLOT >= 4) {
-        offA0 += 65536;
-        offA1 += 65536;
-        offB0 += 65536;
-        offB1 += 65536;
+    constexpr int UP = SLOT >= 4 ? 65536 : 0;
+    const int a0 = c.offA0 + UP, a1 = c.offA1 + UP, b0 = c.offB0 + UP, b1 = c.offB1 + UP;
+    al[0] = tr_read<SB>(a0);
+    ah[0] = tr_read<SB + 512>(a0);
+    bl[0] = tr_read<SB>(b0);
+    bh[0] = tr_read<SB + 512>(b0);
+    al[1] = tr_read<SB>(a1);
+    ah[1] = tr_read<SB + 512>(a1);
+    bl[1] = tr_read<SB>(b1);
+    bh[1] = tr_read<SB + 512>(b1);
+    al[2] = tr_read<SB + 1024>(a0);
+    ah[2] = tr_read<SB + 1536>(a0);
+    al[3] = tr_read<SB + 1024>(a1);
+    ah[3] = tr_read<SB + 1536>(a1);
+}
+
+// One phase = KP slabs (ring slots PS*KP ..): fragments -> registers, LDS-DMA of the slabs PF ahead, 8 KP MFMAs.
+template <int PS, int KP, int PF>
+__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const WgradLane& c, __amdgpu_buffer_rsrc_t ra,
+                                      __amdgpu_buffer_rsrc_t rg, int& soA, int& soG) {
+    i32x2 al[KP][4], ah[KP][4], bl[KP][2], bh[KP][2];
+    read_slab<PS * KP>(c, al[0], ah[0], bl[0], bh[0]);
+    if constexpr (KP == 2) read_slab<PS * KP + 1>(c, al[KP - 1], ah[KP - 1], bl[KP - 1], bh[KP - 1]);
+#pragma unroll
+    for (int u = 0; u < KP; ++u) {
+        const int ds = (PS * KP + u + PF) % kRing;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + ds * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, soG, 0, 0);
+        soA += c.stepA;
+        soG += c.stepG;
     }
-    i32x2 al[4], ah[4], bl[2], bh[2];
-    al[0] = tr_read<SB>(offA0);
-    ah[0] = tr_read<SB + 512>(offA0);
-    bl[0] = tr_read<SB>(offB0);
-    bh[0] = tr_read<SB + 512>(offB0);
-    al[1] = tr_read<SB>(offA1);
-    ah[1] = tr_read<SB + 512>(offA1);
-    bl[1] = tr_read<SB>(offB1);
-    bh[1] = tr_read<SB + 512>(offB1);
-    al[2] = tr_read<SB + 1024>(offA0);
-    ah[2] = tr_read<SB + 1536>(offA0);
-    al[3] = tr_read<SB + 1024>(offA1);
-    ah[3] = tr_read<SB + 1536>(offA1);
-    constexpr int DS = (SLOT + PF) % kRing;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS * kSlabBytes + dmaoff), 16, voA, soA, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + DS * kSlabBytes + kSlabBytes / 2 + dmaoff), 16, voG, soG, 0, 0);
-    soA += stepA;
-    soG += stepG;
-    // this wave's pieces of the NEXT slab have landed (everything younger stays in flight)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 1)) : "memory");
+    // this wave's pieces of the NEXT phase's slabs have landed (everything younger stays in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - KP)) : "memory");
     __builtin_amdgcn_s_barrier();
     // the fragment halves pass through the wait as operands: whatever the compiler does to them (copies into the
     // MFMA's register tuples) is ordered behind it
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]),
-                   "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                 : "+v"(al[0][0]), "+v"(ah[0][0]), "+v"(al[0][1]), "+v"(ah[0][1]), "+v"(al[0][2]), "+v"(ah[0][2]), "+v"(al[0][3]),
+                   "+v"(ah[0][3]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[0][1]), "+v"(bh[0][1])
                  :
                  : "memory");
-    bf16x8 a[4], b[2];
+    if constexpr (KP == 2)
+        asm volatile(""
+                     : "+v"(al[KP - 1][0]), "+v"(ah[KP - 1][0]), "+v"(al[KP - 1][1]), "+v"(ah[KP - 1][1]), "+v"(al[KP - 1][2]),
+                       "+v"(ah[KP - 1][2]), "+v"(al[KP - 1][3]), "+v"(ah[KP - 1][3]), "+v"(bl[KP - 1][0]), "+v"(bh[KP - 1][0]),
+                       "+v"(bl[KP - 1][1]), "+v"(bh[KP - 1][1])
+                     :
+                     : "memory");
+    bf16x8 a[KP][4], b[KP][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = frag(al[i], ah[i]);
-    b[0] = frag(bl[0], bh[0]);
-    b[1] = frag(bl[1], bh[1]);
+    for (int u = 0; u < KP; ++u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[u][i] = frag(al[u][i], ah[u][i]);
+        b[u][0] = frag(bl[u][0], bh[u][0]);
+        b[u][1] = frag(bl[u][1], bh[u][1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int u = 0; u < KP; ++u)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-            acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it], b[jt], acc[it][jt], 0, 0, 0);
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][it], b[u][jt], acc[it][jt], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
 }
 
-template <int PF>
+template <int PS, int KP, int PF>
+__device__ __forceinline__ void phases_from(int left, char* lds, f32x16 (&acc)[4][2], const WgradLane& c,
+                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, int& soA, int& soG) {
+    if constexpr (PS < kRing / KP) {
+        if (left > PS * KP) {
+            phase<PS, KP, PF>(lds, acc, c, ra, rg, soA, soG);
+            phases_from<PS + 1, KP, PF>(left, lds, acc, c, ra, rg, soA, soG);
+        }
+    }
+}
+
+template <int KP, int PF>
 __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
+    static_assert(PF >= KP && PF + (KP == 1 ? 2 : 4) <= kRing, "prefetch distance against the ring (WAR on the slot)");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +173,8 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const long row0 = (long)chunk * p.Mc;
     const long rows = max(0L, min(p.Mc, p.M - row0));
-    const int nslab = (int)((rows + kSlabRows - 1) / kSlabRows);        // rows past M read as zeros (buffer range)
+    // whole phases; rows past M read as zeros (buffer range), and Mc is a multiple of 16 KP
+    const int nslab = (int)((rows + kSlabRows * KP - 1) / (kSlabRows * KP)) * KP;
 
     // LDS-DMA: wave w moves piece (row group w >> 2, 64-column block w & 3) of the A part and of the G part
     const __bf16* ab = p.A + row0 * p.lda + (long)mt * kTile;
@@ -148,21 +185,27 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     const long gbytes = ((p.M - row0 - 1) * p.ldg + p.N - (long)nt * kTile) * 2;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, (int)max(0L, min(gbytes, 0xFFFFFFFFL)), 0x00020000);
+    WgradLane c;
     const int prow = lane >> 3, pch = (lane & 7) ^ (((prow >> 1) & 1) << 2);
-    const int voA = (int)(((8 * (wave >> 2) + prow) * p.lda + 64 * (wave & 3)) * 2) + pch * 16;
-    const int voG = (int)(((8 * (wave >> 2) + prow) * p.ldg + 64 * (wave & 3)) * 2) + pch * 16;
-    const int stepA = (int)(kSlabRows * p.lda * 2), stepG = (int)(kSlabRows * p.ldg * 2);
-    const int dmaoff = wave * 1024;
+    c.voA = (int)(((8 * (wave >> 2) + prow) * p.lda + 64 * (wave & 3)) * 2) + pch * 16;
+    c.voG = (int)(((8 * (wave >> 2) + prow) * p.ldg + 64 * (wave & 3)) * 2) + pch * 16;
+    c.stepA = (int)(kSlabRows * p.lda * 2);
+    c.stepG = (int)(kSlabRows * p.ldg * 2);
+    c.dmaoff = wave * 1024;
     int soA = 0, soG = 0;
 
     // transposing fragment reads: 16-lane group q = (k half, column half), lane c of it addresses row c >> 2,
     // columns 4 (c & 3) .. + 3 and receives column c of the group's 4 x 16 block
-    const int q = lane >> 4, c = lane & 15;
-    const int lowch = (2 * (q & 1) + ((c & 3) >> 1)) ^ (((c >> 3) & 1) << 2);
-    const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-    const int rowoff = lbase + ((q >> 1) * 32 + (c >> 2)) * 128 + lowch * 16 + (c & 1) * 8;
-    const int offA0 = rowoff + 2 * wr * 1024, offA1 = offA0 ^ 64;
-    const int offB0 = rowoff + wc * 1024 + kSlabBytes / 2, offB1 = offB0 ^ 64;
+    {
+        const int q = lane >> 4, cl = lane & 15;
+        const int lowch = (2 * (q & 1) + ((cl & 3) >> 1)) ^ (((cl >> 3) & 1) << 2);
+        const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+        const int rowoff = lbase + ((q >> 1) * 32 + (cl >> 2)) * 128 + lowch * 16 + (cl & 1) * 8;
+        c.offA0 = rowoff + 2 * wr * 1024;
+        c.offA1 = c.offA0 ^ 64;
+        c.offB0 = rowoff + wc * 1024 + kSlabBytes / 2;
+        c.offB1 = c.offB0 ^ 64;
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -172,37 +215,21 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.0f;
 
-    // prologue: slabs 0 .. PF-1 in flight, slab 0 landed
+    // prologue: slabs 0 .. PF-1 in flight, the first phase's slabs landed
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + dmaoff), 16, voA, soA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + dmaoff), 16, voG, soG, 0, 0);
-        soA += stepA;
-        soG += stepG;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, soG, 0, 0);
+        soA += c.stepA;
+        soG += c.stepG;
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - 1)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - KP)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave group runs half a phase behind
 
     int s = 0;
-    for (; s + kRing <= nslab; s += kRing) {
-        phase<0, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<1, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<2, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<3, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<4, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<5, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<6, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-        phase<7, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    }
-    const int rem = nslab - s;                          // < 8 slabs left: same phases, wave-uniform exits
-    if (rem > 0) phase<0, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 1) phase<1, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 2) phase<2, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 3) phase<3, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 4) phase<4, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 5) phase<5, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
-    if (rem > 6) phase<6, PF>(lds, acc, offA0, offA1, offB0, offB1, ra, rg, voA, voG, soA, soG, stepA, stepG, dmaoff);
+    for (; s + kRing <= nslab; s += kRing) phases_from<0, KP, PF>(kRing, lds, acc, c, ra, rg, soA, soG);
+    phases_from<0, KP, PF>(nslab - s, lds, acc, c, ra, rg, soA, soG);     // < 8 slabs left: wave-uniform exits
     if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead pieces nobody reads
 
@@ -263,9 +290,9 @@ int pick_splits(long M, int Ka, int N) {
     return s;
 }
 
-template <int PF>
+template <int KP, int PF>
 void launch_tn(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
-    auto kern = k_wgrad_tn<PF>;
+    auto kern = k_wgrad_tn<KP, PF>;
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
 }
@@ -295,7 +322,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
                 "ver_wgrad_tn: N and the output pitch must be multiples of 4");
     const int S = splits > 0 ? splits : pick_splits(M, Ka, N);
     VER_REQUIRE(S <= 1024, VER_EINVAL, "ver_wgrad_tn: %d row chunks", S);
-    const long Mc = ((M + S - 1) / S + kSlabRows - 1) / kSlabRows * kSlabRows;      // rows per chunk, whole slabs
+    const long Mc = ((M + S - 1) / S + 2 * kSlabRows - 1) / (2 * kSlabRows) * (2 * kSlabRows);  // rows per chunk, whole phases
     VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0xFFFFFFFFL, VER_EUNSUPPORTED,
                 "ver_wgrad_tn: a row chunk exceeds the 4-GiB range of a buffer offset (more splits)");
     VER_REQUIRE(workspace_bytes >= (long)S * Ka * N * (long)sizeof(float), VER_EINVAL, "ver_wgrad_tn: workspace of %ld bytes, %ld needed",
@@ -315,11 +342,13 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
     p.T = ((Ka + kTile - 1) / kTile) * p.tiles_n;
     hipError_t e = hipSuccess;
     if (M > 0) {
-        switch (flags & 7) {
-            case 3: launch_tn<3>(p, p.T * S, st, e); break;
-            case 4: launch_tn<4>(p, p.T * S, st, e); break;
-            case 6: launch_tn<6>(p, p.T * S, st, e); break;
-            default: launch_tn<5>(p, p.T * S, st, e); break;
+        switch (flags & 15) {
+            case 4: launch_tn<1, 4>(p, p.T * S, st, e); break;
+            case 5: launch_tn<1, 5>(p, p.T * S, st, e); break;
+            case 6: launch_tn<1, 6>(p, p.T * S, st, e); break;
+            case 8 + 2: launch_tn<2, 2>(p, p.T * S, st, e); break;
+            case 8 + 4: launch_tn<2, 4>(p, p.T * S, st, e); break;
+            default: launch_tn<1, 3>(p, p.T * S, st, e); break;
         }
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn: LDS attribute: %s", hipGetErrorString(e));
     } else {

@@ -25,7 +25,8 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
-           'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn')
+           'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
+           'ver_occ_mlp_backward_fused_stats')
 
 _lib = None
 
@@ -745,20 +746,32 @@ def occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3):
     return vec.contiguous()
 
 
-def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True, centered=False):
+# 1 (default): on centred rows the forward kernel saves 1/std of both LayerNorms per row (8 B on 288 B of traffic) and the
+# wave-specialised backward kernel reads them back instead of recomputing the statistics; 0: recompute (round-4 form)
+_OCC_MLP_SAVE_RSTD = os.environ.get('VER_OCC_MLP_SAVE_RSTD', '1') == '1'
+
+
+def occ_mlp_forward(x, image, vectors, eps=1e-5, first_linear=True, centered=False, want_rstd=False):
     """x bf16 [..., 128] -> logits bf16 [..., 16] (ver_occ_mlp_forward).  ``first_linear=False``: x is already the
     output of the first Linear (folded into its producer).  ``centered``: the hidden Linears' weights / biases were
-    centred over their output axis (VER_OCC_MLP_CENTERED): the LayerNorms skip the mean pass."""
+    centred over their output axis (VER_OCC_MLP_CENTERED): the LayerNorms skip the mean pass.  ``want_rstd``: returns
+    ``(logits, rstd f32 [N, 2])`` -- 1/std of the two LayerNorms per row, for ver_occ_mlp_backward_fused_stats."""
     x = _gpu(x, 'x')
     if x.dtype != torch.bfloat16 or x.shape[-1] != 128:
         raise TypeError('x must be bf16 [..., 128]')
     x = x.contiguous()
     n = x.numel() // 128
     logits = torch.empty(x.shape[:-1] + (16,), dtype=torch.bfloat16, device=x.device)
-    _launch('ver_occ_mlp_forward', lambda: lib().ver_occ_mlp_forward(
-        _p(x), _p(image), _p(vectors), _p(logits), ctypes.c_long(n), 128, 16, ctypes.c_float(eps),
-        (1 if first_linear else 0) | (2 if centered else 0), _stream()))
-    return logits
+    rstd = torch.empty(n, 2, dtype=torch.float32, device=x.device) if want_rstd else None
+    _launch('ver_occ_mlp_forward', lambda: lib().ver_occ_mlp_forward_stats(
+        _p(x), _p(image), _p(vectors), _p(logits), _p(rstd) if rstd is not None else None, ctypes.c_long(n), 128, 16,
+        ctypes.c_float(eps), (1 if first_linear else 0) | (2 if centered else 0), _stream()))
+    return (logits, rstd) if want_rstd else logits
+
+
+def _occ_mlp_wants_rstd(folded, centered, n):
+    return bool(_OCC_MLP_SAVE_RSTD and folded and centered and _OCC_MLP_BWD_FUSED and occ_mlp_backward_takes_grad_scale()
+                and n < (1 << 28))
 
 
 def _rows_tn(a, b, chunk=8000, with_colsum=True):
@@ -825,14 +838,18 @@ class OccMLPFunction(Function):
             w1, b1 = w2, torch.zeros(128, device=x.device)
         image = occ_mlp_pack(w1, w2, w3)
         vec = occ_mlp_vectors(b1, g1, be1, b2, g2, be2, b3)
-        ctx.save_for_backward(x, image, vec, w2.detach(), w3.detach())
         ctx.eps, ctx.centered = eps, bool(centered)
-        return occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded, centered=centered)
+        ctx.has_rstd = _occ_mlp_wants_rstd(ctx.folded, centered, x.numel() // 128) and any(ctx.needs_input_grad)
+        out = occ_mlp_forward(x, image, vec, eps, first_linear=not ctx.folded, centered=centered, want_rstd=ctx.has_rstd)
+        logits, rstd = out if ctx.has_rstd else (out, None)
+        ctx.save_for_backward(x, image, vec, w2.detach(), w3.detach(), *((rstd,) if ctx.has_rstd else ()))
+        return logits
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_logits):
-        x, image, vec, w2, w3 = ctx.saved_tensors
+        x, image, vec, w2, w3 = ctx.saved_tensors[:5]
+        rstd = ctx.saved_tensors[5] if ctx.has_rstd else None
         shape = x.shape
         x2 = x.view(-1, 128)
         n = x2.shape[0]
@@ -842,8 +859,9 @@ class OccMLPFunction(Function):
             # N-split kernel: d(W2) and every other parameter gradient accumulated in the kernel, no side tensors
             gx = torch.empty_like(x2)
             pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
-            _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
-                _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
+            _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused_stats(
+                _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec),
+                _p(rstd) if rstd is not None else None, _p(gx), _p(pg),
                 ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _p(gscale) if gscale is not None else None,
                 2 if ctx.centered else 0, _stream()))
             vecs = pg[:768].view(6, 128)
@@ -883,7 +901,9 @@ class OccMLPFocalLossFunction(Function):
         x = _gpu(x, 'x').contiguous()
         image = occ_mlp_pack(w2, w2, w3)
         vec = occ_mlp_vectors(torch.zeros(128, device=x.device), g1, be1, b2, g2, be2, b3)
-        logits = occ_mlp_forward(x, image, vec, eps, first_linear=False, centered=centered)
+        ctx.has_rstd = _occ_mlp_wants_rstd(True, centered, x.numel() // 128)
+        out = occ_mlp_forward(x, image, vec, eps, first_linear=False, centered=centered, want_rstd=ctx.has_rstd)
+        logits, rstd = out if ctx.has_rstd else (out, None)
         l2 = logits.view(-1, 16)
         n = l2.shape[0]
         target = _gpu(target, 'target').to(torch.int64).contiguous()
@@ -897,22 +917,24 @@ class OccMLPFocalLossFunction(Function):
             _p(l2), _p(target), _p(partial), _p(l2), ctypes.c_long(n), 16, ctypes.c_float(gamma), ctypes.c_float(alpha),
             1, _p(flag.dev), _stream()))                      # (in place: the logits buffer now holds d loss / d logits)
         flag.mirror(16)
-        ctx.save_for_backward(x, vec, w2.detach(), w3.detach(), l2)
+        ctx.save_for_backward(x, vec, w2.detach(), w3.detach(), l2, *((rstd,) if ctx.has_rstd else ()))
         ctx.eps, ctx.centered = eps, bool(centered)
         return partial.sum()
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        x, vec, w2, w3, gl = ctx.saved_tensors
+        x, vec, w2, w3, gl = ctx.saved_tensors[:5]
+        rstd = ctx.saved_tensors[5] if ctx.has_rstd else None
         shape = x.shape
         x2 = x.view(-1, 128)
         n = x2.shape[0]
         gscale = _gpu(grad_out, 'grad_out').float().reshape(1).contiguous()
         gx = torch.empty_like(x2)
         pg = torch.empty(6 * 128 + 16 * 128 + 16 + 128 * 128, dtype=torch.float32, device=x.device)
-        _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused(
-            _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec), _p(gx), _p(pg),
+        _launch('ver_occ_mlp_backward_fused', lambda: lib().ver_occ_mlp_backward_fused_stats(
+            _p(x2), _p(gl), _p(w2.float().contiguous()), _p(w3.float().contiguous()), _p(vec),
+            _p(rstd) if rstd is not None else None, _p(gx), _p(pg),
             ctypes.c_long(n), 128, 16, ctypes.c_float(ctx.eps), _p(gscale), 2 if ctx.centered else 0, _stream()))
         vecs = pg[:768].view(6, 128)
         dw3 = pg[768:768 + 2048].view(16, 128)

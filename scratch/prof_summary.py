@@ -17,7 +17,7 @@ def pmc_stats(path, out, like=('k_sca', 'k_project', 'k_build', 'k_zero', 'k_msd
         f.write('Kernel,Counter,PerDispatch,Dispatches\n')
         for k, c, v, n in sorted(rows):
             if any(l in k for l in like):
-                f.write('"%s",%s,%.1f,%d\n' % (k.split('(')[0][:80], c, v / n, n))
+                f.write('"%s",%s,%.1f,%d\n' % (k.replace('(anonymous namespace)::', '').split('(')[0][:80], c, v / n, n))
 def kernel_stats_timed(path, out, total_steps, skip_steps):
     """Per-kernel statistics over the dispatches of the TIMED steps only: a kernel launched c times in `total_steps` identical
     steps runs c / total_steps times per step; its first skip_steps * c / total_steps dispatches (priming + warm-up steps,

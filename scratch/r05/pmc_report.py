@@ -6,4 +6,4 @@ rows = cur.execute("select kernel_name, counter_name, sum(value), count(distinct
 with open(sys.argv[2], 'a') as f:
     for k, c, v, n in sorted(rows):
         if not like or any(l in k for l in like):
-            f.write('"%s",%s,%.1f,%d\n' % (k.split('(')[0][:100], c, v / n, n))
+            f.write('"%s",%s,%.1f,%d\n' % (k.replace('(anonymous namespace)::', '').split('(')[0][:100], c, v / n, n))

@@ -20,7 +20,7 @@ echo "# command: rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE> -- pyt
 mkdir -p profiles; cp $R/r05_bench_pmc_fetch_write.csv profiles/   # bench.py reads it from profiles/
 rm -f $R/r05_bench_pmc_mfma.csv
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -d $R/pmc_mfma -o pmc -- python3 $CMD2 > $R/pmc_mfma.json 2> $R/pmc_mfma.err; echo "pmc mfma $?"
-python scratch/r04/mfma_summary.py $R/pmc_mfma/pmc_results.db $R/r05_bench_pmc_mfma.csv > /dev/null; rm -rf $R/pmc_mfma
+python scratch/r05/mfma_summary.py $R/pmc_mfma/pmc_results.db $R/r05_bench_pmc_mfma.csv > /dev/null; rm -rf $R/pmc_mfma
 FT="bench.py --workload vocc_full_train --steps 2 --warmup 1 --no-cpu-baseline --latency-batches= --host-fed-steps 0"
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/trace_ft -o trace -- python3 $FT > $R/trace_ft.json 2> $R/trace_ft.err; echo "trace full_train $?"
 python scratch/prof_summary.py kernels $R/trace_ft/trace_results.db $R/r05_full_train_kernel_stats.csv; rm -rf $R/trace_ft

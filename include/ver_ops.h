@@ -455,6 +455,17 @@ long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits);
 int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int Ka, int N, void* out, long ldo,
                   int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream);
 
+/* Forward product of the same layers (ABI 24):  c[M, N] = a[M, K] w[K, N] (+ bias[N]), bf16 in, fp32 accumulation, bf16 out.
+ * Replaces the `torch.mm(a_mat[:, c0:c1], w, out=...)` / `addmm` of dense_heads/upsample.py and the `a @ wa.t()` of
+ * occ_proj_lattice.py (with wa.t() materialised as [K, N]) -- the reference's ConvTranspose3d / occ_proj forward
+ * (voxelformer_occupancy_head.py:560, :571) on the even lattice.
+ *   a    bf16 [M, lda] (first K columns; K contiguous)      w  bf16 [K, ldw] (first N columns; N contiguous)
+ *   bias f32 [N] or NULL                                     c  bf16 [M, ldc] (first N columns written)
+ * Requirements: K % 32 == 0, K >= 64, a / w 16-byte aligned, lda % 8 == 0, ldw % 8 == 0; any M, N.  flags: 0.
+ */
+int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
+                 int N, int flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1265,3 +1265,71 @@ def test_sca_gather_three_camera_overlap_determinism_bound():
     ref = oracle_slots(o, value, offsets, logits, hit.uv.cpu(), mask, (14, 14))
     first = hip.sca_gather(value.to(DEV), offsets.to(DEV), logits.to(DEV), hit, 14, 14)
     assert maxdiff(first.cpu(), ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ head GEMMs (round 5)
+@pytest.mark.parametrize('M,Ka,lda,c0,N,ldg,splits', [
+    (2048, 256, 256, 0, 256, 256, 1), (4096, 480, 640, 64, 384, 384, 2), (16384, 224, 1024, 128, 260, 264, 8),
+    (32768, 1000, 1024, 0, 772, 776, 16), (1800, 300, 304, 0, 132, 136, 0), (14400 + 7, 520, 520, 0, 256, 256, 3),
+    (50000, 64, 64, 0, 64, 64, 0), (15, 40, 40, 0, 8, 8, 0)])
+def test_wgrad_tn_equals_the_fp32_product(M, Ka, lda, c0, N, ldg, splits):
+    """ver_wgrad_tn (csrc/ver_wgrad.hip): dW = A^T G with the ROWS on the contraction axis -- the weight gradient of the
+    reference's ConvTranspose3d stack and occ_proj (head:251-258, :560, :571) as dense_heads/upsample.py::rows_tn forms it.
+    Operands that are column ranges of wider matrices, ragged tile edges in both output dimensions, row counts that are
+    not multiples of the 16-row slab or of the chunk count (the tail reads as zeros through the buffer range), every
+    split count; fp32 output against the fp32 product of the same bf16 operands (fp32 accumulation order only), bf16
+    output one rounding away."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(M + Ka + N)
+    Af = torch.randn(M, lda, generator=gen).to(DEV).to(torch.bfloat16)
+    Gf = torch.randn(M, ldg, generator=gen).to(DEV).to(torch.bfloat16)
+    A, G = Af[:, c0:c0 + Ka], Gf[:, :N]
+    want = A.float().t() @ G.float()
+    got = hip.wgrad_tn(A, G, out_dtype=torch.float32, splits=splits)
+    assert got.shape == (Ka, N)
+    assert float((got - want).abs().max()) < 3e-5 * float(want.abs().max()) * max(1.0, (M / 4096) ** 0.5)
+    got16 = hip.wgrad_tn(A, G, splits=splits)
+    assert got16.dtype == torch.bfloat16
+    from util import rel_l2
+    assert rel_l2(got16.float(), want) < 3e-3
+    # transpose-detecting: A and G are different random matrices, Ka != N in most cases; and the lattice layers' helper
+    up = pkg('dense_heads.upsample')
+    assert rel_l2(up.rows_tn(A, G).float(), want) < 3e-3
+    assert rel_l2(up.rows_tn(G, A, out_dtype=torch.float32), want.t()) < 1e-4
+
+
+def test_wgrad_tn_refuses_what_it_cannot_take():
+    hip = pkg('hipops')
+    a = torch.randn(64, 32, device=DEV).to(torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        hip.wgrad_tn(a.float(), a.float())                       # fp32 operands: the caller's plain matmul
+    with pytest.raises(RuntimeError):
+        hip.wgrad_tn(a[:, 1:9], a)                                # rows not 16-byte aligned
+    z = hip.wgrad_tn(a[:0], a[:0], out_dtype=torch.float32)       # no rows: zeros
+    assert z.shape == (32, 32) and float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('M,K,lda,c0,N,ldw,bias', [
+    (256, 64, 64, 0, 256, 256, False), (512, 128, 192, 64, 256, 256, True), (300, 96, 96, 0, 200, 200, True),
+    (1000, 1024, 1088, 32, 772, 776, False), (4096, 2048, 2048, 0, 1536, 1536, False), (77, 320, 320, 0, 40, 40, True),
+    (2049, 4096, 4096, 0, 520, 520, True)])
+def test_gemm_nn_equals_the_fp32_product(M, K, lda, c0, N, ldw, bias):
+    """ver_gemm_nn (csrc/ver_gemm.hip): C = A W (+ bias), the forward GEMM of a lattice layer (head:560 on the even
+    lattice).  A as a column range of a wider matrix, partial tiles in M and N, results written into a column range of a
+    wider output without touching its neighbours; against the fp32 product of the same bf16 operands rounded once."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(M + K + N)
+    Af = torch.randn(M, lda, generator=gen).to(DEV).to(torch.bfloat16)
+    Wf = torch.randn(K, ldw, generator=gen).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, generator=gen).to(DEV) if bias else None
+    A, W = Af[:, c0:c0 + K], Wf[:, :N]
+    want = A.float() @ W.float() + (b if bias else 0)
+    got = hip.gemm_nn(A, W, b)
+    from util import rel_l2
+    assert got.dtype == torch.bfloat16 and rel_l2(got.float(), want) < 3e-3
+    assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())       # one bf16 rounding
+    wide = torch.full((M, N + 24), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_nn(A, W, b, out=wide[:, 8:8 + N])
+    assert torch.equal(wide[:, 8:8 + N], got) and float(wide[:, :8].min()) == 7.0 and float(wide[:, 8 + N:].min()) == 7.0
+    with pytest.raises(RuntimeError):
+        hip.gemm_nn(Af[:, :K - 16] if K > 80 else Af[:, :48], Wf[:K - 16 if K > 80 else 48, :N])      # K % 32 != 0

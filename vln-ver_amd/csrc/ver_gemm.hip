@@ -1,0 +1,273 @@
+// Forward product of the occupancy head's GEMM layers on gfx950 matrix cores:
+//     C[M, N] = A[M, K] * W[K, N] (+ bias[N])        (bf16 operands, fp32 accumulation, bf16 result)
+// A = rows of the tap matrix of a lattice layer / of the gathered occ_proj operand (row-major, K contiguous; may be a
+// column range of a wider matrix), W = the class weight matrix [K, N] as the layers keep it (row-major, N contiguous):
+// dense_heads/upsample.py (_Layer0Z4, _LatticeLayerZ4, _LatticeLayer) and occ_proj_lattice.py, i.e. the reference's three
+// ConvTranspose3d and occ_proj (voxelformer_occupancy_head.py:251-258, :560, :571) evaluated on the even lattice.
+//
+// The kernel is the sibling of k_wgrad_tn (ver_wgrad.hip: same 256 x 256 tile, 8 waves as 2 x 4, two wave groups half a
+// phase apart, LDS-DMA ring, counted vmcnt, raw barriers); what differs is the operand with the contraction index on its
+// FAST axis:
+//   * A tile rows are streamed as [256 rows][32 k] images (64 B per row; a wave instruction moves 16 rows x 64 B), their
+//     16-byte chunks XOR-ed by bits 2-3 of the row on the SOURCE address, and the MFMA fragment of a lane (8 consecutive k
+//     of one row) is ONE ds_read_b128, conflict free by that swizzle;
+//   * W is streamed in 16-row slabs and read through ds_read_b64_tr_b16 exactly as both operands of k_wgrad_tn;
+//   * a phase is 32 of K (two MFMA k-steps: 8 + 8 fragment reads, 4 LDS-DMA pieces, 16 MFMAs per wave), the ring holds
+//     four phases (128 KB), pieces are requested two phases ahead;
+//   * no split over K (K = 6 304 .. 38 400 here: 197+ phases per tile); tiles are dealt to the XCDs in contiguous
+//     ranges, the N tiles of one row block next to each other, so that the 32 tiles in flight on an XCD share their A
+//     rows and W columns in its L2.
+#include "ver_common.h"
+
+namespace {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kTile = 256;
+constexpr int kStageBytes = 32768;          // A image [256][32] (16 KB) + two W slabs [16][256] (2 x 8 KB)
+constexpr int kStages = 4;
+constexpr int kLdsBytes = kStages * kStageBytes;
+
+// LDS reads as inline asm: behind the builtins the compiler waits for vmcnt(0) in front of every LDS read that follows an
+// LDS-DMA (ver_wgrad.hip).  Results are valid behind the s_waitcnt lgkmcnt(0) of phase().
+template <int OFF>
+__device__ __forceinline__ i32x2 tr_read(int addr) {
+    i32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ i32x4 row_read(int addr) {
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ bf16x8 frag(i32x2 lo, i32x2 hi) {
+    return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
+}
+
+struct GemmArgs {
+    const __bf16* A;
+    const __bf16* W;
+    const float* bias;      // [N] or null
+    __bf16* C;
+    long lda, ldw, ldc, M;
+    int K, N, tiles_n, T, per_xcd;
+};
+
+struct GemmLane {
+    int offA0, offA1;       // A fragment reads of k-step 0 / 1 of a phase (stage 0, row tile 0)
+    int offB0, offB1;       // W fragment reads (stage 0, slab 0, column tile 0 / 1)
+    int voA, voW;           // per-lane source offsets of this wave's LDS-DMA pieces
+    int stepW;              // bytes per 16-row slab of W
+    int stepA16;            // bytes per 16 rows of A (second LDS-DMA piece of a wave)
+    int dmaA, dmaW;         // offsets of this wave's pieces inside a stage
+};
+
+template <int ST>
+__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const GemmLane& c, __amdgpu_buffer_rsrc_t ra,
+                                      __amdgpu_buffer_rsrc_t rw, int& soA, int& soW) {
+    // (the offset field of a DS instruction has 16 bits: stages 2-3 go through base registers 64 KiB up)
+    constexpr int SB = (ST & 1) * kStageBytes;
+    constexpr int UP = ST >= 2 ? 65536 : 0;
+    const int a0 = c.offA0 + UP, a1 = c.offA1 + UP, b0 = c.offB0 + UP, b1 = c.offB1 + UP;
+    i32x4 av[2][4];
+    i32x2 bl[2][2], bh[2][2];
+    // k-step 0: A chunks (l >> 5), W slab 0; k-step 1: A chunks 2 + (l >> 5), W slab 1
+    av[0][0] = row_read<SB>(a0);
+    av[0][1] = row_read<SB + 2048>(a0);
+    bl[0][0] = tr_read<SB + 16384>(b0);
+    bh[0][0] = tr_read<SB + 16384 + 512>(b0);
+    bl[0][1] = tr_read<SB + 16384>(b1);
+    bh[0][1] = tr_read<SB + 16384 + 512>(b1);
+    av[0][2] = row_read<SB + 4096>(a0);
+    av[0][3] = row_read<SB + 6144>(a0);
+    av[1][0] = row_read<SB>(a1);
+    av[1][1] = row_read<SB + 2048>(a1);
+    bl[1][0] = tr_read<SB + 24576>(b0);
+    bh[1][0] = tr_read<SB + 24576 + 512>(b0);
+    bl[1][1] = tr_read<SB + 24576>(b1);
+    bh[1][1] = tr_read<SB + 24576 + 512>(b1);
+    av[1][2] = row_read<SB + 4096>(a1);
+    av[1][3] = row_read<SB + 6144>(a1);
+    // LDS-DMA of the phase two ahead: this wave's 2 x 16 rows of the A image and its piece of each W slab
+    constexpr int DS = ((ST + 2) % kStages) * kStageBytes;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS + c.dmaA), 16, c.voA, soA, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS + c.dmaA + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
+    soA += 64;
+    soW += 2 * c.stepW;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's pieces of the NEXT phase have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(av[1][0]), "+v"(av[1][1]), "+v"(av[1][2]),
+                   "+v"(av[1][3]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[0][1]), "+v"(bh[0][1]), "+v"(bl[1][0]), "+v"(bh[1][0]),
+                   "+v"(bl[1][1]), "+v"(bh[1][1])
+                 :
+                 : "memory");
+    bf16x8 a[2][4], b[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[u][i] = __builtin_bit_cast(bf16x8, av[u][i]);
+        b[u][0] = frag(bl[u][0], bh[u][0]);
+        b[u][1] = frag(bl[u][1], bh[u][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][it], b[u][jt], acc[it][jt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    // block b runs on XCD b % 8; an XCD works through a contiguous range of tiles (N tiles of a row block adjacent)
+    const int tile = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= p.per_xcd || tile >= p.T) return;
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const long row0 = (long)mt * kTile;
+    const int nphase = p.K / 32;
+
+    // A: rows row0 .. row0 + 255 (past M: zeros by the buffer range), the K columns of the operand
+    const __bf16* ab = p.A + row0 * p.lda;
+    const long abytes = ((p.M - row0 - 1) * p.lda + p.K) * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
+    // W: columns nt * 256 .., all K rows (behind the last element: zeros)
+    const __bf16* wb = p.W + (long)nt * kTile;
+    const long wbytes = ((long)(p.K - 1) * p.ldw + p.N - (long)nt * kTile) * 2;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)max(0L, min(wbytes, 0xFFFFFFFFL)), 0x00020000);
+    GemmLane c;
+    {
+        // A image piece: 16 rows x 64 B per instruction; lane -> (row l >> 2, position l & 3), position p holds source
+        // chunk p ^ ((row >> 2) & 3).  This wave moves rows 32 w .. 32 w + 31 (two instructions, + 16 rows = + 1 KiB).
+        const int prow = 32 * wave + (lane >> 2);
+        const int pch = (lane & 3) ^ ((prow >> 2) & 3);
+        c.voA = (int)(prow * p.lda * 2) + pch * 16;
+        c.dmaA = wave * 2048;
+        c.stepA16 = (int)(16 * p.lda * 2);          // (second instruction: rows + 16; same swizzle term)
+        // W slab piece: 8 rows x 128 B, chunks XOR-ed by bit 1 of the row (ver_wgrad.hip)
+        const int wrow = lane >> 3, wch = (lane & 7) ^ (((wrow >> 1) & 1) << 2);
+        c.voW = (int)(((8 * (wave >> 2) + wrow) * p.ldw + 64 * (wave & 3)) * 2) + wch * 16;
+        c.stepW = (int)(16 * p.ldw * 2);
+        c.dmaW = wave * 1024;
+    }
+    // fragment reads.  A (row mode): lane (i = l & 31, k half = l >> 5) reads chunk (2 step + (l >> 5)) ^ ((i >> 2) & 3)
+    // of row 128 wr + 32 it + i;  W (transposing): as in ver_wgrad.hip
+    {
+        const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+        const int i = lane & 31, sw = (i >> 2) & 3;
+        c.offA0 = lbase + (128 * wr + i) * 64 + (((lane >> 5) ^ sw) << 4);
+        c.offA1 = c.offA0 ^ 32;
+        const int q = lane >> 4, cl = lane & 15;
+        const int lowch = (2 * (q & 1) + ((cl & 3) >> 1)) ^ (((cl >> 3) & 1) << 2);
+        c.offB0 = lbase + ((q >> 1) * 32 + (cl >> 2)) * 128 + lowch * 16 + (cl & 1) * 8 + wc * 1024;
+        c.offB1 = c.offB0 ^ 64;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[it][jt][r] = 0.0f;
+
+    int soA = 0, soW = 0;
+    // prologue: phases 0 and 1 in flight, phase 0 landed
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kStageBytes + c.dmaA), 16, c.voA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kStageBytes + c.dmaA + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
+        soA += 64;
+        soW += 2 * c.stepW;
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave group runs half a phase behind
+
+    int s = 0;
+    for (; s + kStages <= nphase; s += kStages) {
+        phase<0>(lds, acc, c, ra, rw, soA, soW);
+        phase<1>(lds, acc, c, ra, rw, soA, soW);
+        phase<2>(lds, acc, c, ra, rw, soA, soW);
+        phase<3>(lds, acc, c, ra, rw, soA, soW);
+    }
+    const int rem = nphase - s;
+    if (rem > 0) phase<0>(lds, acc, c, ra, rw, soA, soW);
+    if (rem > 1) phase<1>(lds, acc, c, ra, rw, soA, soW);
+    if (rem > 2) phase<2>(lds, acc, c, ra, rw, soA, soW);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // C tile: register r of tile (it, jt) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31.  Buffer stores:
+    // one 32-bit lane offset + a scalar row offset per store; rows past M fall outside the range and are dropped, columns
+    // past N are sent there on purpose.
+    __bf16* cb = p.C + row0 * p.ldc + (long)nt * kTile;
+    const long cbytes = ((p.M - row0 - 1) * p.ldc + p.N - (long)nt * kTile) * 2;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cb, 0, (int)max(0L, min(cbytes, 0xFFFFFFFFL)), 0x00020000);
+    const int ldc2 = (int)(p.ldc * 2);
+    const int vbase = (128 * wr + 4 * (lane >> 5)) * ldc2 + (64 * wc + (lane & 31)) * 2;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = nt * kTile + 64 * wc + 32 * jt + (lane & 31);
+        const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.0f;
+        const int vo = j < p.N ? vbase + 64 * jt : -2;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const __bf16 v = (__bf16)(acc[it][jt][r] + bj);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rc, vo, (32 * it + (r & 3) + 8 * (r >> 2)) * ldc2, 0);
+            }
+    }
+}
+}  // namespace
+
+extern "C" int ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M,
+                           int K, int N, int flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VER_REQUIRE(M >= 0 && K > 0 && N > 0, VER_EINVAL, "ver_gemm_nn: bad sizes M=%ld K=%d N=%d", M, K, N);
+    if (M == 0) return VER_OK;
+    VER_REQUIRE(a && w && c, VER_EINVAL, "ver_gemm_nn: null pointer argument");
+    VER_REQUIRE(flags == 0, VER_EINVAL, "ver_gemm_nn: unknown flags 0x%x", flags);
+    VER_REQUIRE(lda >= K && ldw >= N && ldc >= N, VER_EINVAL, "ver_gemm_nn: row pitch smaller than the row");
+    VER_REQUIRE(K % 32 == 0 && K >= 64, VER_EUNSUPPORTED, "ver_gemm_nn: K = %d must be a multiple of 32 (>= 64)", K);
+    VER_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, VER_EUNSUPPORTED,
+                "ver_gemm_nn: operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
+    VER_REQUIRE(256L * lda * 2 + K * 2L < 0x7FFFFFFFL && (long)K * ldw * 2 < 0xFFFFFFFFL && 256L * ldc * 2 < 0x7FFFFFFFL,
+                VER_EUNSUPPORTED, "ver_gemm_nn: a tile's operand range exceeds the 32-bit offsets");
+    GemmArgs p;
+    p.A = (const __bf16*)a;
+    p.W = (const __bf16*)w;
+    p.bias = bias;
+    p.C = (__bf16*)c;
+    p.lda = lda;
+    p.ldw = ldw;
+    p.ldc = ldc;
+    p.M = M;
+    p.K = K;
+    p.N = N;
+    p.tiles_n = (N + kTile - 1) / kTile;
+    p.T = (int)((M + kTile - 1) / kTile) * p.tiles_n;
+    p.per_xcd = (p.T + 7) / 8;
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_gemm_nn: LDS attribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)(8 * p.per_xcd)), dim3(512), kLdsBytes, st, p);
+    return ver_check_launch("ver_gemm_nn");
+}

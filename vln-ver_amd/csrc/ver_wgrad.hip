@@ -313,7 +313,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
                             int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VER_REQUIRE(M >= 0 && Ka > 0 && N > 0, VER_EINVAL, "ver_wgrad_tn: bad sizes M=%ld Ka=%d N=%d", M, Ka, N);
-    VER_REQUIRE(a && g && out && workspace, VER_EINVAL, "ver_wgrad_tn: null pointer argument");
+    VER_REQUIRE(out && workspace && ((a && g) || M == 0), VER_EINVAL, "ver_wgrad_tn: null pointer argument");
     VER_REQUIRE(out_dtype == VER_F32 || out_dtype == VER_BF16, VER_EINVAL, "ver_wgrad_tn: out_dtype %d", out_dtype);
     VER_REQUIRE(lda >= Ka && ldg >= N && ldo >= N, VER_EINVAL, "ver_wgrad_tn: row pitch smaller than the row");
     VER_REQUIRE(lda % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)g & 15) == 0, VER_EUNSUPPORTED,

@@ -21,6 +21,8 @@ Everything is plain differentiable torch (GEMMs go to hipBLASLt/MFMA on the GPU)
 provides the backward.  ``full_volume`` scatters the last lattice into the dense
 ``[B,C,Z,8H,8W]`` tensor the reference's raw ``.view`` expects.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -504,8 +506,7 @@ class _Layer0Z4(torch.autograd.Function):
         _gather_z4(x, ZS_PLAIN, a_mat, taps, offs, ci, h, w)
         rows = k.reshape(75 * ci, co)
         wmat = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)        # [50 ci, 2 co]
-        with gemm_timed('head_gemm_fwd', a_mat.shape[0], a_mat.shape[1], wmat.shape[1]):
-            out = torch.addmm(torch.cat([bias, bias]).to(x.dtype), a_mat, wmat)
+        out = mm_fwd(a_mat, wmat, bias=torch.cat([bias, bias]))
         ctx.save_for_backward(a_mat, wmat)
         ctx.geom = (tuple(x.shape), ci, co, h, w)
         return out.view(b, 2, h, w, 2, co)
@@ -644,8 +645,7 @@ class _LatticeLayerZ4(torch.autograd.Function):
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, lohi = plan[cls]
             w = rows.index_select(0, lohi).view(c1 - c0, 2 * co)          # [W_lo | W_hi], one gather
-            with gemm_timed('head_gemm_fwd', m, c1 - c0, 2 * co):
-                torch.mm(a_mat[:, c0:c1], w, out=out[p])
+            mm_fwd(a_mat[:, c0:c1], w, out=out[p])
             ws.append(w)
         # the class weight matrices are kept for the backward pass (0.17 GB per layer at Co = 768) instead of being
         # gathered again there: weight-side work does not shrink with the batch (config.latency)
@@ -696,6 +696,31 @@ def gemm_timed(name, m, k, n):
     (hipops.timed: free unless a KernelTimer is set)."""
     from ..hipops import timed
     return timed(name, 2.0 * m * k * n)
+
+
+# Forward GEMMs of the lattice layers on ver_gemm_nn (csrc/ver_gemm.hip) from this many rows on (and K >= 2048); below, and
+# for every other dtype / device, the library.  Measured on the 192-viewpoint shapes (scratch/r05/gemm_bench.py): layer 3
+# 1 266-1 292 -> 1 312-1 338 TFLOP/s, layers 1 / 2 1 121-1 210 -> 1 310; occ_proj (K = 832) and the 8-viewpoint shapes are
+# faster in the library and stay there.  VER_OWN_GEMM=0: library everywhere.
+_OWN_GEMM = os.environ.get('VER_OWN_GEMM', '1') == '1'
+_OWN_GEMM_MIN_ROWS = 49152
+
+
+def mm_fwd(a, w, out=None, bias=None):
+    """``a @ w (+ bias)`` for the forward GEMM of a layer: a [M, K] (may be a column range of the tap matrix), w [K, N]
+    row-major, optional bias [N]; ``out`` [M, N] is written when given."""
+    m, k = a.shape
+    n = w.shape[1]
+    if _OWN_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and m >= _OWN_GEMM_MIN_ROWS and k >= 2048:
+        from ..hipops import gemm_nn, gemm_nn_supported
+        if gemm_nn_supported(a, w) and (out is None or (out.stride(-1) == 1 and out.dtype == torch.bfloat16)):
+            # (the library adds the bias as a bf16 vector: the same rounded values here)
+            return gemm_nn(a, w, None if bias is None else bias.to(a.dtype).float(), out)
+    with gemm_timed('head_gemm_fwd', m, k, n):
+        if bias is None:
+            return torch.mm(a, w, out=out) if out is not None else torch.mm(a, w)
+        b = bias.to(a.dtype)
+        return torch.addmm(b, a, w, out=out) if out is not None else torch.addmm(b, a, w)
 
 
 def rows_tn(a, g, out_dtype=None):

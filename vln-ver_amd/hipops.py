@@ -26,7 +26,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats')
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn')
 
 _lib = None
 
@@ -1133,4 +1133,31 @@ def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0):
         _p(a), ctypes.c_long(a.stride(0)), _p(g), ctypes.c_long(g.stride(0)), ctypes.c_long(m), ka, n, _p(out),
         ctypes.c_long(n), 1 if out_dtype == torch.bfloat16 else 0, int(splits), int(flags), _p(ws), ctypes.c_long(nbytes),
         _stream()), meta=dict(flops=2.0 * m * ka * n))
+    return out
+
+
+def gemm_nn_supported(a, w):
+    """Shapes / strides ``gemm_nn`` takes: bf16 GPU matrices, unit column stride, 16-byte aligned rows, K % 32 == 0."""
+    return (a.is_cuda and w.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2
+            and w.dim() == 2 and a.shape[1] == w.shape[0] and a.stride(1) == 1 and w.stride(1) == 1
+            and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and a.shape[1] % 32 == 0 and a.shape[1] >= 64)
+
+
+def gemm_nn(a, w, bias=None, out=None):
+    """``a @ w (+ bias)`` on ver_gemm_nn: a bf16 [M, K] (may be a column range of a wider row-major matrix), w bf16 [K, N]
+    row-major, bias fp32 [N] or None -> bf16 [M, N] (``out``: a bf16 matrix with unit column stride to write into)."""
+    if not gemm_nn_supported(a, w):
+        raise RuntimeError('gemm_nn: unsupported operands %s %s / %s %s' % (tuple(a.shape), a.stride(), tuple(w.shape), w.stride()))
+    m, k = a.shape
+    n = w.shape[1]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=a.device)
+    if out.shape != (m, n) or out.dtype != torch.bfloat16 or out.stride(1) != 1 or not out.is_cuda:
+        raise RuntimeError('gemm_nn: out must be a bf16 [M, N] GPU matrix with unit column stride')
+    if bias is not None:
+        bias = _gpu(bias, 'bias').float().contiguous()
+    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn(
+        _p(a), ctypes.c_long(a.stride(0)), _p(w), ctypes.c_long(w.stride(0)), _p(bias) if bias is not None else None,
+        _p(out), ctypes.c_long(out.stride(0)), ctypes.c_long(m), k, n, 0, _stream()), meta=dict(flops=2.0 * m * k * n))
     return out

@@ -669,6 +669,8 @@ class _LatticeLayerZ4(torch.autograd.Function):
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, _ = plan[cls]
             w = ws[p]
+            # (library GEMMs: a one-pass kernel of our own over all four classes was built and measured 7 % slower,
+            #  scratch/experiments/k_dgrad_nt.hip.inc)
             with gemm_timed('head_gemm_dgrad', m, 2 * co, c1 - c0):
                 if p == 0:                                      # class (0,0): initialises every tap block
                     torch.mm(g[p], w.t(), out=d_a[:, c0:c1])

@@ -282,12 +282,32 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 int pick_splits(long M, int Ka, int N) {
     const long tiles = (long)((Ka + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
-    // >= ~8 rounds of 256 workgroups, but the fp32 partial tiles (8 B of traffic per element and chunk) must stay
-    // small against the product itself: chunks of >= 12 000 rows.  From 8 chunks on an XCD keeps to its own chunks.
-    int s = 1;
-    while (s < 64 && tiles * s < 8 * 256 && M / (2 * s) >= 12000) s *= 2;
-    while (s < 1024 && M / s > 45000) s *= 2;            // a chunk stays inside the 4-GiB range of a buffer offset
-    return s;
+    // Cost model (microseconds, from the measurements in profiles/r05_wgrad_microbench.txt): rounds of 256 workgroups, each
+    // one chunk of rows at 0.37 us per 16-row slab + 8 us of fill / drain / epilogue, plus 8 B of workspace traffic per
+    // output element and chunk at ~3 TB/s.  Multiples of 8 chunks keep every XCD on its own rows (ties go to them; above
+    // 32 768 rows nothing else is considered);
+    // a chunk has to stay inside the 4-GiB range of a buffer offset (45 000 rows at the widest operands here).
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    int best = 0;
+    double best_us = 0.0;
+    for (int s : cand) {
+        if (M / s > 45000) continue;
+        if (s > 1 && M / s < 256) break;
+        if (M > 32768 && s % 8) continue;       // (long row ranges: only the XCD-local form has been measured)
+        const long rounds = (tiles * s + 255) / 256;
+        const double slabs = (double)((M + s - 1) / s + 15) / 16.0;
+        double us = (double)rounds * (slabs * 0.37 + 8.0) + (double)s * (double)Ka * (double)N * 8.0 / 3.0e6;
+        if (s % 8 == 0) us *= 0.97;
+        if (!best || us < best_us) {
+            best = s;
+            best_us = us;
+        }
+    }
+    if (!best) {
+        best = 64;
+        while (best < 1024 && M / best > 45000) best *= 2;
+    }
+    return best;
 }
 
 template <int KP, int PF>

@@ -31,19 +31,26 @@ class _RowLinear(torch.autograd.Function):
         g = g.contiguous()
         n, o = g.shape
         gx = g @ w if ctx.needs_input_grad[0] else None
+        gb = None
+        if ctx.has_bias:
+            # (a column sum, not a batched product with a stride-0 row of ones: a GEMM with M = 1 buys nothing over the
+            #  reduction kernel, and stride-0 batch operands fault inside some hipBLASLt solutions when TunableOp tries them)
+            gb = g.sum(0, dtype=torch.float32)
+        if g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and n >= 4096 and min(o, x.shape[1]) >= 192:
+            # rows on the contraction axis: the hand-written kernel of the head's weight gradients (csrc/ver_wgrad.hip;
+            # fp32 sums over all rows, row chunks chosen by its cost model); the 128-wide Linears of occ_branches would fill a
+            # quarter of its 256 x 256 tile and keep the batched form below
+            from ..hipops import wgrad_tn, wgrad_tn_supported
+            if wgrad_tn_supported(g, x):
+                return gx, wgrad_tn(g, x, out_dtype=torch.float32), gb
         s = n // _CHUNK
         main = s * _CHUNK
         gw = x.new_zeros((o, x.shape[1]), dtype=torch.float32)
-        gb = None
         if s:
             g3 = g[:main].view(s, _CHUNK, o)
             gw += torch.bmm(g3.transpose(1, 2), x[:main].view(s, _CHUNK, -1)).sum(0, dtype=torch.float32)
         if main < n:
             gw += (g[main:].t() @ x[main:]).float()
-        if ctx.has_bias:
-            # (a column sum, not a batched product with a stride-0 row of ones: a GEMM with M = 1 buys nothing over the
-            #  reduction kernel, and stride-0 batch operands fault inside some hipBLASLt solutions when TunableOp tries them)
-            gb = g.sum(0, dtype=torch.float32)
         return gx, gw, gb
 
 

@@ -1107,7 +1107,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // LayerNorm-forward steps of the row team skip the mean pass as the forward kernel does.
 // RSTD (with CENTERED): the forward kernel saved 1/std of both LayerNorms per row (`rstd` f32 [N, 2]): the two recomputed
 // LayerNorm-forward steps are elementwise -- no sum of squares, no cross-lane reduction in the middle of the slot's chain.
-template <bool CENTERED, bool RSTD = false>
+// ROWS4 (with RSTD): the row team's other lane mapping -- a lane owns 8 features of FOUR rows (a row = the 16 lanes of a DPP
+// row) instead of 32 features of one row (a row = a quad).  The LayerNorm parameters of a lane are then 8 + 8 floats per
+// layer and live in registers for the whole kernel (the quad mapping reads 16 x 16 bytes of them from LDS in every step:
+// ~20 % of a slot, all four row waves at once behind the barrier), the four rows are four independent dependency chains, the
+// row sums of the backward steps are 4-step DPP reductions; with the saved statistics the forward steps have none.
+template <bool CENTERED, bool RSTD = false, bool ROWS4 = false>
 __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict__ x, const __bf16* __restrict__ dlog,
                                                         const float* __restrict__ W2, const float* __restrict__ W3,
                                                         const float* __restrict__ vec, __bf16* __restrict__ dx,
@@ -1134,7 +1139,176 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
     const long nmine = blockIdx.x < nblk ? (nblk - 1 - blockIdx.x) / gridDim.x + 1 : 0;
     const long rounds = nmine / 2 + 1;
     __syncthreads();
-    if (team == 0) {
+    if constexpr (ROWS4) {
+        static_assert(!ROWS4 || (RSTD && CENTERED), "the 4-row mapping is built for the saved-statistics form");
+        if (team == 0) {
+            // =============================================================== ROW team, 4 rows x 8 features per lane
+            // lane l: row group l >> 4 (rows 16 q + 4 (l >> 4) + i), feature chunk fc = ((l & 15) + 12 (l >> 4)) & 15 -- the
+            // rotation makes the 16-byte tile reads of a wave conflict free at the 272-byte row stride
+            const int rgp = lane >> 4, fc = ((lane & 15) + 12 * rgp) & 15;
+            const int rbase = 16 * q + 4 * rgp;
+            f32x4 g1v[2], b1v[2], g2v[2], b2v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                g1v[h] = *reinterpret_cast<const f32x4*>(vec + kW + 8 * fc + 4 * h);
+                b1v[h] = *reinterpret_cast<const f32x4*>(vec + 2 * kW + 8 * fc + 4 * h);
+                g2v[h] = *reinterpret_cast<const f32x4*>(vec + 4 * kW + 8 * fc + 4 * h);
+                b2v[h] = *reinterpret_cast<const f32x4*>(vec + 5 * kW + 8 * fc + 4 * h);
+            }
+            struct Row4 {
+                bf16x8 xh1[4], xh2[4];
+                float rs1[4], rs2[4];
+                long r0;
+            };
+            Row4 sa, sb;
+            // ONE operand buffer for both blocks: A's step 0 (slot 0) consumes it and requests B's rows, B's step 0 (slot 3)
+            // consumes those and requests the next round's A rows -- three and five slots of flight
+            bf16x8 xn[4], dln;
+            bool okx[4], okd;               // rows past N (or of a block this workgroup does not have) read as zeros: no gradient
+            const int dlrow = lane >> 1, dlh = lane & 1;            // d(logits) staging: lanes 0-31 of a wave, 16 rows x 2 halves
+            // (unconditional loads from clamped rows: loads under a branch make the compiler wait for vmcnt(0) everywhere)
+            auto prefetch = [&](long blk, bool valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long rn = blk * kWsRows + rbase + i;
+                    okx[i] = valid && rn < N;
+                    xn[i] = *reinterpret_cast<const bf16x8*>(x + (okx[i] ? rn : N - 1) * kW + 8 * fc);
+                }
+                const long rd = blk * kWsRows + 16 * q + dlrow;
+                okd = valid && rd < N;
+                dln = *reinterpret_cast<const bf16x8*>(dlog + (okd ? rd : N - 1) * kC + 8 * dlh);
+            };
+            auto prefetch_rs = [&](Row4& st, long blk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long rn = blk * kWsRows + rbase + i;
+                    const float2 v = *reinterpret_cast<const float2*>(rstd + 2 * (rn < N ? rn : N - 1));
+                    st.rs1[i] = v.x;
+                    st.rs2[i] = v.y;
+                }
+            };
+            // LayerNorm forward of the lane's 4 x 8 values with the saved 1/std: n = v rs (kept as bf16), y = n gamma + beta
+            // from the ROUNDED n, h = relu(y) -> tile
+            auto ln_fwd4 = [&](const bf16x8 (&xin)[4], const float (&rs)[4], const f32x4 (&gm)[2], const f32x4 (&bt)[2],
+                               bf16x8 (&xh)[4], __bf16* dst) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[i] = pack8(unpack_half(xin[i], 0) * rs[i], unpack_half(xin[i], 1) * rs[i]);
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 raw = __builtin_bit_cast(u32x4, xh[i]);
+                    asm("" : "+v"(raw));                      // (see ln_relu_nat: keeps the pack + unpack from being seen through)
+                    xh[i] = __builtin_bit_cast(bf16x8, raw);
+                    const f32x4 y0 = unpack_half(xh[i], 0) * gm[0] + bt[0], y1 = unpack_half(xh[i], 1) * gm[1] + bt[1];
+                    *reinterpret_cast<bf16x8*>(dst + (rbase + i) * kNsLd + 8 * fc) = relu_packed(pack8(y0, y1));
+                }
+            };
+            // LayerNorm + ReLU backward: d = gradient w.r.t. the post-ReLU values (4 rows x 8), xh = kept normalised values.
+            // dz -> pz tile, n -> pn tile (the feature team forms their row sums), d(pre-LayerNorm) -> out (row pitch ldo)
+            auto ln_bwd4 = [&](const bf16x8 (&din)[4], const bf16x8 (&xh)[4], const float (&rs)[4], const f32x4 (&gm)[2],
+                               const f32x4 (&bt)[2], __bf16* pz, __bf16* pn, __bf16* out, long ldo, const bool (&ok)[4]) {
+                f32x4 dg[4][2];
+                float s1[4], s2[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 dz[2];
+                    s1[i] = s2[i] = 0.0f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 n = unpack_half(xh[i], h), d = unpack_half(din[i], h);
+                        const f32x4 y = n * gm[h] + bt[h];
+                        dz[h].x = y.x > 0.0f ? d.x : 0.0f;
+                        dz[h].y = y.y > 0.0f ? d.y : 0.0f;
+                        dz[h].z = y.z > 0.0f ? d.z : 0.0f;
+                        dz[h].w = y.w > 0.0f ? d.w : 0.0f;
+                        dg[i][h] = dz[h] * gm[h];
+                        s1[i] += (dg[i][h].x + dg[i][h].y) + (dg[i][h].z + dg[i][h].w);
+                        const f32x4 dn = dg[i][h] * n;
+                        s2[i] += (dn.x + dn.y) + (dn.z + dn.w);
+                    }
+                    *reinterpret_cast<bf16x8*>(pz + (rbase + i) * kNsLd + 8 * fc) = pack8(dz[0], dz[1]);
+                    *reinterpret_cast<bf16x8*>(pn + (rbase + i) * kNsLd + 8 * fc) = xh[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1[i] = group_sum<16>(s1[i]);
+                    s2[i] = group_sum<16>(s2[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m1 = s1[i] * (1.0f / kW), m2 = s2[i] * (1.0f / kW);
+                    const f32x4 a = (dg[i][0] - m1 - unpack_half(xh[i], 0) * m2) * rs[i];
+                    const f32x4 b = (dg[i][1] - m1 - unpack_half(xh[i], 1) * m2) * rs[i];
+                    if (ok[i]) *reinterpret_cast<bf16x8*>(out + (long)i * ldo) = pack8(a, b);
+                }
+            };
+            const bool all4[4] = {true, true, true, true};
+            auto r0 = [&](Row4& st, __bf16* T, __bf16* DL, long blk) {
+                st.r0 = blk * kWsRows + rbase;
+                bf16x8 xr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[i] = okx[i] ? xn[i] : z8;
+                if (lane < 32) {
+                    bf16x8 dl = okd ? dln : z8;
+                    if (gscale != 1.0f) {        // (wave-uniform) d(logits) arrives unscaled: ver_focal_loss_forward_grad
+                        const f32x4 lo = __builtin_convertvector(__builtin_shufflevector(dl, dl, 0, 1, 2, 3), f32x4) * gscale;
+                        const f32x4 hi = __builtin_convertvector(__builtin_shufflevector(dl, dl, 4, 5, 6, 7), f32x4) * gscale;
+                        dl = pack8(lo, hi);
+                    }
+                    *reinterpret_cast<bf16x8*>(DL + (16 * q + dlrow) * kNsDlLd + 8 * dlh) = dl;
+                }
+                const long nxt = blk + (long)gridDim.x;             // the block whose step 0 comes next (the other set)
+                prefetch(nxt, nxt < nblk);
+                ln_fwd4(xr, st.rs1, g1v, b1v, st.xh1, T);
+            };
+            auto r2 = [&](Row4& st, __bf16* T) {                                      // a2 (T1) -> LN2 + ReLU -> h2 (T2)
+                bf16x8 xr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(T + kWsTile + (rbase + i) * kNsLd + 8 * fc);
+                ln_fwd4(xr, st.rs2, g2v, b2v, st.xh2, T + 2 * kWsTile);
+            };
+            auto r4 = [&](Row4& st, __bf16* T) {                                      // d(h2) (T1) -> LN2 bwd -> d(a2) T3, d(z2) T2, n2 T1
+                bf16x8 d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const bf16x8*>(T + kWsTile + (rbase + i) * kNsLd + 8 * fc);
+                ln_bwd4(d, st.xh2, st.rs2, g2v, b2v, T + 2 * kWsTile, T + kWsTile, T + 3 * kWsTile + rbase * kNsLd + 8 * fc, kNsLd, all4);
+            };
+            auto r6 = [&](Row4& st, __bf16* T, long blk_next) {                       // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, n1 T3
+                bf16x8 d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const bf16x8*>(T4 + (rbase + i) * kNsLd + 8 * fc);
+                const bool ok[4] = {st.r0 < N, st.r0 + 1 < N, st.r0 + 2 < N, st.r0 + 3 < N};
+                ln_bwd4(d, st.xh1, st.rs1, g1v, b1v, T + 2 * kWsTile, T + 3 * kWsTile, dx + st.r0 * kW + 8 * fc, kW, ok);
+                prefetch_rs(st, blk_next < nblk ? blk_next : nblk - 1);
+            };
+            __bf16* const TA = tiles;
+            __bf16* const TB = tiles + 4 * kWsTile;
+            prefetch(blockIdx.x, blockIdx.x < nblk);
+            prefetch_rs(sa, blockIdx.x < nblk ? (long)blockIdx.x : nblk - 1);
+            prefetch_rs(sb, blockIdx.x + (long)gridDim.x < nblk ? blockIdx.x + (long)gridDim.x : nblk - 1);
+            for (long k = 0; k < rounds; ++k) {
+                const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
+                const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
+                if (va) r0(sa, TA, DLs, blk_a);
+                lds_barrier();
+                if (vp) r6(sb, TB, blk_b);
+                lds_barrier();
+                if (va) r2(sa, TA);
+                lds_barrier();
+                if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
+                lds_barrier();
+                if (va) r4(sa, TA);
+                lds_barrier();
+                if (vb) r2(sb, TB);
+                lds_barrier();
+                if (va) r6(sa, TA, blk_a + 2 * (long)gridDim.x);
+                lds_barrier();
+                if (vb) r4(sb, TB);
+                lds_barrier();
+            }
+            return;
+        }
+    }
+    if (!ROWS4 && team == 0) {
         // =================================================================== ROW team
         const float* sv_n = sv + 8 * g;
         const int myrow = 16 * q + c;
@@ -1289,6 +1463,12 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) dw2[ot][kt] = zero4;
     }
+    // The four product steps are SOFTWARE PIPELINED by hand (round 5): a lone wave per SIMD has nothing to switch to while an
+    // LDS read is in flight, and written as "read a fragment, use it" every group of 2-4 MFMAs waited for a full LDS round
+    // trip -- ~60 exposed round trips per block: the feature team ALONE took as long as the whole kernel (29.8 ms per 96.8 M
+    // rows with -DVER_WS_ABL_NOROW; the row team alone 24).  Every step now requests all the operands of a group of 6-16 MFMAs
+    // up front (and the next row tile's while the current one is multiplied); the scheduling barriers pin that order and keep
+    // the compiler from hoisting every read of a step to its top (128+ VGPRs).
     auto f1 = [&](__bf16* T) {                                            // a2 = W2 h1 + b2: T0 -> T1
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -1332,11 +1512,13 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
                 ada[ot] = ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
+#ifndef VER_WS_ABL_NOSUMS
                 sb2[ot] = mfma(ada[ot], ones, sb2[ot]);
                 const bf16x8 adz = ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
                 sbet2[ot] = mfma(adz, ones, sbet2[ot]);
                 // d(gamma2)[f] = sum_r d(z2)[r][f] n2[r][f] = the DIAGONAL of d(z2)^T n2 (T1 holds n2 itself)
                 sgam2[ot] = mfma(adz, ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam2[ot]);
+#endif
             }
 #pragma unroll
             for (int kt = 0; kt < 8; ++kt) {
@@ -1364,6 +1546,10 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
         }
     };
     auto f7 = [&](__bf16* T) {                                            // LN1 row sums from T2, T3
+#ifdef VER_WS_ABL_NOSUMS
+        (void)T;
+        return;
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -1460,8 +1646,14 @@ extern "C" int ver_occ_mlp_backward_fused_stats(const void* x, const void* grad_
     if (ws) {
         // (the saved statistics replace the recomputation only on centred rows; otherwise they are ignored)
         const bool use_rstd = rstd && (flags & VER_OCC_MLP_CENTERED);
-        auto kern = (flags & VER_OCC_MLP_CENTERED) ? (use_rstd ? k_occ_mlp_bwd_ws<true, true> : k_occ_mlp_bwd_ws<true, false>)
-                                                   : k_occ_mlp_bwd_ws<false, false>;
+        static const int rows4 = [] {
+            const char* ev = getenv("VER_OCC_MLP_ROWS4");       // 1 (default): 4 rows x 8 features per row-team lane; 0: quad mapping
+            return ev ? atoi(ev) : 1;
+        }();
+        auto kern = (flags & VER_OCC_MLP_CENTERED)
+                        ? (use_rstd ? (rows4 ? k_occ_mlp_bwd_ws<true, true, true> : k_occ_mlp_bwd_ws<true, true, false>)
+                                    : k_occ_mlp_bwd_ws<true, false, false>)
+                        : k_occ_mlp_bwd_ws<false, false, false>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: LDS attribute: %s", hipGetErrorString(e));
         const long nb = (N + kWsRows - 1) / kWsRows;

@@ -136,7 +136,9 @@ class FullTrainer(torch.nn.Module):
 
     def forward(self, feats, w2p, org, gt, gt_boxes, gt_labels):
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.autocast):
-            outs = self.head(feats, None, world2pixel=w2p, origin=org, occupancy_rows=True)
+            # (targets_for: the Hungarian cost matrices leave for the host right behind the decoder and are solved there
+            #  while the GPU runs the occupancy head; head.loss picks the assignment up)
+            outs = self.head(feats, None, world2pixel=w2p, origin=org, occupancy_rows=True, targets_for=(gt_boxes, gt_labels))
         outs = {k: (v.float() if torch.is_tensor(v) and k != 'occupancy_preds' else v) for k, v in outs.items()}
         losses = self.head.loss(gt_boxes, gt_labels, gt, outs)
         return sum(losses.values())

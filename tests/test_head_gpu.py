@@ -335,6 +335,39 @@ def test_full_multitask_head_forward_and_loss_on_gpu():
         assert k in grads and torch.isfinite(grads[k]).all() and float(grads[k].abs().max()) > 0, k
 
 
+def test_hungarian_targets_started_in_forward_give_the_same_losses():
+    """``head(..., targets_for=(gt_boxes, gt_labels))`` (round 5): the cls / reg branches run before the occupancy head and
+    the cost matrices of the Hungarian assignment (head:642-705) leave for the host right behind them, so that the host
+    solves them while the GPU is busy with the occupancy head; ``loss`` picks the result up.  Same outputs as the plain
+    forward (the branch order does not matter), the SAME loss dict to the last bit (identical cost matrices, identical
+    assignment), and ``loss`` falls back to computing the targets itself when it is handed other ground truth."""
+    syn = pkg('synthetic')
+    cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
+    head = _head(cfg, 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gts = [cases.detection_gt(seed=40 + i, num_gt=3 + i) for i in range(2)]
+    gb, gl = [T(b[:, :7]).to(DEV) for b, _ in gts], [T(l).to(DEV) for _, l in gts]
+    gt_occ = T(np.random.default_rng(9).integers(0, 17, size=(2, 504000))).to(DEV)
+    with torch.no_grad():
+        plain = head(feats, None, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV))
+        early = head(feats, None, world2pixel=T(w2p).to(DEV), origin=T(org).to(DEV), targets_for=(gb, gl))
+        assert 'pending_targets' not in plain and early['pending_targets']['event'] is not None
+        for k in ('all_cls_scores', 'all_bbox_preds', 'occupancy_preds', 'bev_embed'):
+            assert torch.equal(plain[k], early[k]), k
+        want = head.loss(gb, gl, gt_occ, plain)
+        got = head.loss(gb, gl, gt_occ, early)
+        assert sorted(want) == sorted(got)
+        for k in want:
+            assert float(want[k]) == float(got[k]), k
+        # other ground truth than the one the targets were started for: recomputed, not reused
+        other = [g.clone() for g in gb]
+        other[0][:, 0] += 1.0
+        redo = head.loss(other, gl, gt_occ, early)
+        ref = head.loss(other, gl, gt_occ, plain)
+        assert float(redo['loss_bbox']) == float(ref['loss_bbox']) != float(want['loss_bbox'])
+
+
 def test_full_multitask_training_steps_bf16():
     """Two optimiser steps of bench.py's `--workload vocc_full_train` arithmetic (bf16 autocast, occupancy loss in row
     order, Hungarian targets batched, grad clip, fused AdamW) on 3 viewpoints: finite and decreasing-or-equal is not

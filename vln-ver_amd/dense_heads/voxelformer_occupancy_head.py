@@ -371,7 +371,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         return x
 
     # ------------------------------------------------------------------ forward
-    def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, occupancy_rows=False, **kwargs):
+    def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, occupancy_rows=False, targets_for=None, **kwargs):
         """mlvl_feats [Ncam, bs, Nk, C] (the detector's (6,1,196,768)); img_metas: per-sample
         meta dicts (``sample_idx`` -> camera files, or inline ``world2pixel``/``origin``).
         Extra kwargs (``world2pixel``, ``origin`` device tensors) bypass the metas.
@@ -403,14 +403,6 @@ class VoxelFormerOccupancyHead(BaseModule):
             reg_branches=self.reg_branches if self.with_box_refine else None,
             cls_branches=None, **common)
         # bev_embed [Nq,bs,C] is a permuted view of the contiguous [bs,Nq,C] encoder output
-        if self.only_det:
-            occupancy = None
-        elif self.add_layout:
-            # head:458-474: the layout branch of the reference never upsamples -- plain [bs,Z,H,W,C] view,
-            # occ_proj, occ_branches on the coarse grid (X*Y = bev_h*bev_w cells, occ_zdim layers)
-            occupancy = self._only_occ(bev_embed.permute(1, 0, 2))
-        else:
-            occupancy = self.occupancy_from_volume(bev_embed.permute(1, 0, 2), rows_only=occupancy_rows)
         hs = hs.permute(0, 2, 1, 3)
         classes, coords, layouts = [], [], []
         for lvl in range(hs.shape[0]):
@@ -436,12 +428,32 @@ class VoxelFormerOccupancyHead(BaseModule):
                 layouts.append(torch.cat([lxy[..., 0:1] * (lr[3] - lr[0]) + lr[0],
                                           lxy[..., 1:2] * (lr[4] - lr[1]) + lr[1], lay[..., 2:4],
                                           lz * (lr[5] - lr[2]) + lr[2], lay[..., 5:]], -1))
+        all_cls, all_box = torch.stack(classes), torch.stack(coords)
+        # (the branches above only read the decoder states: they run BEFORE the occupancy head -- the reference runs them
+        #  after it, head:584-613, same results -- so that a training step can start its Hungarian assignment early:
+        #  ``targets_for=(gt_bboxes_list, gt_labels_list)`` queues the cost matrices and their device -> host copy here, the
+        #  host solves them while the GPU is busy with the occupancy head below, and ``loss`` picks the result up)
+        pending = None
+        if targets_for is not None and not self.add_layout and not torch.cuda.is_current_stream_capturing():
+            pending = self._targets_begin(all_cls, all_box, *self._prepare_gts(targets_for[0], targets_for[1], all_box.device))
+            if pending is not None:
+                pending['key'] = tuple(id(g) for g in targets_for[0])      # (the caller's box tensors: loss() checks them)
+        if self.only_det:
+            occupancy = None
+        elif self.add_layout:
+            # head:458-474: the layout branch of the reference never upsamples -- plain [bs,Z,H,W,C] view,
+            # occ_proj, occ_branches on the coarse grid (X*Y = bev_h*bev_w cells, occ_zdim layers)
+            occupancy = self._only_occ(bev_embed.permute(1, 0, 2))
+        else:
+            occupancy = self.occupancy_from_volume(bev_embed.permute(1, 0, 2), rows_only=occupancy_rows)
         self._dump_volumes(bev_embed.permute(1, 0, 2), img_metas)
-        return dict(bev_embed=bev_embed, all_cls_scores=torch.stack(classes),
-                    all_bbox_preds=torch.stack(coords),
-                    all_layout_preds=torch.stack(layouts) if self.add_layout else None,
-                    occupancy_preds=occupancy, flow_preds=None, enc_cls_scores=None,
-                    enc_bbox_preds=None, enc_occupancy_preds=None)
+        out = dict(bev_embed=bev_embed, all_cls_scores=all_cls, all_bbox_preds=all_box,
+                   all_layout_preds=torch.stack(layouts) if self.add_layout else None,
+                   occupancy_preds=occupancy, flow_preds=None, enc_cls_scores=None,
+                   enc_bbox_preds=None, enc_occupancy_preds=None)
+        if pending is not None:
+            out['pending_targets'] = pending
+        return out
 
     def _only_occ(self, voxel_embed):
         """head:338-350: the only_occ branch never upsamples (plain [bs,Z,H,W,C] view)."""
@@ -530,16 +542,14 @@ class VoxelFormerOccupancyHead(BaseModule):
         gt_occupancy: int64 [bs, voxel_num] with ``occupancy_classes`` = empty."""
         all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
         occ = preds_dicts['occupancy_preds']
-        padded = []
-        for g in gt_bboxes_list:                       # pad velocity columns (head:1316-1317)
-            g = g.to(all_box.device)
-            if g.shape[-1] < 9:
-                g = torch.cat([g, g.new_zeros(g.shape[0], 9 - g.shape[-1])], dim=1)
-            padded.append(g)
-        labels = [torch.as_tensor(x, device=all_box.device).long() for x in gt_labels_list]
+        padded, labels = self._prepare_gts(gt_bboxes_list, gt_labels_list, all_box.device)
         nl = len(all_cls)
         losses = {}
-        targets = self._batched_targets(all_cls, all_box, padded, labels)
+        pending = preds_dicts.get('pending_targets')
+        if pending is not None and pending.get('key') == tuple(id(g) for g in gt_bboxes_list):
+            targets = self._targets_finish(pending)         # started in forward(), solved under the occupancy head
+        else:
+            targets = self._batched_targets(all_cls, all_box, padded, labels)
         for lvl in range(nl):
             last = lvl == nl - 1
             if targets is None:
@@ -555,6 +565,18 @@ class VoxelFormerOccupancyHead(BaseModule):
                 losses['d%d.loss_cls' % lvl] = lc
                 losses['d%d.loss_bbox' % lvl] = lb
         return losses
+
+    @staticmethod
+    def _prepare_gts(gt_bboxes_list, gt_labels_list, device):
+        """Boxes padded with zero velocity columns (head:1316-1317), labels as int64 tensors, on ``device``."""
+        padded = []
+        for g in gt_bboxes_list:
+            g = g.to(device)
+            if g.shape[-1] < 9:
+                g = torch.cat([g, g.new_zeros(g.shape[0], 9 - g.shape[-1])], dim=1)
+            padded.append(g)
+        labels = [torch.as_tensor(x, device=device).long() for x in gt_labels_list]
+        return padded, labels
 
     def occupancy_targets(self, occ_gts, device=None):
         """The dataset's sparse occupancy annotation -> the dense target ``loss`` takes (head:1322-1326, :1404-1408):
@@ -699,6 +721,11 @@ class VoxelFormerOccupancyHead(BaseModule):
         copied to the host in one piece, solved there (scipy, as in the reference) and the matched
         indices come back in one piece.  Returns (labels [L,bs,Nq], bbox_targets [L,bs,Nq,9],
         positive mask [L,bs,Nq], positives per layer) or None when there is nothing to batch."""
+        return self._targets_finish(self._targets_begin(all_cls, all_box, gt_boxes, gt_labels))
+
+    def _targets_begin(self, all_cls, all_box, gt_boxes, gt_labels):
+        """First half of ``_batched_targets``: cost matrices on the device and their ASYNCHRONOUS copy into pinned host
+        memory (an event marks its end).  Nothing here waits for the device."""
         from .assigner import BBox3DL1Cost, FocalLossCost, linear_sum_assignment
         a = self.assigner
         if (a is None or linear_sum_assignment is None or not isinstance(a.cls_cost, FocalLossCost)
@@ -726,8 +753,29 @@ class VoxelFormerOccupancyHead(BaseModule):
             # padded gts hold log(0): keep them finite, their columns are never handed to the solver
             gt_norm = torch.nan_to_num(gt_norm, nan=0.0, posinf=0.0, neginf=0.0)
             reg_cost = (all_box.float()[..., None, :8] - gt_norm[None, :, None]).abs().sum(-1) * a.reg_cost.weight
-            cost = (cls_cost + reg_cost).cpu().numpy()
+            cost = cls_cost + reg_cost
+            event = None
+            if cost.is_cuda:
+                host = torch.empty(cost.shape, dtype=cost.dtype, pin_memory=True)
+                host.copy_(cost, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+            else:
+                host = cost
+        return dict(host=host, event=event, counts=counts, gt_pad=gt_pad, lab_pad=lab_pad, shape=(nl, bs, nq, gmax))
+
+    def _targets_finish(self, ctx):
+        """Second half: wait for the copy (only), solve the assignments on the host, build the targets on the device."""
+        if ctx is None:
+            return None
+        from .assigner import linear_sum_assignment
         import numpy as np
+        if ctx['event'] is not None:
+            ctx['event'].synchronize()
+        cost = ctx['host'].numpy()
+        nl, bs, nq, gmax = ctx['shape']
+        counts, gt_pad, lab_pad = ctx['counts'], ctx['gt_pad'], ctx['lab_pad']
+        dev = gt_pad.device
         idx = np.full((nl, bs, nq), -1, dtype=np.int64)
         for lvl in range(nl):
             for i in range(bs):

@@ -83,6 +83,61 @@ def test_argument_validation_of_the_head_entry_points():
     assert rc == -2
 
 
+def test_argument_validation_of_the_gemm_entry_points():
+    """ver_wgrad_tn / ver_gemm_nn / the *_stats MLP entries (ABI 24): sizes, alignment, row pitches, workspace size and the
+    split arithmetic are checked on the host before anything is launched; the split chooser and the workspace size are
+    pure host functions."""
+    hip = pkg('hipops')
+    lib = hip.lib()
+    lib.ver_wgrad_tn_workspace.restype = ctypes.c_long
+    L = ctypes.c_long
+    buf = (ctypes.c_float * 64)()
+    # the chunk count of the shapes of the 192-viewpoint step (cost model of csrc/ver_wgrad.hip) and its bounds
+    assert lib.ver_wgrad_tn_splits(L(345600), 14304, 1536) == 8          # one chunk per XCD
+    assert lib.ver_wgrad_tn_splits(L(1800), 14304, 1536) == 1            # one viewpoint: no fp32 partials
+    assert lib.ver_wgrad_tn_splits(L(0), 8, 8) == 1
+    for m, ka, n in ((345600, 14304, 1536), (552960, 4480, 832), (14400, 14304, 1536), (96768000, 128, 128), (17, 40, 8)):
+        s = lib.ver_wgrad_tn_splits(L(m), ka, n)
+        assert 1 <= s <= 65536 and m / s <= 45000 + 1, (m, ka, n, s)  # a chunk stays inside a 32-bit buffer offset
+        assert lib.ver_wgrad_tn_workspace(L(m), ka, n, 0) == s * ka * n * 4
+    assert lib.ver_wgrad_tn_workspace(L(1000), 256, 128, 3) == 3 * 256 * 128 * 4
+    args = lambda a, g, out, ws, m=64, ka=32, n=32, lda=32, ldg=32, ldo=32, dt=1, sp=0, fl=0, wsb=1 << 20: (
+        a, L(lda), g, L(ldg), L(m), ka, n, out, L(ldo), dt, sp, fl, ws, L(wsb), None)
+    rc = lib.ver_wgrad_tn(*args(None, None, buf, buf))
+    assert rc == -1 and b'null' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, ka=0))
+    assert rc == -1 and b'bad sizes' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, lda=16))
+    assert rc == -1 and b'pitch' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, lda=36, ldg=36))
+    assert rc == -2 and b'multiples of 8' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, n=30))
+    assert rc == -2 and b'multiples of 4' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, dt=7))
+    assert rc == -1 and b'out_dtype' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, wsb=16))
+    assert rc == -1 and b'workspace' in lib.ver_last_error()
+    rc = lib.ver_wgrad_tn(*args(buf, buf, buf, buf, m=1 << 40, lda=40000, ka=40000, sp=1, wsb=1 << 40))
+    assert rc == -2 and b'4-GiB' in lib.ver_last_error()                  # one chunk of 2^40 rows
+    g = lambda a, w, c, m=64, k=64, n=32, lda=64, ldw=32, ldc=32, fl=0: (a, L(lda), w, L(ldw), None, c, L(ldc), L(m), k, n, fl, None)
+    assert lib.ver_gemm_nn(*g(None, None, None, m=0)) == 0
+    rc = lib.ver_gemm_nn(*g(None, buf, buf))
+    assert rc == -1 and b'null' in lib.ver_last_error()
+    rc = lib.ver_gemm_nn(*g(buf, buf, buf, k=48, lda=48))
+    assert rc == -2 and b'multiple of 32' in lib.ver_last_error()
+    rc = lib.ver_gemm_nn(*g(buf, buf, buf, ldw=16))
+    assert rc == -1 and b'pitch' in lib.ver_last_error()
+    rc = lib.ver_gemm_nn(*g(buf, buf, buf, fl=1))
+    assert rc == -1 and b'flags' in lib.ver_last_error()
+    # the MLP entries with the saved statistics: the rstd pointer must be 8-byte aligned and N < 2^28
+    off = ctypes.cast(ctypes.addressof(buf) + 4, ctypes.c_void_p)
+    rc = lib.ver_occ_mlp_forward_stats(buf, buf, buf, buf, off, L(4), 128, 16, ctypes.c_float(1e-5), 2, None)
+    assert rc == -2 and b'rstd' in lib.ver_last_error()
+    assert lib.ver_occ_mlp_forward_stats(None, buf, buf, None, None, L(0), 128, 16, ctypes.c_float(1e-5), 2, None) == 0
+    rc = lib.ver_occ_mlp_backward_fused_stats(None, None, None, buf, buf, None, None, buf, L(4), 128, 16, ctypes.c_float(1e-5), None, 2, None)
+    assert rc == -1 and b'null' in lib.ver_last_error()
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
 def test_ops_refuse_cpu_tensors():
     hip = pkg('hipops')
@@ -122,7 +177,7 @@ def test_host_launchers_under_address_sanitizer():
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert 'AddressSanitizer' not in proc.stderr and 'AddressSanitizer' not in proc.stdout, proc.stderr[-3000:]
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
-    assert '4 passed' in proc.stdout, proc.stdout[-500:]
+    assert '5 passed' in proc.stdout, proc.stdout[-500:]
 
 
 def test_magic_division_of_the_gather_launcher_is_exact_in_its_range():

@@ -305,7 +305,7 @@ int pick_splits(long M, int Ka, int N) {
     }
     if (!best) {
         best = 64;
-        while (best < 1024 && M / best > 45000) best *= 2;
+        while (best < 65536 && M / best > 45000) best *= 2;
     }
     return best;
 }
@@ -341,7 +341,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
     VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
                 "ver_wgrad_tn: N and the output pitch must be multiples of 4");
     const int S = splits > 0 ? splits : pick_splits(M, Ka, N);
-    VER_REQUIRE(S <= 1024, VER_EINVAL, "ver_wgrad_tn: %d row chunks", S);
+    VER_REQUIRE(S <= 65536, VER_EINVAL, "ver_wgrad_tn: %d row chunks", S);
     const long Mc = ((M + S - 1) / S + 2 * kSlabRows - 1) / (2 * kSlabRows) * (2 * kSlabRows);  // rows per chunk, whole phases
     VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0xFFFFFFFFL, VER_EUNSUPPORTED,
                 "ver_wgrad_tn: a row chunk exceeds the 4-GiB range of a buffer offset (more splits)");

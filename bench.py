@@ -69,10 +69,12 @@ def parse():
     ap.add_argument('--graph-max-batch', type=int, default=4,
                     help='config.latency records of the full multi-task workload up to this many viewpoints per step replay '
                          'the head as hipGraphs (one rank only; 0: always eager)')
-    ap.add_argument('--graph-full-train', type=int, default=1,
-                    help='config.full_train sub-record (64 viewpoints per step, one rank): 1 = the head\'s forward and backward '
-                         'are replayed as two hipGraphs (vln-ver_amd/graphs.py; the eager step is bound by the host\'s launch '
-                         'rate: ~4 000 launches, 127 ms of GPU work in a 150-ms step), 0 = eager')
+    ap.add_argument('--graph-full-train', type=int, default=0,
+                    help='config.full_train sub-record (64 viewpoints per step, one rank): 0 (default) = the eager step, whose '
+                         'Hungarian assignment is started in forward() and solved on the host under the occupancy head '
+                         '(138-139 ms); 1 = the head\'s forward and backward replayed as two hipGraphs (vln-ver_amd/graphs.py; '
+                         '144-148 ms: the replay removes launch gaps the 64-viewpoint step does not have, and the assignment '
+                         'waits for the whole forward graph)')
     ap.add_argument('--host-fed-steps', type=int, default=3,
                     help='steps of the config.host_fed record: the same step with the features handed over in (pinned) HOST '
                          'memory, as the detector does, the PCIe copy inside the timed region; 0: none')

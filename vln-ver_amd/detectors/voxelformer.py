@@ -137,8 +137,14 @@ class VoxelFormer(BaseModule):
         head = self.pts_bbox_head
         lowp = self.autocast_dtype is not None and img_feats.is_cuda
         rows = self.occupancy_rows and not (self.only_det or self.only_occ or self.add_layout)
+        # the default multi-task mode hands the head its boxes with the features: the Hungarian cost matrices then leave for the
+        # host right behind the decoder and are solved there while the GPU runs the occupancy head (head.forward, targets_for)
+        boxes = None
+        if not (self.only_det or self.only_occ or self.add_layout):
+            boxes = [head._boxes_as_tensor(b, img_feats.device) for b in gt_bboxes_3d]
         with torch.autocast('cuda', dtype=self.autocast_dtype or torch.bfloat16, enabled=lowp):
-            outs = head(img_feats, img_metas, prev_bev, occupancy_rows=rows)
+            outs = head(img_feats, img_metas, prev_bev, occupancy_rows=rows,
+                        targets_for=(boxes, gt_labels_3d) if boxes is not None and img_feats.is_cuda else None)
         if lowp:
             outs = {k: (v.float() if torch.is_tensor(v) and k != 'occupancy_preds' else v) for k, v in outs.items()}
         if self.only_det:
@@ -148,7 +154,6 @@ class VoxelFormer(BaseModule):
             return head.loss_only_occupancy(gt_bboxes_3d, gt_labels_3d, gt_occupancy, outs)
         if self.add_layout:
             return head.loss_addlayout(gt_bboxes_3d, gt_labels_3d, gt_layout_3d, gt_occupancy, outs)
-        boxes = [head._boxes_as_tensor(b, img_feats.device) for b in gt_bboxes_3d]
         return head.loss(boxes, gt_labels_3d, gt_occupancy, outs)
 
     def forward_train(self, img_metas=None, **kwargs):

@@ -1298,6 +1298,25 @@ def test_wgrad_tn_equals_the_fp32_product(M, Ka, lda, c0, N, ldg, splits):
     assert rel_l2(up.rows_tn(G, A, out_dtype=torch.float32), want.t()) < 1e-4
 
 
+def test_wgrad_tn_row_chunk_beyond_2_gib():
+    """One row chunk whose byte range exceeds 2^31 (40 000 rows of a 64-KiB row pitch, one chunk): the running slab offset
+    of the LDS-DMA descriptors is an UNSIGNED 32-bit byte count (the launcher admits chunks up to 4 GiB)."""
+    hip = pkg('hipops')
+    M, lda, Ka, N = 40000, 32768, 256, 256
+    torch.manual_seed(5)
+    Af = torch.empty(M, lda, device=DEV, dtype=torch.bfloat16)
+    Af[:, 512:768] = torch.randn(M, Ka, device=DEV).to(torch.bfloat16)
+    G = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    A = Af[:, 512:768]
+    want = A.float().t() @ G.float()
+    got = hip.wgrad_tn(A, G, out_dtype=torch.float32, splits=1)
+    assert float((got - want).abs().max()) < 1e-4 * float(want.abs().max())
+    # the last rows (offsets above 2^31) carry weight: zero them and the product changes
+    G2 = G.clone()
+    G2[-4096:] = 0
+    assert float((hip.wgrad_tn(A, G2, out_dtype=torch.float32, splits=1) - got).abs().max()) > 1.0
+
+
 def test_wgrad_tn_refuses_what_it_cannot_take():
     hip = pkg('hipops')
     a = torch.randn(64, 32, device=DEV).to(torch.bfloat16)

@@ -89,17 +89,17 @@ __device__ __forceinline__ void read_slab(const WgradLane& c, i32x2 (&al)[4], i3
 // One phase = KP slabs (ring slots PS*KP ..): fragments -> registers, LDS-DMA of the slabs PF ahead, 8 KP MFMAs.
 template <int PS, int KP, int PF>
 __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const WgradLane& c, __amdgpu_buffer_rsrc_t ra,
-                                      __amdgpu_buffer_rsrc_t rg, int& soA, int& soG) {
+                                      __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG) {
     i32x2 al[KP][4], ah[KP][4], bl[KP][2], bh[KP][2];
     read_slab<PS * KP>(c, al[0], ah[0], bl[0], bh[0]);
     if constexpr (KP == 2) read_slab<PS * KP + 1>(c, al[KP - 1], ah[KP - 1], bl[KP - 1], bh[KP - 1]);
 #pragma unroll
     for (int u = 0; u < KP; ++u) {
         const int ds = (PS * KP + u + PF) % kRing;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, soA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + ds * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, soG, 0, 0);
-        soA += c.stepA;
-        soG += c.stepG;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + ds * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
+        soA += (unsigned)c.stepA;
+        soG += (unsigned)c.stepG;
     }
     // this wave's pieces of the NEXT phase's slabs have landed (everything younger stays in flight)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - KP)) : "memory");
@@ -142,7 +142,7 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Wgra
 
 template <int PS, int KP, int PF>
 __device__ __forceinline__ void phases_from(int left, char* lds, f32x16 (&acc)[4][2], const WgradLane& c,
-                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, int& soA, int& soG) {
+                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG) {
     if constexpr (PS < kRing / KP) {
         if (left > PS * KP) {
             phase<PS, KP, PF>(lds, acc, c, ra, rg, soA, soG);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     c.stepA = (int)(kSlabRows * p.lda * 2);
     c.stepG = (int)(kSlabRows * p.ldg * 2);
     c.dmaoff = wave * 1024;
-    int soA = 0, soG = 0;
+    unsigned soA = 0, soG = 0;          // (byte offsets of the running slab: up to 4 GiB, unsigned arithmetic)
 
     // transposing fragment reads: 16-lane group q = (k half, column half), lane c of it addresses row c >> 2,
     // columns 4 (c & 3) .. + 3 and receives column c of the group's 4 x 16 block
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     // prologue: slabs 0 .. PF-1 in flight, the first phase's slabs landed
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, soA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, soG, 0, 0);
-        soA += c.stepA;
-        soG += c.stepG;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
+        soA += (unsigned)c.stepA;
+        soG += (unsigned)c.stepG;
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PF - KP)) : "memory");
     __builtin_amdgcn_s_barrier();

@@ -14,6 +14,7 @@ a = ap.parse_args()
 args = argparse.Namespace(workload="vocc_c2f_train", dtype="bf16", micro=a.micro, batch=a.batch, config=None)
 dev = torch.device('cuda', 0)
 hip = importlib.import_module('vln-ver_amd.hipops'); hip.lib()
+importlib.import_module('vln-ver_amd.tuning').enable_tuned_gemms()
 pkg, syn, head, n_train = bench.build_model(args, dev)
 model = bench.LiftTrainer(head, a.micro, 'bf16').to(dev).train()
 params = [p for p in model.parameters() if p.requires_grad]
@@ -30,11 +31,14 @@ def step():
 
 for _ in range(2): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
 ka = prof.key_averages(group_by_input_shape=True)
 with open(a.out, 'w') as f:
     f.write(ka.table(sort_by='self_device_time_total', row_limit=400, max_name_column_width=60, max_shapes_column_width=110))
     f.write('\n\n==== kernels ====\n')
     f.write(prof.key_averages().table(sort_by='self_device_time_total', row_limit=60, max_name_column_width=110))
+f = open(a.out.replace('.txt', '_stack.txt'), 'w')
+f.write(prof.key_averages(group_by_stack_n=8).table(sort_by='self_device_time_total', row_limit=150, max_name_column_width=50, max_src_column_width=140))
+f.close()
 print('ok')

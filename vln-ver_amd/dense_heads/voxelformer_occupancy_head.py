@@ -41,6 +41,14 @@ def _mean_over_ranks(value, like):
     return float(reduce_mean(like.new_tensor([float(value)])))
 
 
+def _to_device_async(t, dev):
+    """Host tensor -> ``dev`` without making the host wait for the stream (pinned staging + asynchronous copy); the
+    plain ``.to(dev)`` of a pageable tensor blocks until every launch queued before it has run."""
+    if torch.device(dev).type != 'cuda':
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def bias_init_with_prob(prior_prob):
     return float(-math.log((1 - prior_prob) / prior_prob))
 
@@ -398,46 +406,15 @@ class VoxelFormerOccupancyHead(BaseModule):
                         flow_preds=None, enc_cls_scores=None, enc_bbox_preds=None,
                         enc_occupancy_preds=None)
         object_query_embeds = self.query_embedding.weight.to(dtype)
-        bev_embed, hs, init_reference, inter_references = self.transformer(
-            mlvl_feats, voxel_queries, object_query_embeds, self.bev_z, self.bev_h, self.bev_w,
-            reg_branches=self.reg_branches if self.with_box_refine else None,
-            cls_branches=None, **common)
-        # bev_embed [Nq,bs,C] is a permuted view of the contiguous [bs,Nq,C] encoder output
-        hs = hs.permute(0, 2, 1, 3)
-        classes, coords, layouts = [], [], []
-        for lvl in range(hs.shape[0]):
-            reference = init_reference if lvl == 0 else inter_references[lvl - 1]
-            reference = inverse_sigmoid(reference)
-            cls = self.cls_branches[lvl](hs[lvl])
-            tmp = self.reg_branches[lvl](hs[lvl])
-            assert reference.shape[-1] == 3
-            xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid()
-            zc = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid()
-            x = xy[..., 0:1] * (self.pc_range[3] - self.pc_range[0]) + self.pc_range[0]
-            y = xy[..., 1:2] * (self.pc_range[4] - self.pc_range[1]) + self.pc_range[1]
-            z = zc * (self.pc_range[5] - self.pc_range[2]) + self.pc_range[2]
-            coords.append(torch.cat([x, y, tmp[..., 2:4], z, tmp[..., 5:]], -1))
-            classes.append(cls)
-            if self.add_layout:
-                # head:501-513: the room layout is regressed from the SAME decoder states by its own branch and
-                # de-normalised into the (fixed, 100 m) layout range
-                lay = self.layout_branches[lvl](hs[lvl])
-                lr = self.layout_range
-                lxy = (lay[..., 0:2] + reference[..., 0:2]).sigmoid()
-                lz = (lay[..., 4:5] + reference[..., 2:3]).sigmoid()
-                layouts.append(torch.cat([lxy[..., 0:1] * (lr[3] - lr[0]) + lr[0],
-                                          lxy[..., 1:2] * (lr[4] - lr[1]) + lr[1], lay[..., 2:4],
-                                          lz * (lr[5] - lr[2]) + lr[2], lay[..., 5:]], -1))
-        all_cls, all_box = torch.stack(classes), torch.stack(coords)
-        # (the branches above only read the decoder states: they run BEFORE the occupancy head -- the reference runs them
-        #  after it, head:584-613, same results -- so that a training step can start its Hungarian assignment early:
-        #  ``targets_for=(gt_bboxes_list, gt_labels_list)`` queues the cost matrices and their device -> host copy here, the
-        #  host solves them while the GPU is busy with the occupancy head below, and ``loss`` picks the result up)
-        pending = None
-        if targets_for is not None and not self.add_layout and not torch.cuda.is_current_stream_capturing():
-            pending = self._targets_begin(all_cls, all_box, *self._prepare_gts(targets_for[0], targets_for[1], all_box.device))
-            if pending is not None:
-                pending['key'] = tuple(id(g) for g in targets_for[0])      # (the caller's box tensors: loss() checks them)
+        voxel_embed = self.transformer.get_voxel_features(
+            mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
+        # (the detection half -- decoder, cls / reg branches, Hungarian cost matrices -- only reads the encoder output, and so
+        #  does the occupancy head.  Running the former on a second HIP stream was measured in round 5: its ~1 500 small
+        #  launches per direction do execute beside the occupancy head's GEMMs, but those fill every CU, the small kernels
+        #  stretch 2x and the 64-viewpoint step gains 0.7 % (480 -> 483 viewpoints/s); one traced run with the second
+        #  stream never finished.  One stream.)
+        out = self._detection_half(voxel_embed, object_query_embeds, targets_for, img_metas, kwargs)
+        bev_embed, all_cls, all_box, layouts, pending = out
         if self.only_det:
             occupancy = None
         elif self.add_layout:
@@ -454,6 +431,53 @@ class VoxelFormerOccupancyHead(BaseModule):
         if pending is not None:
             out['pending_targets'] = pending
         return out
+
+    def _detection_half(self, voxel_embed, object_query_embeds, targets_for, img_metas, kwargs):
+        """Decoder + cls / reg (/ layout) branches on the encoder output [bs,Nq,C] (head:584-613), and the start of the
+        Hungarian assignment when ``targets_for`` is given.  -> (bev_embed [Nq,bs,C], all_cls, all_box, layouts, pending)."""
+        bev_embed, hs, init_reference, inter_references = self.transformer.decode(
+            voxel_embed, object_query_embeds, self.bev_z, self.bev_h, self.bev_w,
+            reg_branches=self.reg_branches if self.with_box_refine else None,
+            cls_branches=None, img_metas=img_metas, **kwargs)
+        # bev_embed [Nq,bs,C] is a permuted view of the contiguous [bs,Nq,C] encoder output
+        hs = hs.permute(0, 2, 1, 3)
+        # head:584-613 evaluates the branches layer by layer and de-normalises each layer's boxes on its own; the branch
+        # outputs of all L layers are stacked here and de-normalised in one pass (the same elementwise arithmetic on
+        # [L,bs,Nq,.] instead of L times on [bs,Nq,.]: a sixth of the launches, forward and backward)
+        nl = hs.shape[0]
+        all_cls = torch.stack([self.cls_branches[lvl](hs[lvl]) for lvl in range(nl)])
+        tmp = torch.stack([self.reg_branches[lvl](hs[lvl]) for lvl in range(nl)])
+        reference = init_reference[None] if nl == 1 else torch.cat([init_reference[None], inter_references[:nl - 1]])
+        assert reference.shape[-1] == 3
+        reference = inverse_sigmoid(reference)
+        all_box = self._denormalize(tmp, reference, self.pc_range)
+        layouts = []
+        if self.add_layout:
+            # head:501-513: the room layout is regressed from the SAME decoder states by its own branch and
+            # de-normalised into the (fixed, 100 m) layout range
+            lay = torch.stack([self.layout_branches[lvl](hs[lvl]) for lvl in range(nl)])
+            layouts = list(self._denormalize(lay, reference, self.layout_range).unbind(0))
+        # (the branches above only read the decoder states: they run BEFORE the occupancy head -- the reference runs them
+        #  after it, head:584-613, same results -- so that a training step can start its Hungarian assignment early:
+        #  ``targets_for=(gt_bboxes_list, gt_labels_list)`` queues the cost matrices and their device -> host copy here, the
+        #  host solves them while the GPU is busy with the occupancy head below, and ``loss`` picks the result up)
+        pending = None
+        if targets_for is not None and not self.add_layout and not torch.cuda.is_current_stream_capturing():
+            pending = self._targets_begin(all_cls, all_box, list(targets_for[0]), list(targets_for[1]))
+            if pending is not None:
+                pending['key'] = tuple(id(g) for g in targets_for[0])      # (the caller's box tensors: loss() checks them)
+        return bev_embed, all_cls, all_box, layouts, pending
+
+    @staticmethod
+    def _denormalize(tmp, reference, rng):
+        """Branch output [..., 10] + inverse-sigmoid reference [..., 3] -> box code with metric centre (head:590-606):
+        (cx, cy) and cz through a sigmoid into ``rng`` = (x0, y0, z0, x1, y1, z1), the other entries as they are."""
+        xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid()
+        zc = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid()
+        x = xy[..., 0:1] * (rng[3] - rng[0]) + rng[0]
+        y = xy[..., 1:2] * (rng[4] - rng[1]) + rng[1]
+        z = zc * (rng[5] - rng[2]) + rng[2]
+        return torch.cat([x, y, tmp[..., 2:4], z, tmp[..., 5:]], -1)
 
     def _only_occ(self, voxel_embed):
         """head:338-350: the only_occ branch never upsamples (plain [bs,Z,H,W,C] view)."""
@@ -542,22 +566,27 @@ class VoxelFormerOccupancyHead(BaseModule):
         gt_occupancy: int64 [bs, voxel_num] with ``occupancy_classes`` = empty."""
         all_cls, all_box = preds_dicts['all_cls_scores'], preds_dicts['all_bbox_preds']
         occ = preds_dicts['occupancy_preds']
-        padded, labels = self._prepare_gts(gt_bboxes_list, gt_labels_list, all_box.device)
         nl = len(all_cls)
         losses = {}
         pending = preds_dicts.get('pending_targets')
+        padded = labels = None
         if pending is not None and pending.get('key') == tuple(id(g) for g in gt_bboxes_list):
             targets = self._targets_finish(pending)         # started in forward(), solved under the occupancy head
         else:
+            padded, labels = self._prepare_gts(gt_bboxes_list, gt_labels_list, all_box.device)
             targets = self._batched_targets(all_cls, all_box, padded, labels)
+        if targets is not None:
+            # every decoder layer's classification / box terms in one pass over [L * bs * Nq] rows
+            all_lc, all_lb = self._losses_from_targets(all_cls, all_box, *targets)
+        elif padded is None:
+            padded, labels = self._prepare_gts(gt_bboxes_list, gt_labels_list, all_box.device)
         for lvl in range(nl):
             last = lvl == nl - 1
             if targets is None:
                 lc, lb, lo = self.loss_single(all_cls[lvl], all_box[lvl], occ if last else None, padded, labels,
                                               gt_occupancy if last else None)
             else:
-                lc, lb = self._loss_from_targets(all_cls[lvl], all_box[lvl], *[t[lvl] for t in targets[:3]],
-                                                 targets[3][lvl])
+                lc, lb = all_lc[lvl], all_lb[lvl]
                 lo = self.occupancy_loss(occ, gt_occupancy) if (last and occ is not None) else torch.zeros_like(lc)
             if last:
                 losses.update(loss_cls=lc, loss_bbox=lb, loss_occupancy=lo, loss_flow=torch.zeros_like(lc))
@@ -739,10 +768,21 @@ class VoxelFormerOccupancyHead(BaseModule):
         dev = all_box.device
         gt_pad = all_box.new_zeros(bs, gmax, 9)
         lab_pad = torch.zeros(bs, gmax, dtype=torch.long, device=dev)
-        for i, (g, lab) in enumerate(zip(gt_boxes, gt_labels)):
-            if counts[i]:
-                gt_pad[i, :counts[i]] = g.to(all_box.dtype)
-                lab_pad[i, :counts[i]] = lab.reshape(-1)
+        widths = {int(g.shape[-1]) for g in gt_boxes}
+        if len(widths) == 1 and all(torch.is_tensor(g) and g.device == dev for g in gt_boxes) \
+                and all(torch.is_tensor(x) and x.device == dev for x in gt_labels):
+            # the usual case (every sample's boxes on the device, one width): the padded [bs, Gmax] tables are one
+            # concatenation and one indexed copy each, whatever the batch size (velocity columns stay zero, head:1316-1317)
+            width = min(widths.pop(), 9)
+            slots = self._gt_slots(tuple(counts), gmax, dev)
+            gt_pad.view(bs * gmax, 9)[:, :width].index_copy_(0, slots, torch.cat(list(gt_boxes))[:, :width].to(all_box.dtype))
+            lab_pad.view(-1).index_copy_(0, slots, torch.cat([x.reshape(-1) for x in gt_labels]).long())
+        else:
+            gt_boxes, gt_labels = self._prepare_gts(gt_boxes, gt_labels, dev)
+            for i, (g, lab) in enumerate(zip(gt_boxes, gt_labels)):
+                if counts[i]:
+                    gt_pad[i, :counts[i]] = g.to(all_box.dtype)
+                    lab_pad[i, :counts[i]] = lab.reshape(-1)
         with torch.no_grad():
             c = a.cls_cost
             p = all_cls.float().sigmoid()
@@ -783,7 +823,7 @@ class VoxelFormerOccupancyHead(BaseModule):
                     rows, cols = linear_sum_assignment(cost[lvl, i, :, :counts[i]])
                     idx[lvl, i, rows] = cols
         num_pos = (idx >= 0).reshape(nl, -1).sum(1).tolist()
-        idx_t = torch.from_numpy(idx).to(dev)
+        idx_t = _to_device_async(torch.from_numpy(idx), dev)
         pos_mask = idx_t >= 0
         safe = idx_t.clamp(min=0)
         labels = torch.where(pos_mask, lab_pad[None].expand(nl, bs, gmax).gather(2, safe),
@@ -791,28 +831,47 @@ class VoxelFormerOccupancyHead(BaseModule):
         bbox_targets = gt_pad[None].expand(nl, bs, gmax, 9).gather(2, safe[..., None].expand(nl, bs, nq, 9))
         return labels, bbox_targets, pos_mask, num_pos
 
-    def _loss_from_targets(self, cls_scores, bbox_preds, labels, bbox_targets, pos_mask, num_total_pos):
-        """The detection terms of ``loss_single`` (head:903-976) from precomputed targets; rows the
-        reference drops by boolean indexing (non-finite normalised targets) get weight 0 instead, so
-        nothing here synchronises with the host."""
-        cls_scores = cls_scores.reshape(-1, self.cls_out_channels)
-        num_total_neg = pos_mask.numel() - num_total_pos
-        cls_avg_factor = num_total_pos * 1.0 + num_total_neg * self.bg_cls_weight
-        if self.sync_cls_avg_factor:
-            cls_avg_factor = _mean_over_ranks(cls_avg_factor, cls_scores)
-        cls_avg_factor = max(cls_avg_factor, 1)
-        labels = labels.reshape(-1)
-        loss_cls = self.loss_cls(cls_scores, labels, labels.new_ones(labels.shape, dtype=cls_scores.dtype),
-                                 avg_factor=cls_avg_factor)
-        num_total_pos = max(_mean_over_ranks(num_total_pos, loss_cls), 1.0)
-        bbox_preds = bbox_preds.reshape(-1, bbox_preds.size(-1))
+    _GT_SLOTS = {}
+
+    @classmethod
+    def _gt_slots(cls, counts, gmax, dev):
+        """Rows of the padded [bs * Gmax] gt tables that hold a box, for this step's gt counts (int64 on ``dev``; the
+        last few count patterns are kept: a fixed dataset order repeats them every epoch, a synthetic step every step)."""
+        key = (counts, gmax, str(dev))
+        hit = cls._GT_SLOTS.get(key)
+        if hit is None:
+            if len(cls._GT_SLOTS) >= 64:
+                cls._GT_SLOTS.clear()
+            rows = [i * gmax + j for i, c in enumerate(counts) for j in range(c)]
+            hit = cls._GT_SLOTS[key] = _to_device_async(torch.tensor(rows, dtype=torch.long), dev)
+        return hit
+
+    def _losses_from_targets(self, all_cls, all_box, labels, bbox_targets, pos_mask, num_pos):
+        """The detection terms of ``loss_single`` (head:903-976, applied per layer by multi_apply) for all L decoder layers
+        at once, from precomputed targets -> (loss_cls [L], loss_bbox [L]): the same per-element terms, summed per layer and
+        divided by that layer's normaliser.  Rows the reference drops by boolean indexing (non-finite normalised targets)
+        get weight 0 instead, so nothing here synchronises with the host."""
+        nl = all_cls.shape[0]
+        per_layer = pos_mask[0].numel()
+        cls_avg, pos_avg = [], []
+        for lvl in range(nl):
+            f = num_pos[lvl] * 1.0 + (per_layer - num_pos[lvl]) * self.bg_cls_weight
+            if self.sync_cls_avg_factor:
+                f = _mean_over_ranks(f, all_cls)
+            cls_avg.append(max(f, 1))
+            pos_avg.append(max(_mean_over_ranks(num_pos[lvl], all_cls), 1.0))
+        norm = _to_device_async(torch.tensor([cls_avg, pos_avg], dtype=torch.float32), all_cls.device)
+        cls_scores = all_cls.reshape(-1, self.cls_out_channels)
+        elem = self.loss_cls(cls_scores, labels.reshape(-1), None, reduction_override='none')
+        loss_cls = elem.reshape(nl, -1).sum(1) / norm[0]
+        bbox_preds = all_box.reshape(-1, all_box.size(-1))
         pos = pos_mask.reshape(-1)
         normalized = normalize_bbox(bbox_targets.reshape(-1, bbox_targets.size(-1)), self.pc_range)
         keep = (torch.isfinite(normalized).all(dim=-1) & pos).to(bbox_preds.dtype)
         weights = keep[:, None] * self.code_weights
         target = torch.nan_to_num(normalized[:, :10], nan=0.0, posinf=0.0, neginf=0.0) * keep[:, None]
-        loss_bbox = self.loss_bbox(bbox_preds[:, :10] * keep[:, None], target, weights[:, :10],
-                                   avg_factor=num_total_pos)
+        elem = self.loss_bbox(bbox_preds[:, :10] * keep[:, None], target, weights[:, :10], reduction_override='none')
+        loss_bbox = elem.reshape(nl, -1).sum(1) / norm[1]
         return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)
 
     def get_occupancy_prediction(self, occ_results, occ_threshold=0.25):

@@ -233,10 +233,11 @@ class VoxelDetectionTransformerDecoder(TransformerLayerSequence):
             if reg_branches is not None:
                 tmp = reg_branches[lid](output)
                 assert reference_points.shape[-1] == 3
-                new_ref = torch.zeros_like(reference_points)
-                new_ref[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points[..., :2])
-                new_ref[..., 2:3] = tmp[..., 4:5] + inverse_sigmoid(reference_points[..., 2:3])
-                reference_points = new_ref.sigmoid().detach()
+                # voxel_decoder.py:118-126 fills (x, y) and z of a zero tensor in two assignments and detaches the result:
+                # the same three columns in one expression, outside the autograd graph
+                with torch.no_grad():
+                    new_ref = torch.cat([tmp[..., :2], tmp[..., 4:5]], -1) + inverse_sigmoid(reference_points)
+                    reference_points = new_ref.sigmoid()
             output = output.permute(1, 0, 2)
             if self.return_intermediate:
                 intermediate.append(output)

@@ -108,7 +108,16 @@ class VoxelPerceptionTransformer(BaseModule):
         voxel_embed = self.get_voxel_features(mlvl_feats, bev_queries, bev_z, bev_h, bev_w,
                                               grid_length=grid_length, bev_pos=bev_pos,
                                               prev_bev=prev_bev, **kwargs)
-        bs = mlvl_feats.shape[1]
+        return self.decode(voxel_embed, object_query_embed, bev_z, bev_h, bev_w, reg_branches=reg_branches,
+                           cls_branches=cls_branches, **kwargs)
+
+    def decode(self, voxel_embed, object_query_embed, bev_z, bev_h, bev_w, reg_branches=None, cls_branches=None,
+               **kwargs):
+        """The detection half of ``forward`` (reference :230-301) on an encoder output ``voxel_embed`` [bs,Nq,C]: a
+        caller that wants the decoder on its own HIP stream (the head's training step) runs the two halves itself."""
+        if self.decoder is None:
+            raise RuntimeError('decode() needs a decoder')
+        bs = voxel_embed.shape[0]
         query_pos, query = torch.split(object_query_embed, self.embed_dims, dim=1)
         query_pos = query_pos.unsqueeze(0).expand(bs, -1, -1)
         query = query.unsqueeze(0).expand(bs, -1, -1)
@@ -119,7 +128,7 @@ class VoxelPerceptionTransformer(BaseModule):
         voxel_embed = voxel_embed.permute(1, 0, 2)
         if self.decoder_on_bev:
             raise NotImplementedError('decoder_on_bev=True is not used by vocc.py (:109)')
-        for k in ('world2pixel', 'origin', 'hit_table', 'map_hw'):
+        for k in ('world2pixel', 'origin', 'hit_table', 'map_hw', 'img_metas'):
             kwargs.pop(k, None)
         inter_states, inter_references = self.decoder(
             query=query, key=None, value=voxel_embed, query_pos=query_pos,

@@ -368,6 +368,46 @@ def test_hungarian_targets_started_in_forward_give_the_same_losses():
         assert float(redo['loss_bbox']) == float(ref['loss_bbox']) != float(want['loss_bbox'])
 
 
+def test_grouped_bf16_parameter_copies_equal_autocast(monkeypatch):
+    """Under bf16 autocast a training step lends the decoder and the cls / reg branches bf16 copies of their Linear
+    parameters made by ONE multi-tensor cast (modules/lowp_params.py; VER_LOWP_PARAMS=0: autocast's cast per parameter
+    and call).  The copies hold the values autocast would have produced, so outputs and losses are equal to the last bit;
+    gradients arrive in fp32 on the fp32 masters, equal up to the atomics' order in the deformable-attention backward;
+    parameters the step does not touch keep ``grad is None`` and every module has its fp32 parameters back afterwards."""
+    syn = pkg('synthetic')
+    cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
+    head = _head(cfg, 7)
+    w2p, org = syn.camera_batch(2, seed=1)
+    w2p, org = T(w2p).to(DEV), T(org).to(DEV)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gts = [cases.detection_gt(seed=40 + i, num_gt=3 + i) for i in range(2)]
+    gb, gl = [T(b[:, :7]).to(DEV) for b, _ in gts], [T(l).to(DEV) for _, l in gts]
+    gt_occ = T(np.random.default_rng(9).integers(0, 17, size=(2, 504000))).to(DEV)
+    results = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('VER_LOWP_PARAMS', mode)
+        head.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            outs = head(feats, None, world2pixel=w2p, origin=org, targets_for=(gb, gl))
+        outs = {k: (v.float() if torch.is_tensor(v) else v) for k, v in outs.items()}
+        losses = head.loss(gb, gl, gt_occ, outs)
+        sum(losses.values()).backward()
+        results[mode] = ({k: outs[k].detach().clone() for k in ('all_cls_scores', 'all_bbox_preds')},
+                         {k: float(v) for k, v in losses.items()},
+                         {k: p.grad.detach().clone() for k, p in head.named_parameters() if p.grad is not None})
+    for k, p in head.named_parameters():
+        assert isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 and p.is_leaf, k
+    (o0, l0, g0), (o1, l1, g1) = results['0'], results['1']
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    assert l0 == l1
+    assert sorted(g0) == sorted(g1) and len(g0) > 100
+    assert 'transformer.decoder.layers.0.attentions.0.attn.in_proj_weight' in g1 and 'cls_branches.0.0.weight' in g1
+    for k in g0:
+        assert g1[k].dtype == torch.float32
+        assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-3, k
+
+
 def test_full_multitask_training_steps_bf16():
     """Two optimiser steps of bench.py's `--workload vocc_full_train` arithmetic (bf16 autocast, occupancy loss in row
     order, Hungarian targets batched, grad clip, fused AdamW) on 3 viewpoints: finite and decreasing-or-equal is not

@@ -12,8 +12,10 @@ What differs is how the occupancy branch is evaluated:
 * the raw ``.view`` re-interpretations of :558 and :564 are kept exactly (they are part of the
   reference's results), per sample, so any batch size works (the reference is bs=1 only).
 """
+import contextlib
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -413,7 +415,8 @@ class VoxelFormerOccupancyHead(BaseModule):
         #  launches per direction do execute beside the occupancy head's GEMMs, but those fill every CU, the small kernels
         #  stretch 2x and the 64-viewpoint step gains 0.7 % (480 -> 483 viewpoints/s); one traced run with the second
         #  stream never finished.  One stream.)
-        out = self._detection_half(voxel_embed, object_query_embeds, targets_for, img_metas, kwargs)
+        with self._detection_params(voxel_embed):
+            out = self._detection_half(voxel_embed, object_query_embeds, targets_for, img_metas, kwargs)
         bev_embed, all_cls, all_box, layouts, pending = out
         if self.only_det:
             occupancy = None
@@ -431,6 +434,19 @@ class VoxelFormerOccupancyHead(BaseModule):
         if pending is not None:
             out['pending_targets'] = pending
         return out
+
+    def _detection_params(self, like):
+        """Under bf16 autocast in a training step: the Linear parameters of the decoder and of the cls / reg branches as
+        bf16 copies made by one multi-tensor cast (modules/lowp_params.py) instead of one cast per parameter and call."""
+        lowp = getattr(self, '_lowp_detection', None)
+        if lowp is None:
+            from ..modules.lowp_params import LowpParams
+            roots = [self.transformer.decoder, self.cls_branches, self.reg_branches]
+            if hasattr(self.transformer, 'reference_points'):
+                roots.append(self.transformer.reference_points)
+            lowp = self.__dict__['_lowp_detection'] = LowpParams([r for r in roots if r is not None])
+        on = os.environ.get('VER_LOWP_PARAMS', '1') == '1'            # (0: autocast's own per-call casts, for A/B runs)
+        return lowp.lent() if (on and lowp.applies(like)) else contextlib.nullcontext()
 
     def _detection_half(self, voxel_embed, object_query_embeds, targets_for, img_metas, kwargs):
         """Decoder + cls / reg (/ layout) branches on the encoder output [bs,Nq,C] (head:584-613), and the start of the

@@ -1,6 +1,7 @@
 """Head-level parity on the GPU against vectors from the reference's own
 ``VoxelFormerOccupancyHead`` built from vocc.py (tests/golden/make_golden_head.py).
 fp32, tolerance 1e-4 (north_star) on the occupancy logits.  ``-m gpu``."""
+import contextlib
 import warnings
 
 import numpy as np
@@ -370,10 +371,12 @@ def test_hungarian_targets_started_in_forward_give_the_same_losses():
 
 def test_grouped_bf16_parameter_copies_equal_autocast(monkeypatch):
     """Under bf16 autocast a training step lends the decoder and the cls / reg branches bf16 copies of their Linear
-    parameters made by ONE multi-tensor cast (modules/lowp_params.py; VER_LOWP_PARAMS=0: autocast's cast per parameter
-    and call).  The copies hold the values autocast would have produced, so outputs and losses are equal to the last bit;
-    gradients arrive in fp32 on the fp32 masters, equal up to the atomics' order in the deformable-attention backward;
-    parameters the step does not touch keep ``grad is None`` and every module has its fp32 parameters back afterwards."""
+    parameters made by ONE multi-tensor cast, and runs their plain Linears through a bf16 Function whose weight gradient
+    is ``ver_wgrad_tn`` (modules/lowp_params.py; VER_LOWP_PARAMS=0: autocast's cast per parameter and call, the library's
+    GEMMs).  The copies hold the values autocast would have produced; the Linear adds its bias inside the GEMM where
+    autocast's 3-D path rounds to bf16 first, so outputs and losses agree to bf16 rounding, not to the bit.  Gradients
+    arrive in fp32 on the fp32 masters; parameters the step does not touch keep ``grad is None`` and every module has its
+    fp32 parameters (and its class's forward) back afterwards."""
     syn = pkg('synthetic')
     cfg = dict(cases.vocc_head_cfg(), train_cfg=cases.VOCC_TRAIN_CFG)
     head = _head(cfg, 7)
@@ -391,21 +394,88 @@ def test_grouped_bf16_parameter_copies_equal_autocast(monkeypatch):
             outs = head(feats, None, world2pixel=w2p, origin=org, targets_for=(gb, gl))
         outs = {k: (v.float() if torch.is_tensor(v) else v) for k, v in outs.items()}
         losses = head.loss(gb, gl, gt_occ, outs)
-        sum(losses.values()).backward()
+        # (gradients of a FIXED functional of the outputs: the Hungarian assignment may legitimately flip between two
+        #  bf16 evaluations of an untrained head, and with it whole rows of the box gradients)
+        probe = sum((outs[k] * torch.sin(torch.arange(outs[k].numel(), device=DEV).view_as(outs[k]) * 0.37)).sum()
+                    for k in ('all_cls_scores', 'all_bbox_preds'))
+        probe.backward()
         results[mode] = ({k: outs[k].detach().clone() for k in ('all_cls_scores', 'all_bbox_preds')},
                          {k: float(v) for k, v in losses.items()},
                          {k: p.grad.detach().clone() for k, p in head.named_parameters() if p.grad is not None})
     for k, p in head.named_parameters():
         assert isinstance(p, torch.nn.Parameter) and p.dtype == torch.float32 and p.is_leaf, k
     (o0, l0, g0), (o1, l1, g1) = results['0'], results['1']
+    for m in head.modules():
+        assert 'forward' not in m.__dict__
     for k in o0:
-        assert torch.equal(o0[k], o1[k]), k
-    assert l0 == l1
+        assert rel_l2(o1[k].cpu().numpy(), o0[k].cpu().numpy()) < 3e-2, k      # (two bf16 evaluations of 6 decoder layers)
+    for k in l0:
+        assert l1[k] == pytest.approx(l0[k], rel=5e-2, abs=1e-6), k
     assert sorted(g0) == sorted(g1) and len(g0) > 100
     assert 'transformer.decoder.layers.0.attentions.0.attn.in_proj_weight' in g1 and 'cls_branches.0.0.weight' in g1
+    worst = {k: rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) for k in g0}
+    # Two bf16 evaluations of an untrained 3 + 6 layer network: the gradients of the sampling offsets (a sum of signed
+    # trilinear slopes) move by 10-40 % between them, the typical parameter by 4 % (measured: median 0.039, max 0.42).
+    # The arithmetic of the lent path itself is pinned by test_lent_linears_against_fp32 below; here only the plumbing is:
+    # every gradient arrives, in fp32, on the master parameter, at the noise level of bf16.
     for k in g0:
-        assert g1[k].dtype == torch.float32
-        assert rel_l2(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 2e-3, k
+        assert g1[k].dtype == torch.float32 and torch.isfinite(g1[k]).all(), k
+        assert worst[k] < 0.8, (k, worst[k])
+    assert float(np.median(list(worst.values()))) < 8e-2
+
+
+def test_lent_linears_against_fp32():
+    """modules/lowp_params.py on a small stack of Linears (the shapes of a 64-viewpoint decoder call: 6 400 rows x 768):
+    outputs, input gradient and parameter gradients of the lent bf16 path against the same stack in fp32 -- within the
+    bf16 bound the package states (rel-L2 1e-2) and at least as close as autocast's own evaluation; unused parameters
+    keep ``grad is None``; the multi-tensor casts are exact (round-to-nearest bf16 of the master, fp32 of the bf16 grad)."""
+    lp = pkg('modules.lowp_params')
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(768, 768), torch.nn.ReLU(), torch.nn.Linear(768, 1536), torch.nn.ReLU(),
+                              torch.nn.Linear(1536, 96)).to(DEV)
+    spare = torch.nn.Linear(768, 32).to(DEV)                       # lent but never called
+    x = torch.randn(64, 100, 768, device=DEV)
+    w = torch.randn(64, 100, 96, device=DEV)
+
+    def run(mode):
+        xx = x.clone().requires_grad_(True)
+        for p in list(net.parameters()) + list(spare.parameters()):
+            p.grad = None
+        if mode == 'fp32':
+            y = net(xx)
+        else:
+            lent = lp.LowpParams([net, spare])
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                assert lent.applies(xx)
+                with (lent.lent() if mode == 'lent' else contextlib.nullcontext()):
+                    if mode == 'lent':
+                        assert net[0].weight.dtype == torch.bfloat16 and 'forward' in net[0].__dict__
+                        assert torch.equal(net[0].weight, net[0]._parameters['weight']) and net[0].weight.data_ptr() % 256 == 0
+                    y = net(xx)
+            assert net[0].weight.dtype == torch.float32 and 'forward' not in net[0].__dict__
+        (y.float() * w).sum().backward()
+        return y.detach().float(), xx.grad, [p.grad.clone() for p in net.parameters()]
+
+    want, lent, auto = run('fp32'), run('lent'), run('autocast')
+    assert spare.weight.grad is None and spare.bias.grad is None
+    assert rel_l2(lent[0].cpu().numpy(), want[0].cpu().numpy()) < 1e-2
+    assert rel_l2(auto[0].cpu().numpy(), want[0].cpu().numpy()) < 1e-2
+    # gradients: bf16 rounding flips ReLU gates of pre-activations near zero, so BOTH bf16 evaluations sit some per cent
+    # away from fp32 (6 % on the input gradient here); the lent path must not be further away than autocast's
+    for g, a, wnt in zip([lent[1]] + lent[2], [auto[1]] + auto[2], [want[1]] + want[2]):
+        assert g.dtype == torch.float32 and g.shape == wnt.shape
+        e_lent, e_auto = rel_l2(g.cpu().numpy(), wnt.cpu().numpy()), rel_l2(a.cpu().numpy(), wnt.cpu().numpy())
+        assert e_lent < 0.12 and e_lent < 1.25 * e_auto + 1e-3, (e_lent, e_auto)
+    # the casts themselves
+    lent_set = lp.LowpParams([net])
+    with torch.autocast('cuda', dtype=torch.bfloat16), lent_set.lent():
+        for m in (net[0], net[2], net[4]):
+            assert torch.equal(m.weight, m._parameters['weight']) and m.weight.dtype == torch.bfloat16
+        copies = [net[0].weight, net[0].bias]
+        masters = [p for p in net[0].parameters()]
+    # (outside the context the parameters are the fp32 masters again)
+    assert all(p.dtype == torch.float32 for p in net.parameters())
+    assert torch.equal(copies[0], masters[0].detach().bfloat16()) and torch.equal(copies[1], masters[1].detach().bfloat16())
 
 
 def test_full_multitask_training_steps_bf16():

@@ -21,6 +21,7 @@ class _RowLinear(torch.autograd.Function):
         w = weight.to(x.dtype)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.weight_dtype = weight.dtype
         if bias is None:
             return x @ w.t()
         return torch.addmm(bias.to(x.dtype), x, w.t())
@@ -42,7 +43,12 @@ class _RowLinear(torch.autograd.Function):
             # quarter of its 256 x 256 tile and keep the batched form below
             from ..hipops import wgrad_tn, wgrad_tn_supported
             if wgrad_tn_supported(g, x):
-                return gx, wgrad_tn(g, x, out_dtype=torch.float32), gb
+                # (fp32 for an fp32 master weight; a bf16 working copy -- modules/lowp_params.py -- gets the bf16 gradient
+                #  autograd expects for it, widened with all the others in one pass)
+                wide = torch.float32 if ctx.weight_dtype == torch.float32 else torch.bfloat16
+                if wide == torch.bfloat16 and gb is not None:
+                    gb = gb.to(torch.bfloat16)
+                return gx, wgrad_tn(g, x, out_dtype=wide), gb
         s = n // _CHUNK
         main = s * _CHUNK
         gw = x.new_zeros((o, x.shape[1]), dtype=torch.float32)

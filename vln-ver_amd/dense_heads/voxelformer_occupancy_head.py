@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..modules.bricks import BaseModule
+from ..modules.bricks import BaseModule, const_tensor
 from ..modules.voxel_decoder import inverse_sigmoid
 from ..registry import (HEADS, build_bbox_coder, build_loss, build_positional_encoding,
                         build_transformer)
@@ -461,8 +461,14 @@ class VoxelFormerOccupancyHead(BaseModule):
         # outputs of all L layers are stacked here and de-normalised in one pass (the same elementwise arithmetic on
         # [L,bs,Nq,.] instead of L times on [bs,Nq,.]: a sixth of the launches, forward and backward)
         nl = hs.shape[0]
-        all_cls = torch.stack([self.cls_branches[lvl](hs[lvl]) for lvl in range(nl)])
-        tmp = torch.stack([self.reg_branches[lvl](hs[lvl]) for lvl in range(nl)])
+        states = hs.unbind(0)           # (one backward node for the L layers instead of a zero-filled [L,...] buffer per use)
+        all_cls = torch.stack([self.cls_branches[lvl](states[lvl]) for lvl in range(nl)])
+        # with box refinement the decoder has evaluated reg_branches[lvl] on these very states already (its reference-point
+        # update, detached there): the same values, now with the graph the reference builds by evaluating them again
+        taken = self.transformer.decoder.take_branch_outputs() if self.with_box_refine else None
+        if taken is None or len(taken) != nl:
+            taken = [self.reg_branches[lvl](states[lvl]) for lvl in range(nl)]
+        tmp = torch.stack(taken)
         reference = init_reference[None] if nl == 1 else torch.cat([init_reference[None], inter_references[:nl - 1]])
         assert reference.shape[-1] == 3
         reference = inverse_sigmoid(reference)
@@ -487,13 +493,18 @@ class VoxelFormerOccupancyHead(BaseModule):
     @staticmethod
     def _denormalize(tmp, reference, rng):
         """Branch output [..., 10] + inverse-sigmoid reference [..., 3] -> box code with metric centre (head:590-606):
-        (cx, cy) and cz through a sigmoid into ``rng`` = (x0, y0, z0, x1, y1, z1), the other entries as they are."""
-        xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid()
-        zc = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid()
-        x = xy[..., 0:1] * (rng[3] - rng[0]) + rng[0]
-        y = xy[..., 1:2] * (rng[4] - rng[1]) + rng[1]
-        z = zc * (rng[5] - rng[2]) + rng[2]
-        return torch.cat([x, y, tmp[..., 2:4], z, tmp[..., 5:]], -1)
+        (cx, cy) and cz go through a sigmoid into ``rng`` = (x0, y0, z0, x1, y1, z1), the other entries stay as they are.
+        Written over whole rows (the reference slices columns 0:2 and 4:5 out and concatenates): the three columns see the
+        same operations in the same order, and the backward is five elementwise passes instead of a zero-filled buffer
+        per slice."""
+        dev, width = tmp.device, tmp.shape[-1]
+        cols = const_tensor([0, 1, 0, 0, 2, 0, 0, 0, 0, 0][:width], dev, torch.long)
+        span = const_tensor([rng[3] - rng[0], rng[4] - rng[1], 0, 0, rng[5] - rng[2], 0, 0, 0, 0, 0][:width], dev, torch.float32)
+        low = const_tensor([rng[0], rng[1], 0, 0, rng[2], 0, 0, 0, 0, 0][:width], dev, torch.float32)
+        centre = const_tensor([1, 1, 0, 0, 1, 0, 0, 0, 0, 0][:width], dev, torch.bool)
+        ref = reference.index_select(-1, cols)          # (x, y, z) of the reference under columns 0, 1, 4 (the rest is unused)
+        metric = (tmp + ref).sigmoid() * span + low     # fp32 whenever the reference is (type promotion, as in the reference)
+        return torch.where(centre, metric, tmp)
 
     def _only_occ(self, voxel_embed):
         """head:338-350: the only_occ branch never upsamples (plain [bs,Z,H,W,C] view)."""
@@ -888,7 +899,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         target = torch.nan_to_num(normalized[:, :10], nan=0.0, posinf=0.0, neginf=0.0) * keep[:, None]
         elem = self.loss_bbox(bbox_preds[:, :10] * keep[:, None], target, weights[:, :10], reduction_override='none')
         loss_bbox = elem.reshape(nl, -1).sum(1) / norm[1]
-        return torch.nan_to_num(loss_cls), torch.nan_to_num(loss_bbox)
+        return torch.nan_to_num(loss_cls).unbind(0), torch.nan_to_num(loss_bbox).unbind(0)
 
     def get_occupancy_prediction(self, occ_results, occ_threshold=0.25):
         """head:1505-1540 (focal-loss branch): sigmoid, threshold as an extra "empty" column,

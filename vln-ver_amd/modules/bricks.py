@@ -138,6 +138,8 @@ def tall_linear(mod, x, weight=None, bias=None):
     runs on the few workgroups its 9-18 output tiles give (GEMM ledger, profiles/r04_gemm_ledger.csv: 0.15-0.6 PFLOP/s) --
     ``row_linear`` splits the row axis into one batched GEMM with fp32-summed partials.  ``weight`` / ``bias``: fused
     parameter stacks (the two narrow projections of the query) instead of ``mod``'s own."""
+    if weight is None and bias is None and mod is not None and 'forward' in mod.__dict__:
+        return mod(x)                   # the module is lent bf16 parameters and its own bf16 path (modules/lowp_params.py)
     w = mod.weight if weight is None else weight
     b = (mod.bias if mod is not None else None) if bias is None else bias
     if x.is_cuda and torch.is_grad_enabled() and w.requires_grad and x.numel() // x.shape[-1] >= _TALL_ROWS:

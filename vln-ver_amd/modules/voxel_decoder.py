@@ -225,6 +225,9 @@ class VoxelDetectionTransformerDecoder(TransformerLayerSequence):
                 **kwargs):
         output = query
         intermediate, intermediate_reference_points = [], []
+        # reg_branches[lid](state of layer lid), in graph: the head evaluates the same branch on the same state again
+        # (head:590 after voxel_decoder.py:118) and may take these instead (``take_branch_outputs``)
+        self._branch_outputs = [] if (reg_branches is not None and self.return_intermediate) else None
         for lid, layer in enumerate(self.layers):
             reference_points_input = reference_points[..., :3].unsqueeze(2)
             output = layer(output, *args, reference_points=reference_points_input,
@@ -232,6 +235,8 @@ class VoxelDetectionTransformerDecoder(TransformerLayerSequence):
             output = output.permute(1, 0, 2)
             if reg_branches is not None:
                 tmp = reg_branches[lid](output)
+                if self._branch_outputs is not None:
+                    self._branch_outputs.append(tmp)
                 assert reference_points.shape[-1] == 3
                 # voxel_decoder.py:118-126 fills (x, y) and z of a zero tensor in two assignments and detaches the result:
                 # the same three columns in one expression, outside the autograd graph
@@ -245,3 +250,9 @@ class VoxelDetectionTransformerDecoder(TransformerLayerSequence):
         if self.return_intermediate:
             return torch.stack(intermediate), torch.stack(intermediate_reference_points)
         return output, reference_points
+
+    def take_branch_outputs(self):
+        """The per-layer ``reg_branches`` outputs [bs,Nq,code] of the last ``forward`` (None without box refinement);
+        handed out once, so that no graph stays alive on the module."""
+        out, self._branch_outputs = getattr(self, '_branch_outputs', None), None
+        return out

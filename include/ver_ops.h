@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 24
+#define VER_ABI_VERSION 25
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -261,6 +261,13 @@ int ver_lattice_scatter(const void* grad_col, void* grad_src, const int* taps, c
  */
 int ver_convt_weight_forward(const float* weight, void* taps, long pairs, int dtype, void* stream);
 int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pairs, int dtype, void* stream);
+/*   ver_convt_weight_backward_blocks : the same adjoint taken straight from the weight gradients of a lattice layer's class
+ *       GEMMs (no reference counterpart: the reference's ConvTranspose3d backward, head:251-258 through autograd): tap t
+ *       is the fp32 sum of up to two [ci x co] blocks of `blocks` (row pitch `ld` elements, `dtype`) at element offsets
+ *       block_offsets[2t], block_offsets[2t+1] (device int64 [75][2], -1 = none) plus prev_bias[ci] * grad_v[t*co + co']
+ *       (both `dtype`, or both NULL) -> grad_weight f32 [ci*co][75], taps flipped as above. */
+int ver_convt_weight_backward_blocks(const void* blocks, const long* block_offsets, long ld, const void* prev_bias,
+                                     const void* grad_v, float* grad_weight, int ci, int co, int dtype, void* stream);
 int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
                           int C, int layout, int to_channel_first, int dtype, void* stream);
 

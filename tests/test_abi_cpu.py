@@ -84,7 +84,7 @@ def test_argument_validation_of_the_head_entry_points():
 
 
 def test_argument_validation_of_the_gemm_entry_points():
-    """ver_wgrad_tn / ver_gemm_nn / the *_stats MLP entries (ABI 24): sizes, alignment, row pitches, workspace size and the
+    """ver_wgrad_tn / ver_gemm_nn / the *_stats MLP entries (ABI 24), ver_convt_weight_backward_blocks (ABI 25): sizes, alignment, row pitches, workspace size and the
     split arithmetic are checked on the host before anything is launched; the split chooser and the workspace size are
     pure host functions."""
     hip = pkg('hipops')
@@ -129,6 +129,17 @@ def test_argument_validation_of_the_gemm_entry_points():
     assert rc == -1 and b'pitch' in lib.ver_last_error()
     rc = lib.ver_gemm_nn(*g(buf, buf, buf, fl=1))
     assert rc == -1 and b'flags' in lib.ver_last_error()
+    # ver_convt_weight_backward_blocks (ABI 25): sizes, dtype and the prev_bias / grad_v pairing before any launch
+    blk = lambda src, off, pb, dv, gw, ci=8, co=8, ld=16, dt=1: (src, off, L(ld), pb, dv, gw, ci, co, dt, None)
+    assert lib.ver_convt_weight_backward_blocks(*blk(None, None, None, None, None, ci=0)) == 0
+    rc = lib.ver_convt_weight_backward_blocks(*blk(buf, buf, None, None, buf, ld=4))
+    assert rc == -1 and b'bad sizes' in lib.ver_last_error()
+    rc = lib.ver_convt_weight_backward_blocks(*blk(buf, buf, None, None, buf, dt=5))
+    assert rc == -1 and b'dtype' in lib.ver_last_error()
+    rc = lib.ver_convt_weight_backward_blocks(*blk(buf, buf, buf, None, buf))
+    assert rc == -1 and b'come together' in lib.ver_last_error()
+    rc = lib.ver_convt_weight_backward_blocks(*blk(None, buf, None, None, buf))
+    assert rc == -1 and b'null' in lib.ver_last_error()
     # the MLP entries with the saved statistics: the rstd pointer must be 8-byte aligned and N < 2^28
     off = ctypes.cast(ctypes.addressof(buf) + 4, ctypes.c_void_p)
     rc = lib.ver_occ_mlp_forward_stats(buf, buf, buf, buf, off, L(4), 128, 16, ctypes.c_float(1e-5), 2, None)

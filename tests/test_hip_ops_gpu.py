@@ -650,6 +650,50 @@ def test_convt_weight_taps_and_lattice_transpose(dtype):
             assert torch.equal(back.cpu(), src)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kind', ['l0', 'lat'])
+def test_convt_weight_gradient_from_class_blocks(kind, dtype):
+    """ver_convt_weight_backward_blocks against the sequence of torch ops it replaces in the z-split layers' backward
+    (dense_heads/upsample.py): per class two indexed copies of the half gradients into zero-filled [75 Ci, Co] buffers,
+    their sum, + prev_bias (x) d(v), the adjoint of the tap flip.  fp32 sums of at most three terms: exact up to the
+    rounding of the bf16 intermediates the torch sequence keeps (compared in fp64 with those intermediates left out)."""
+    hip, up = pkg('hipops'), pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(31)
+    ci, co = 24, 40                                  # (Co not a multiple of the kernel's 64-pair tile)
+    if kind == 'l0':
+        _, _, lo, hi = up._layer0_z4_plan(ci, 'cpu')
+        rows = 50 * ci
+        pieces = [(0, rows, lo, hi)]
+        pb = dv = None
+    else:
+        plan, kt, total_rows, _, _ = up._layer_plan_z4(ci, 'cpu')
+        class_rows = up._class_rows_z4(ci)
+        pieces = [(class_rows[cls][0], plan[cls][1] - plan[cls][0], plan[cls][2], plan[cls][3]) for cls in up._CLASSES]
+        rows = sum(p[1] for p in pieces)
+        pb = torch.randn(ci, generator=gen).to(dtype)
+        dv = torch.randn(75, co, generator=gen).to(dtype)
+    stacked = torch.randn(rows, 2 * co, generator=gen).to(dtype)
+    total = 75 * ci + 8 * up._PW2                    # data rows + every constant / dummy row the plans may name
+    d_lo = torch.zeros(total, co, dtype=torch.float64)
+    d_hi = torch.zeros(total, co, dtype=torch.float64)
+    for r0, n, lo, hi in pieces:
+        d_lo.index_copy_(0, lo, stacked[r0:r0 + n, :co].double())
+        d_hi.index_copy_(0, hi, stacked[r0:r0 + n, co:].double())
+    d_k = (d_lo + d_hi)[:75 * ci].view(75, ci, co)
+    if pb is not None:
+        d_k = d_k + pb.double()[None, :, None] * dv.double()[:, None, :]
+    want = d_k.view(3, 5, 5, ci, co).permute(3, 4, 0, 1, 2).flip(2, 3, 4)
+    got = hip.convt_weight_backward_blocks(stacked.to(DEV), up._block_offsets(kind, ci, co, DEV),
+                                           None if pb is None else pb.to(DEV), None if dv is None else dv.to(DEV), ci, co)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (ci, co, 3, 5, 5)
+    assert close(got.cpu(), want, atol=1e-5, rtol=1e-6)
+    if kind == 'lat':                                # the rows of the classes' own constant blocks, as the backward reads them
+        aug = stacked.view(-1, co).index_select(0, up._aug_rows_z4(ci, 'cpu')).view(8, up._PW, co).double().sum(0)
+        n_data = 75 * ci
+        want_aug = (d_lo + d_hi)[n_data:n_data + 4 * up._PW].view(4, up._PW, co).sum(0)
+        assert close(aug, want_aug, atol=1e-9, rtol=1e-9)
+
+
 def test_upsample_on_gpu_matches_conv_transpose():
     up = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(6)

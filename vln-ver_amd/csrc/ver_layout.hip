@@ -61,6 +61,43 @@ __global__ __launch_bounds__(256) void k_convt_weight_bwd(const void* __restrict
     for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
 }
 
+// adjoint from the class gradients of a z-split lattice layer: every tap t gathers up to two [Ci x Co] blocks of ONE
+// row-major buffer (element offsets off[t][0..1], -1 = none; row pitch ld) -- the "lower half" and "upper half" weight
+// gradients of the class GEMMs (dense_heads/upsample.py::_LatticeLayerZ4) -- plus prev_bias[ci] * d_v[t][co] (the constant
+// rows' gradient through v = prev_bias^T K[t]); fp32 sums -> dw [P][75] fp32, tap order flipped.  Replaces two zero-filled
+// [75 Ci, Co] buffers, eight indexed copies, an add, an addcmul and k_convt_weight_bwd.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_convt_weight_bwd_blocks(const void* __restrict__ src, const long* __restrict__ off,
+                                                                 long ld, const void* __restrict__ pb,
+                                                                 const void* __restrict__ dv, float* __restrict__ dw,
+                                                                 long P, int Co) {
+    __shared__ float tile[kPairs * kTaps + 1];
+    __shared__ long offs[2 * kTaps];
+    const long p0 = (long)blockIdx.x * kPairs;
+    const int np = (int)((P - p0) < kPairs ? (P - p0) : kPairs);
+    if (threadIdx.x < 2 * kTaps) offs[threadIdx.x] = off[threadIdx.x];
+    __syncthreads();
+    auto ld_elem = [&](const void* base, long i) -> float {
+        if (BF16) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[i] << 16);
+        return reinterpret_cast<const float*>(base)[i];
+    };
+    for (int i = threadIdx.x; i < kTaps * kPairs; i += 256) {
+        const int t = i / kPairs, p = i % kPairs;
+        if (p >= np) continue;
+        const long pair = p0 + p;
+        const long ci = pair / Co, co = pair - ci * Co;
+        float v = 0.f;
+        const long o0 = offs[2 * t], o1 = offs[2 * t + 1];
+        if (o0 >= 0) v += ld_elem(src, o0 + ci * ld + co);
+        if (o1 >= 0) v += ld_elem(src, o1 + ci * ld + co);
+        if (pb) v += ld_elem(pb, ci) * ld_elem(dv, (long)t * Co + co);
+        const int a = t / 25, b = (t / 5) % 5, c = t % 5;
+        tile[p * kTaps + ((2 - a) * 5 + (4 - b)) * 5 + (4 - c)] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
+}
+
 // ---- lattice <-> channel-first rows.  One workgroup = one (b, z, y) row of W positions x 128 channels.
 namespace {
 constexpr int kCh = 128;
@@ -263,6 +300,27 @@ extern "C" int ver_convt_weight_backward(const void* grad_taps, float* grad_weig
         hipLaunchKernelGGL(k_convt_weight_bwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_taps,
                            grad_weight, pairs);
     return ver_check_launch("ver_convt_weight_backward");
+}
+
+extern "C" int ver_convt_weight_backward_blocks(const void* blocks, const long* block_offsets, long ld, const void* prev_bias,
+                                               const void* grad_v, float* grad_weight, int ci, int co, int dtype,
+                                               void* stream) {
+    VER_REQUIRE(ci >= 0 && co >= 0 && ld >= co, VER_EINVAL, "ver_convt_weight_backward_blocks: bad sizes (ci %d co %d ld %ld)",
+                ci, co, ld);
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_convt_weight_backward_blocks: dtype %d", dtype);
+    VER_REQUIRE((prev_bias == nullptr) == (grad_v == nullptr), VER_EINVAL,
+                "ver_convt_weight_backward_blocks: prev_bias and grad_v come together");
+    const long pairs = (long)ci * co;
+    if (pairs == 0) return VER_OK;
+    VER_REQUIRE(blocks && block_offsets && grad_weight, VER_EINVAL, "ver_convt_weight_backward_blocks: null pointer argument");
+    const unsigned nb = (unsigned)((pairs + kPairs - 1) / kPairs);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_convt_weight_bwd_blocks<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, blocks, block_offsets,
+                           ld, prev_bias, grad_v, grad_weight, pairs, co);
+    else
+        hipLaunchKernelGGL(k_convt_weight_bwd_blocks<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, blocks, block_offsets,
+                           ld, prev_bias, grad_v, grad_weight, pairs, co);
+    return ver_check_launch("ver_convt_weight_backward_blocks");
 }
 
 extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,

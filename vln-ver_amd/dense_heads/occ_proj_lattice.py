@@ -157,6 +157,21 @@ def _row_index(plan, bs, device):
     return plan._row_index[bs]
 
 
+def _token_matrix(plan, like):
+    """[Z*C, groups*Z] 0/1 (counts): column (g, k) marks the non-data columns of token k in group g (``ncols_by_token``);
+    built once per plan and dtype."""
+    cache = plan.__dict__.setdefault('_token_matrices', {})
+    key = (like.dtype, str(like.device))
+    if key not in cache:
+        Z = plan.Z
+        m = torch.zeros(plan.Z * plan.C, len(plan.groups) * Z, dtype=like.dtype, device=like.device)
+        for gi, g in enumerate(plan.groups):
+            for k, n in enumerate(g.ncols_by_token):
+                m[:, gi * Z + k].index_add_(0, n.to(like.device), torch.ones(n.numel(), dtype=like.dtype, device=like.device))
+        cache[key] = m
+    return cache[key]
+
+
 class _OccProjLattice(torch.autograd.Function):
 
     @staticmethod
@@ -190,7 +205,11 @@ class _OccProjLattice(torch.autograd.Function):
         w = weight.to(dt)
         out = torch.empty(bs * plan.rows, out_dim, dtype=dt, device=e.device)
         operands, weights = [], []
-        for g in plan.groups:
+        # summed constant columns of every (group, token): weight @ (0/1 membership matrix) -- one small product in the
+        # master weight's precision instead of an index_select + sum per token and group (20 pairs at Z = 4)
+        with torch.autocast(weight.device.type, enabled=False):
+            s_all = weight @ _token_matrix(plan, weight)                                   # [out, groups * Z]
+        for gi, g in enumerate(plan.groups):
             if use_hip and g.run_len:
                 from ..hipops import run_gather
                 a = torch.empty(bs * g.n_rows, g.k_aug, dtype=dt, device=e.device)
@@ -198,7 +217,7 @@ class _OccProjLattice(torch.autograd.Function):
             else:
                 a = lat.index_select(1, g.gather_aug).view(bs * g.n_rows, g.k_aug)
             # W_aug^T [out, k_aug] = data columns | summed constant columns per token | bias | 0
-            s = torch.stack([weight.index_select(1, n).sum(1) for n in g.ncols_by_token], 1)      # [out, Z] fp32
+            s = s_all[:, gi * Z:(gi + 1) * Z]                                              # [out, Z] fp32
             pad = g.k_aug - g.n_cols - Z - 1
             wa = torch.cat([w.index_select(1, g.cols), s.to(dt), bias.to(dt)[:, None],
                             w.new_zeros(out_dim, pad)], 1)
@@ -224,6 +243,7 @@ class _OccProjLattice(torch.autograd.Function):
         d_weight = torch.zeros(weight.shape, dtype=acc, device=weight.device)
         d_bias = torch.zeros(weight.shape[0], dtype=acc, device=weight.device)
         d_up = torch.zeros(C, dtype=acc, device=weight.device)
+        d_tokens = []
         for g, a, wa in zip(plan.groups, operands, weights):
             go = grad_out[bs * g.offset: bs * (g.offset + g.n_rows)]
             # d(operand): data columns go back to their lattice positions (each written exactly once)
@@ -244,9 +264,10 @@ class _OccProjLattice(torch.autograd.Function):
             # d(W_aug^T) = go^T a
             d_wa = rows_tn(go, a, out_dtype=acc)                                     # [out, k_aug], fp32 sums
             d_weight.index_add_(1, g.cols, d_wa[:, :g.n_cols])
-            for k, n in enumerate(g.ncols_by_token):
-                d_weight[:, n] += d_wa[:, g.n_cols + k][:, None]
+            d_tokens.append(d_wa[:, g.n_cols:g.n_cols + Z])
             d_bias += d_wa[:, g.n_cols + Z]
+        # every constant column of a token receives that token's gradient: the adjoint of `weight @ membership`
+        d_weight.addmm_(torch.cat(d_tokens, 1), _token_matrix(plan, d_weight).t())
         d5 = d_lat.view(bs, C, Z, Hl, Wl)
         if d_lat.is_cuda and dt in (torch.float32, torch.bfloat16):
             from ..hipops import lattice_transpose

@@ -100,6 +100,14 @@ def _constant_pattern(z, h_in, w_in, device, dtype):
     return _PATTERN_CACHE[key]
 
 
+def _bias_through_taps(prev_bias, k):
+    """prev_bias [Ci] @ k [75,Ci,Co] -> [75,Co] (the bias-valued odd positions of the input seen through every tap).  As a
+    batched [1 x Ci] x [Ci x Co] product: ``torch.matmul`` of a vector with a 3-D tensor first makes a TRANSPOSED contiguous
+    copy of all 75 tap blocks (88 MB at 768 channels, 190 us -- a fifth of the weight-side time of a one-viewpoint step)."""
+    t, ci, _ = k.shape
+    return torch.bmm(prev_bias.view(1, 1, ci).expand(t, 1, ci).contiguous(), k).squeeze(1)
+
+
 def _layer0(e, k, bias):
     """All 75 taps hit data.  e [B,Z,H,W,C] channels-last -> E_1 [B,Z,H,W,Co]."""
     b, z, h, w, c = e.shape
@@ -305,7 +313,7 @@ class _LatticeLayer(torch.autograd.Function):
             o = _const_offset(pm, pn, ci)
             a3[:, :, o:o + _PW] = pat
         # stacked weight rows: 75 tap blocks | per class (K^T prev_bias | bias | 0) | zero rows
-        v = torch.matmul(prev_bias.to(dt), k)                                     # [75, Co]
+        v = _bias_through_taps(prev_bias.to(dt), k)                               # [75, Co]
         vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
         rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug, v.new_zeros(3 * _PW, co)])
         assert rows.shape[0] == total_rows
@@ -494,12 +502,54 @@ def _layer0_z4_plan(ci, device):
     return _L0Z4[key]
 
 
+_BLOCK_OFFSETS = {}
+
+
+def _block_offsets(kind, ci, co, device):
+    """int64 [75, 2] for ``ver_convt_weight_backward_blocks``: element offsets, inside the [rows, 2 Co] weight-gradient
+    buffer of a z-split layer, of the [Ci x Co] block that holds tap t's "lower half" / "upper half" gradient (-1: none).
+    kind 'l0': layer 0 (50 blocks (bb, cc, j) in a row); 'lat': the class-stacked buffer of ``_LatticeLayerZ4``."""
+    key = (kind, ci, co, str(device))
+    if key not in _BLOCK_OFFSETS:
+        off = np.full((75, 2), -1, dtype=np.int64)
+        ld = 2 * co
+
+        def put(t, half, row):
+            assert off[t, half] == -1
+            off[t, half] = row * ld + half * co
+        if kind == 'l0':
+            i = 0
+            for bb in range(5):
+                for cc in range(5):
+                    for j in range(2):
+                        put(((1 + j) * 5 + bb) * 5 + cc, 0, i * ci)
+                        put((j * 5 + bb) * 5 + cc, 1, i * ci)
+                        i += 1
+        else:
+            for (pm, pn), (roff, segs) in _class_rows_z4(ci).items():
+                for kind_, val, r0 in segs:
+                    if kind_ == 'b':
+                        dxi, dyi, j = _ORDER4[val]
+                        bb, cc = 2 * dyi - pm, 2 * dxi - pn
+                        put(((1 + j) * 5 + bb) * 5 + cc, 0, roff + r0)
+                        put((j * 5 + bb) * 5 + cc, 1, roff + r0)
+        a = np.arange(75) // 25
+        assert ((off[:, 0] >= 0) == (a >= 1)).all() and ((off[:, 1] >= 0) == (a <= 1)).all()
+        _BLOCK_OFFSETS[key] = torch.from_numpy(off).to(device)
+    return _BLOCK_OFFSETS[key]
+
+
 class _Layer0Z4(torch.autograd.Function):
     """First layer for Z = 4: every tap hits data.  x plain [B,4,H,W,Ci] -> z-split [B,2,H,W,2,Co]."""
 
     @staticmethod
-    def forward(ctx, x, k, bias):
+    def forward(ctx, x, k, bias, raw=None):
+        """``raw``: the fp32 ConvTranspose3d weight [Ci,Co,3,5,5] instead of its taps ``k`` (GPU training steps): the
+        backward then returns the weight's gradient straight from the GEMM's (``ver_convt_weight_backward_blocks``)."""
         b, z, h, w, ci = x.shape
+        if raw is not None:
+            k = _corr_weight(raw, x.dtype)
+        ctx.raw = raw is not None
         co = k.shape[-1]
         taps, offs, lo, hi = _layer0_z4_plan(ci, x.device)
         a_mat = x.new_empty(b * 2 * h * w, 50 * ci)
@@ -521,13 +571,17 @@ class _Layer0Z4(torch.autograd.Function):
             d_a = torch.mm(g, wmat.t())
         d_x = _scatter_z4(d_a, ZS_PLAIN, shape, taps, offs, ci, h, w)
         d_w = rows_tn(a_mat, g)                                                            # [50 ci, 2 co]
+        acc = torch.float64 if g.dtype == torch.float64 else torch.float32
+        d_b = g.sum(0, dtype=acc)
+        if ctx.raw:
+            from ..hipops import convt_weight_backward_blocks
+            d_raw = convt_weight_backward_blocks(d_w, _block_offsets('l0', ci, co, d_w.device), None, None, ci, co)
+            return d_x, None, (d_b[:co] + d_b[co:]).to(g.dtype), d_raw
         d_lo = d_w.new_zeros(75 * ci, co)
         d_hi = d_w.new_zeros(75 * ci, co)
         d_lo.index_copy_(0, lo, d_w[:, :co])
         d_hi.index_copy_(0, hi, d_w[:, co:])
-        acc = torch.float64 if g.dtype == torch.float64 else torch.float32
-        d_b = g.sum(0, dtype=acc)
-        return d_x, (d_lo + d_hi).view(75, ci, co), (d_b[:co] + d_b[co:]).to(g.dtype)
+        return d_x, (d_lo + d_hi).view(75, ci, co), (d_b[:co] + d_b[co:]).to(g.dtype), None
 
 
 def _block_order_z4():
@@ -551,6 +605,49 @@ def _const_offset4(pm, pn, c):
 
 
 _LAYER_PLAN4 = {}
+
+
+def _class_layout_z4():
+    b = lambda lo, hi: [('b', t) for t in range(lo, hi)]
+    g = _GROUP_START4
+    return {
+        (0, 0): [('c', (0, 0))] + b(g[0], g[1]) + [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[4]),
+        (1, 0): [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[3]),
+        (1, 1): [('c', (1, 1))] + b(g[2], g[3]),
+        (0, 1): b(g[2], g[4]) + [('c', (0, 1))],
+    }
+
+
+def _class_rows_z4(ci):
+    """{class: (first row of the class in the class-stacked [sum K_c, 2 Co] buffer (classes in _CLASSES order),
+    [(kind, val, first row inside the class)])}."""
+    layout = _class_layout_z4()
+    out, roff = {}, 0
+    for cls in _CLASSES:
+        segs, r = [], 0
+        for kind, val in layout[cls]:
+            segs.append((kind, val, r))
+            r += ci if kind == 'b' else _PW2
+        out[cls] = (roff, segs)
+        roff += r
+    return out
+
+
+_AUG_ROWS = {}
+
+
+def _aug_rows_z4(ci, device):
+    """Rows of the class-stacked buffer viewed as [2 sum K_c, Co] (row 2r + half) that hold the gradient of a class's own
+    constant block: [4 classes x (lower, upper)] x 80."""
+    key = (ci, str(device))
+    if key not in _AUG_ROWS:
+        idx = []
+        for cls, (roff, segs) in _class_rows_z4(ci).items():
+            r0 = next(r for kind, val, r in segs if kind == 'c' and val == cls)
+            idx.append(2 * (roff + r0 + np.arange(_PW)))                    # [P_lo] rows, lower-half columns
+            idx.append(2 * (roff + r0 + _PW + np.arange(_PW)) + 1)          # [P_hi] rows, upper-half columns
+        _AUG_ROWS[key] = torch.from_numpy(np.concatenate(idx).astype(np.int64)).to(device)
+    return _AUG_ROWS[key]
 
 
 def _layer_plan_z4(ci, device):
@@ -583,14 +680,7 @@ def _layer_plan_z4(ci, device):
             own = np.arange(n_data + p * _PW, n_data + (p + 1) * _PW)
             return (np.concatenate([own, zeros('lo', _PW)]), np.concatenate([zeros('hi', _PW), own]))
         return zeros('lo', _PW2), zeros('hi', _PW2)    # foreign constant block
-    b = lambda lo, hi: [('b', t) for t in range(lo, hi)]
-    g = _GROUP_START4
-    layout = {
-        (0, 0): [('c', (0, 0))] + b(g[0], g[1]) + [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[4]),
-        (1, 0): [('c', (1, 0))] + b(g[1], g[2]) + [('c', (1, 1))] + b(g[2], g[3]),
-        (1, 1): [('c', (1, 1))] + b(g[2], g[3]),
-        (0, 1): b(g[2], g[4]) + [('c', (0, 1))],
-    }
+    layout = _class_layout_z4()
     plan = {}
     for (pm, pn), segs in layout.items():
         first = segs[0]
@@ -612,9 +702,14 @@ def _layer_plan_z4(ci, device):
 class _LatticeLayerZ4(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, e, k, bias, prev_bias, planar):
+    def forward(ctx, e, k, bias, prev_bias, planar, raw=None):
         """e: z-split [B,2,H,W,2,C] or planar z-split [4,B,2,H/2,W/2,2,C]; k [75,Ci,Co]
-        -> planar z-split output [4,B,2,H,W,2,Co] (H, W = combined size of the input)."""
+        -> planar z-split output [4,B,2,H,W,2,Co] (H, W = combined size of the input).
+        ``raw``: the fp32 ConvTranspose3d weight [Ci,Co,3,5,5] instead of ``k`` (GPU training steps): the four class
+        weight gradients are then written into one stacked buffer and turned into the weight's gradient by ONE kernel."""
+        if raw is not None:
+            k = _corr_weight(raw, e.dtype)
+        ctx.raw = raw is not None
         if planar:
             _, b, _, hh, wh, _, ci = e.shape
             hc, wc = 2 * hh, 2 * wh
@@ -636,7 +731,7 @@ class _LatticeLayerZ4(torch.autograd.Function):
                 halves = pat.view(2, 2 * hc * wc, _PW)              # output z = zl (lower), zl + 2 (upper)
                 a3[:, :, o:o + _PW] = halves[0]
                 a3[:, :, o + _PW:o + _PW2] = halves[1]
-        v = torch.matmul(prev_bias.to(dt), k)                                     # [75, Co]
+        v = _bias_through_taps(prev_bias.to(dt), k)                               # [75, Co]
         vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
         rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug,
                           v.new_zeros(total_rows - 75 * ci - 4 * _PW, co)])
@@ -664,8 +759,13 @@ class _LatticeLayerZ4(torch.autograd.Function):
         g = grad_out.contiguous().view(4, m, 2 * co)
         d_a = a_mat.new_empty(m, kt)
         d_a[:, kt - _PW2:] = 0                                  # P01 is outside class (0,0)'s range
-        d_lo = a_mat.new_zeros(total_rows, co)
-        d_hi = a_mat.new_zeros(total_rows, co)
+        fused = ctx.raw
+        if fused:
+            class_rows = _class_rows_z4(ci)
+            stacked = a_mat.new_empty(sum(plan[cls][1] - plan[cls][0] for cls in _CLASSES), 2 * co)
+        else:
+            d_lo = a_mat.new_zeros(total_rows, co)
+            d_hi = a_mat.new_zeros(total_rows, co)
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, _ = plan[cls]
             w = ws[p]
@@ -676,13 +776,27 @@ class _LatticeLayerZ4(torch.autograd.Function):
                     torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
                 else:
                     torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
+            if fused:
+                r0 = class_rows[cls][0]
+                rows_tn(a_mat[:, c0:c1], g[p], out=stacked[r0:r0 + c1 - c0])
+                continue
             d_w = rows_tn(a_mat[:, c0:c1], g[p])
             d_lo.index_copy_(0, lo, d_w[:, :co])
             d_hi.index_copy_(0, hi, d_w[:, co:])
         d_e = _scatter_z4(d_a, layout, e_shape, taps, offs, ci, hc, wc)
+        acc = torch.float64 if dt == torch.float64 else torch.float32
+        if fused:
+            from ..hipops import convt_weight_backward_blocks
+            # own constant blocks of the four classes -> d(v | bias); every tap's two half gradients + prev_bias (x) d(v)
+            # -> the gradient of the ConvTranspose3d weight, in one pass over the stacked buffer
+            d_vaug = stacked.view(-1, co).index_select(0, _aug_rows_z4(ci, stacked.device)).view(8, _PW, co).sum(0, dtype=acc)
+            d_v = d_vaug[:75].to(dt)
+            pb = prev_bias.to(dt)
+            d_raw = convt_weight_backward_blocks(stacked, _block_offsets('lat', ci, co, stacked.device), pb, d_v, ci, co)
+            d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
+            return d_e, None, d_vaug[75].to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None, d_raw
         d_rows = d_lo + d_hi
         n_data = 75 * ci
-        acc = torch.float64 if dt == torch.float64 else torch.float32
         d_k = d_rows[:n_data].view(75, ci, co)
         d_vaug = d_rows[n_data:n_data + 4 * _PW].view(4, _PW, co).sum(0, dtype=acc)
         d_v = d_vaug[:75].to(dt)
@@ -690,7 +804,7 @@ class _LatticeLayerZ4(torch.autograd.Function):
         pb = prev_bias.to(dt)
         d_k = torch.addcmul(d_k, pb[None, :, None], d_v[:, None, :])
         d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
-        return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None
+        return d_e, d_k, d_bias.to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None, None
 
 
 def gemm_timed(name, m, k, n):
@@ -725,7 +839,7 @@ def mm_fwd(a, w, out=None, bias=None):
         return torch.addmm(b, a, w, out=out) if out is not None else torch.addmm(b, a, w)
 
 
-def rows_tn(a, g, out_dtype=None):
+def rows_tn(a, g, out_dtype=None, out=None):
     """a^T g for tall operands (a [M,K] may be a column range of a wider matrix, g [M,N]): the weight gradient of a GEMM
     layer, rows on the contraction axis.  bf16 GPU operands run on ``ver_wgrad_tn`` (csrc/ver_wgrad.hip: both
     operands streamed row-major into LDS, fragments through transposing LDS reads, fp32 partial sums over row chunks
@@ -736,9 +850,11 @@ def rows_tn(a, g, out_dtype=None):
         if g.stride(-1) != 1 or g.stride(0) % 8:
             g = g.contiguous()
         if wgrad_tn_supported(a, g):
-            return wgrad_tn(a, g, out_dtype=out_dtype)
-    out = torch.mm(a.t(), g)
-    return out if out_dtype is None else out.to(out_dtype)
+            return wgrad_tn(a, g, out_dtype=out_dtype if out is None else out.dtype, out=out)
+    if out is not None:                                  # (a row range of a stacked gradient buffer)
+        return torch.mm(a.t(), g, out=out) if out.dtype == a.dtype else out.copy_(torch.mm(a.t(), g))
+    res = torch.mm(a.t(), g)
+    return res if out_dtype is None else res.to(out_dtype)
 
 
 def _compute_dtype(x):
@@ -791,8 +907,16 @@ def upsample_lattice(x0, weights, biases):
     z-split [4,B,2,2H,2W,2,C] (``lattice_to_plain`` gives the channels-last [B,Z,4H,4W,C] lattice)."""
     dt = _compute_dtype(x0)
     e = _channels_last(x0, dt)
-    ks = [_corr_weight(w, dt) for w in weights]
     bs = [b.to(dt) for b in biases]
+    if e.shape[1] == 4 and e.is_cuda and dt in (torch.float32, torch.bfloat16) and \
+            all(w.is_cuda and w.dtype == torch.float32 for w in weights):
+        # GPU: the layers take the ConvTranspose3d weights themselves (taps made inside, weight gradient made from the class
+        # GEMMs' gradients by one kernel: the weight-side work of a step does not shrink with the batch)
+        e = _Layer0Z4.apply(e, None, bs[0], weights[0])
+        e = _LatticeLayerZ4.apply(e, None, bs[1], bs[0], False, weights[1])
+        e = _LatticeLayerZ4.apply(e, None, bs[2], bs[1], True, weights[2])
+        return e, bs[2]
+    ks = [_corr_weight(w, dt) for w in weights]
     if e.shape[1] == 4:                                   # bev_z = 4: z-split path (a third fewer FLOPs)
         e = _Layer0Z4.apply(e, ks[0], bs[0])
         e = _LatticeLayerZ4.apply(e, ks[1], bs[1], bs[0], False)

@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
@@ -22,7 +22,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
-           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_lattice_transpose', 'ver_run_gather',
+           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_lattice_transpose', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
@@ -476,6 +476,32 @@ class ConvTWeightFunction(Function):
 
 def convt_weight_taps(weight, dtype):
     return ConvTWeightFunction.apply(weight, dtype)
+
+
+def convt_weight_backward_blocks(blocks, block_offsets, prev_bias, grad_v, ci, co):
+    """ver_convt_weight_backward_blocks (no autograd): the fp32 gradient [Ci,Co,3,5,5] of a ConvTranspose3d weight from the
+    class-stacked weight gradients of a lattice layer: ``blocks`` [rows, ld] (fp32 or bf16, unit column stride); tap t is
+    the sum of the [Ci x Co] blocks at element offsets ``block_offsets[t]`` (int64 [75,2] on the device, -1 = none) plus
+    ``prev_bias[ci] * grad_v[t, co]`` (both in blocks' dtype, or both None)."""
+    src = _gpu(blocks, 'blocks')
+    if src.dim() != 2 or src.stride(1) != 1 or src.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('convt_weight_backward_blocks: blocks must be an fp32 / bf16 matrix with unit column stride')
+    off = _gpu(block_offsets, 'block_offsets')
+    if off.dtype != torch.int64 or tuple(off.shape) != (75, 2) or not off.is_contiguous():
+        raise TypeError('convt_weight_backward_blocks: block_offsets must be a contiguous int64 [75, 2]')
+    if (prev_bias is None) != (grad_v is None):
+        raise ValueError('convt_weight_backward_blocks: prev_bias and grad_v come together')
+    if prev_bias is not None:
+        prev_bias = _gpu(prev_bias, 'prev_bias').to(src.dtype).contiguous()
+        grad_v = _gpu(grad_v, 'grad_v').to(src.dtype).contiguous()
+        if prev_bias.numel() != ci or tuple(grad_v.shape) != (75, co):
+            raise ValueError('convt_weight_backward_blocks: prev_bias [Ci] and grad_v [75, Co] expected')
+    gw = torch.empty(ci, co, 3, 5, 5, dtype=torch.float32, device=src.device)
+    dt = 1 if src.dtype == torch.bfloat16 else 0
+    _launch('ver_convt_weight_backward_blocks', lambda: lib().ver_convt_weight_backward_blocks(
+        _p(src), _p(off), ctypes.c_long(src.stride(0)), _p(prev_bias) if prev_bias is not None else None,
+        _p(grad_v) if grad_v is not None else None, _p(gw), int(ci), int(co), dt, _stream()))
+    return gw
 
 
 PLAIN, PLANAR, ZSPLIT, PLANAR_ZSPLIT = 0, 1, 2, 3      # lattice layouts of ver_lattice_gather / _transpose
@@ -1112,10 +1138,10 @@ def wgrad_tn_supported(a, g):
             and g.shape[1] % 4 == 0)
 
 
-def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0):
+def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0, out=None):
     """``a.t() @ g`` for tall bf16 operands with the ROWS on the contraction axis (ver_wgrad_tn): a [M, Ka] (may be a
-    column range of a wider row-major matrix), g [M, N] -> [Ka, N] in ``out_dtype`` (default: a's dtype), fp32
-    accumulation over all rows.  The weight gradient of a lattice layer / of occ_proj (dense_heads/upsample.py::rows_tn)."""
+    column range of a wider row-major matrix), g [M, N] -> [Ka, N] in ``out_dtype`` (default: a's dtype; ``out``: a matrix
+    of that dtype to write into, e.g. a row range of a stacked buffer), fp32 accumulation over all rows.  The weight gradient of a lattice layer / of occ_proj (dense_heads/upsample.py::rows_tn)."""
     if not wgrad_tn_supported(a, g):
         raise RuntimeError('wgrad_tn: unsupported operands %s %s / %s %s' % (tuple(a.shape), a.stride(), tuple(g.shape), g.stride()))
     m, ka = a.shape
@@ -1128,10 +1154,13 @@ def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0):
         splits = L.ver_wgrad_tn_splits(ctypes.c_long(m), ka, n)
     nbytes = L.ver_wgrad_tn_workspace(ctypes.c_long(m), ka, n, splits)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
-    out = torch.empty(ka, n, dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(ka, n, dtype=out_dtype, device=a.device)
+    elif not (out.is_cuda and out.shape == (ka, n) and out.dtype == out_dtype and out.stride(1) == 1):
+        raise RuntimeError('wgrad_tn: out must be a [Ka, N] GPU matrix of out_dtype with unit column stride')
     _launch('ver_wgrad_tn', lambda: L.ver_wgrad_tn(
         _p(a), ctypes.c_long(a.stride(0)), _p(g), ctypes.c_long(g.stride(0)), ctypes.c_long(m), ka, n, _p(out),
-        ctypes.c_long(n), 1 if out_dtype == torch.bfloat16 else 0, int(splits), int(flags), _p(ws), ctypes.c_long(nbytes),
+        ctypes.c_long(out.stride(0)), 1 if out_dtype == torch.bfloat16 else 0, int(splits), int(flags), _p(ws), ctypes.c_long(nbytes),
         _stream()), meta=dict(flops=2.0 * m * ka * n))
     return out
 

@@ -265,7 +265,8 @@ int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pa
  *       GEMMs (no reference counterpart: the reference's ConvTranspose3d backward, head:251-258 through autograd): tap t
  *       is the fp32 sum of up to two [ci x co] blocks of `blocks` (row pitch `ld` elements, `dtype`) at element offsets
  *       block_offsets[2t], block_offsets[2t+1] (device int64 [75][2], -1 = none) plus prev_bias[ci] * grad_v[t*co + co']
- *       (both `dtype`, or both NULL) -> grad_weight f32 [ci*co][75], taps flipped as above. */
+ *       (both `dtype`, or both NULL) -> grad_weight f32 [ci*co][75], taps flipped as above.  bf16 with even co and ld:
+ *       the offsets must be even too (4-byte loads; the layers' offsets row * ld + {0, co} are). */
 int ver_convt_weight_backward_blocks(const void* blocks, const long* block_offsets, long ld, const void* prev_bias,
                                      const void* grad_v, float* grad_weight, int ci, int co, int dtype, void* stream);
 int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,

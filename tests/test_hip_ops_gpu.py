@@ -651,15 +651,15 @@ def test_convt_weight_taps_and_lattice_transpose(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('kind', ['l0', 'lat'])
-def test_convt_weight_gradient_from_class_blocks(kind, dtype):
+@pytest.mark.parametrize('kind,ci,co', [('l0', 24, 40), ('lat', 24, 40), ('lat', 5, 41), ('lat', 3, 130)])
+def test_convt_weight_gradient_from_class_blocks(kind, ci, co, dtype):
     """ver_convt_weight_backward_blocks against the sequence of torch ops it replaces in the z-split layers' backward
     (dense_heads/upsample.py): per class two indexed copies of the half gradients into zero-filled [75 Ci, Co] buffers,
     their sum, + prev_bias (x) d(v), the adjoint of the tap flip.  fp32 sums of at most three terms: exact up to the
     rounding of the bf16 intermediates the torch sequence keeps (compared in fp64 with those intermediates left out)."""
     hip, up = pkg('hipops'), pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(31)
-    ci, co = 24, 40                                  # (Co not a multiple of the kernel's 64-pair tile)
+    # (Co = 40, 130: the two-pairs-per-lane bf16 kernel with ragged last workgroups; Co = 41: the element-wise one)
     if kind == 'l0':
         _, _, lo, hi = up._layer0_z4_plan(ci, 'cpu')
         rows = 50 * ci

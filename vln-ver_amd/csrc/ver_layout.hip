@@ -98,6 +98,50 @@ __global__ __launch_bounds__(256) void k_convt_weight_bwd_blocks(const void* __r
     for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
 }
 
+// bf16 form for even Co / ld: a lane owns TWO adjacent (ci, co) pairs (4-byte loads, 256 B per wavefront and tap), a
+// workgroup 128 pairs; the pair -> (ci, co) division is made once per lane.
+__global__ __launch_bounds__(256) void k_convt_weight_bwd_blocks2(const uint16_t* __restrict__ src, const long* __restrict__ off,
+                                                                  long ld, const uint16_t* __restrict__ pb,
+                                                                  const uint16_t* __restrict__ dv, float* __restrict__ dw,
+                                                                  long P, int Co) {
+    constexpr int kP2 = 2 * kPairs;
+    __shared__ float tile[kP2 * kTaps + 1];
+    __shared__ long offs[2 * kTaps];
+    const long p0 = (long)blockIdx.x * kP2;
+    const int np = (int)((P - p0) < kP2 ? (P - p0) : kP2);
+    if (threadIdx.x < 2 * kTaps) offs[threadIdx.x] = off[threadIdx.x];
+    __syncthreads();
+    const int p = 2 * (threadIdx.x & 63);
+    if (p < np) {                                         // (P is even: both pairs of a lane exist together)
+        const long pair = p0 + p;
+        const long ci = pair / Co, co = pair - ci * Co;   // co even, co + 1 < Co
+        const long row = ci * ld + co;
+        const float b = pb ? __uint_as_float((uint32_t)pb[ci] << 16) : 0.f;
+        for (int t = threadIdx.x >> 6; t < kTaps; t += 4) {
+            float v0 = 0.f, v1 = 0.f;
+            const long o0 = offs[2 * t], o1 = offs[2 * t + 1];
+            if (o0 >= 0) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(src + o0 + row);
+                v0 += __uint_as_float(u << 16), v1 += __uint_as_float(u & 0xffff0000u);
+            }
+            if (o1 >= 0) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(src + o1 + row);
+                v0 += __uint_as_float(u << 16), v1 += __uint_as_float(u & 0xffff0000u);
+            }
+            if (pb) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(dv + (long)t * Co + co);
+                v0 += b * __uint_as_float(u << 16), v1 += b * __uint_as_float(u & 0xffff0000u);
+            }
+            const int a = t / 25, bb = (t / 5) % 5, c = t % 5;
+            const int f = ((2 - a) * 5 + (4 - bb)) * 5 + (4 - c);
+            tile[p * kTaps + f] = v0;
+            tile[(p + 1) * kTaps + f] = v1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
+}
+
 // ---- lattice <-> channel-first rows.  One workgroup = one (b, z, y) row of W positions x 128 channels.
 namespace {
 constexpr int kCh = 128;
@@ -314,7 +358,12 @@ extern "C" int ver_convt_weight_backward_blocks(const void* blocks, const long* 
     if (pairs == 0) return VER_OK;
     VER_REQUIRE(blocks && block_offsets && grad_weight, VER_EINVAL, "ver_convt_weight_backward_blocks: null pointer argument");
     const unsigned nb = (unsigned)((pairs + kPairs - 1) / kPairs);
-    if (dtype == VER_BF16)
+    if (dtype == VER_BF16 && co % 2 == 0 && ld % 2 == 0 && ((uintptr_t)blocks & 3) == 0 && ((uintptr_t)grad_v & 3) == 0)
+        // (even Co and pitch: every block offset the layers hand over -- row * ld + {0, co} -- is even as well)
+        hipLaunchKernelGGL(k_convt_weight_bwd_blocks2, dim3((unsigned)((pairs + 2 * kPairs - 1) / (2 * kPairs))), dim3(256), 0,
+                           (hipStream_t)stream, (const uint16_t*)blocks, block_offsets, ld, (const uint16_t*)prev_bias,
+                           (const uint16_t*)grad_v, grad_weight, pairs, co);
+    else if (dtype == VER_BF16)
         hipLaunchKernelGGL(k_convt_weight_bwd_blocks<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, blocks, block_offsets,
                            ld, prev_bias, grad_v, grad_weight, pairs, co);
     else

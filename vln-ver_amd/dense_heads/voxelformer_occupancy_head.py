@@ -267,7 +267,10 @@ class VoxelFormerOccupancyHead(BaseModule):
                         # MLP kernel loads then have zero mean by construction and its LayerNorm skips the mean pass
                         # (a quarter of the forward kernel's VALU work); autograd maps the gradients back through P
                         w1c, b1c = self._centered(l1.weight.float(), l1.bias.float())
-                        w_proj = torch.matmul(w1c, w_proj.float().view(self.occ_zdim, self.occ_dims, -1)).view_as(w_proj)
+                        # (a batched product over the 35 z-slices: ``matmul`` of a matrix with a 3-D tensor goes through
+                        #  transposed contiguous copies of the whole [35, 128, 3072] weight, forward and backward)
+                        w_proj = torch.bmm(w1c.expand(self.occ_zdim, *w1c.shape).contiguous(),
+                                           w_proj.float().view(self.occ_zdim, self.occ_dims, -1)).view_as(w_proj)
                         b_proj = torch.addmm(b1c, b_proj.float().view(self.occ_zdim, self.occ_dims), w1c.t()).view(-1)
                 res = occ_proj_from_lattice(e, convs[-1].bias, w_proj, b_proj)
                 if res is not None:

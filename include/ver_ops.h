@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 25
+#define VER_ABI_VERSION 26
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -271,6 +271,15 @@ int ver_convt_weight_backward_blocks(const void* blocks, const long* block_offse
                                      const void* grad_v, float* grad_weight, int ci, int co, int dtype, void* stream);
 int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
                           int C, int layout, int to_channel_first, int dtype, void* stream);
+/*   ver_lattice_rows : ver_lattice_transpose and ver_run_gather / _scatter (below) in ONE pass, bf16: the lattice
+ *       (channels-last, one of the four layouts) <-> the gathered operand rows of occ_proj's GEMMs, when the runs of the
+ *       raw .view (head:564) tile the flat channel-first lattice periodically: flat = k*quarter + row*period + off, the
+ *       segment j with seg_off[j] <= off < seg_off[j] + seg_len[j] (host tables, nseg <= 8, the segments cover the
+ *       period in order) is a pattern group whose rows live at rows[seg_base[j] + (b*seg_rows[j] + row)*seg_pitch[j]
+ *       + k*seg_len[j] + (off - seg_off[j])] (elements).  to_rows != 0: the lattice is read; else it is written. */
+int ver_lattice_rows(void* channels_last, void* rows, long quarter, int period, int nseg, const int* seg_off,
+                     const int* seg_len, const long* seg_base, const int* seg_pitch, const int* seg_rows, int B, int Z,
+                     int H, int W, int C, int layout, int to_rows, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused LayerNorm(128) + ReLU of the occupancy MLP (`occ_branches`, layers 1-2 and 4-5:

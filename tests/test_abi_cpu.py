@@ -140,6 +140,23 @@ def test_argument_validation_of_the_gemm_entry_points():
     assert rc == -1 and b'come together' in lib.ver_last_error()
     rc = lib.ver_convt_weight_backward_blocks(*blk(None, buf, None, None, buf))
     assert rc == -1 and b'null' in lib.ver_last_error()
+    # ver_lattice_rows (ABI 26): the periodic run tables are checked on the host (order, coverage, alignment, row count)
+    I, LL = ctypes.c_int * 2, ctypes.c_long * 2
+    rows = lambda cl, buf_, off=(0, 8), ln=(8, 8), base=(0, 4096), pitch=(32, 32), nrows=(4, 4), quarter=64, period=16, B=1, dt=1, C=8, W=4: (
+        cl, buf_, L(quarter), period, 2, I(*off), I(*ln), LL(*base), I(*pitch), I(*nrows), B, 2, 4, W, C, 0, 1, dt, None)
+    assert lib.ver_lattice_rows(*rows(None, None, B=0)) == 0                 # C*Z*H*W = 8*2*4*4 = 256 = 4 quarters of 64
+    rc = lib.ver_lattice_rows(*rows(buf, buf, dt=0))
+    assert rc == -2 and b'bf16' in lib.ver_last_error()
+    rc = lib.ver_lattice_rows(*rows(buf, buf, off=(0, 12)))
+    assert rc == -1 and b'segment 1' in lib.ver_last_error()
+    rc = lib.ver_lattice_rows(*rows(buf, buf, ln=(8, 4)))
+    assert rc == -1 and b'cover' in lib.ver_last_error()
+    rc = lib.ver_lattice_rows(*rows(buf, buf, nrows=(4, 3)))
+    assert rc == -1 and b'segment 1' in lib.ver_last_error()
+    rc = lib.ver_lattice_rows(*rows(buf, buf, quarter=60))
+    assert rc == -1 and b'quarter' in lib.ver_last_error()
+    rc = lib.ver_lattice_rows(*rows(None, buf))
+    assert rc == -1 and b'null' in lib.ver_last_error()
     # the MLP entries with the saved statistics: the rstd pointer must be 8-byte aligned and N < 2^28
     off = ctypes.cast(ctypes.addressof(buf) + 4, ctypes.c_void_p)
     rc = lib.ver_occ_mlp_forward_stats(buf, buf, buf, buf, off, L(4), 128, 16, ctypes.c_float(1e-5), 2, None)

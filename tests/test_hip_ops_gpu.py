@@ -694,6 +694,68 @@ def test_convt_weight_gradient_from_class_blocks(kind, ci, co, dtype):
         assert close(aug, want_aug, atol=1e-9, rtol=1e-9)
 
 
+@pytest.mark.parametrize('layout', [0, 1, 2, 3])
+def test_lattice_rows_equals_transpose_plus_run_copies(layout):
+    """ver_lattice_rows (bf16 lattice <-> the operand rows of all occ_proj pattern groups in one pass) against the two
+    passes it replaces, ver_lattice_transpose + ver_run_gather / ver_run_scatter, on the vocc.py geometry (768 channels,
+    4 x 60 x 60 lattice, 5 groups, period 960): pure data movement, bit-exact both ways, rows of other samples and the
+    augmentation columns untouched."""
+    hip, ups, opl = pkg('hipops'), pkg('dense_heads.upsample'), pkg('dense_heads.occ_proj_lattice')
+    C, Z, Hl, Wl, bs = 768, 4, 60, 60, 2
+    plan = opl.get_plan(C, Z, 2 * Hl, 2 * Wl, torch.device(DEV))
+    assert plan is not None and plan.row_map is not None and plan.row_map['period'] == 960
+    gen = torch.Generator(device='cpu').manual_seed(41)
+    plain = torch.randn(bs, Z, Hl, Wl, C, generator=gen).bfloat16()
+    src = ups._from_plain(plain, layout).contiguous().to(DEV)
+    L = C * Z * Hl * Wl
+    row_map, spans, total = opl._row_map_for(plan, bs)
+    # forward: lattice -> rows
+    lat = torch.empty(bs, (L + C + 2 + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV)
+    hip.lattice_transpose(src, lat, (Hl, Wl), layout, True)
+    lat[:, L:] = 0
+    buf = torch.full((total,), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip.lattice_rows(src, buf, row_map, (Hl, Wl), layout, True)
+    for g, (b0, n) in zip(plan.groups, spans):
+        want = torch.empty(bs * g.n_rows, g.k_aug, dtype=torch.bfloat16, device=DEV)
+        hip.run_gather(lat, g.run_start, g.aug_idx, want, g.n_rows, g.run_len)
+        got = buf[b0:b0 + n].view(bs * g.n_rows, g.k_aug)
+        assert torch.equal(got[:, :g.n_cols], want[:, :g.n_cols])
+        assert bool((got[:, g.n_cols:] == 7.0).all())                     # augmentation columns are not this kernel's
+    # backward: rows -> lattice
+    rows = torch.randn(total, generator=gen).bfloat16().to(DEV)
+    d_lat = torch.empty(bs, L, dtype=torch.bfloat16, device=DEV)
+    for g, (b0, n) in zip(plan.groups, spans):
+        hip.run_scatter(rows[b0:b0 + n].view(bs * g.n_rows, g.k_aug), d_lat, g.run_start, g.n_rows, g.run_len)
+    want_e = torch.empty_like(src)
+    hip.lattice_transpose(want_e, d_lat, (Hl, Wl), layout, False)
+    got_e = torch.empty_like(src)
+    hip.lattice_rows(got_e, rows, row_map, (Hl, Wl), layout, False)
+    assert torch.equal(got_e, want_e)
+
+
+def test_occ_proj_lattice_fused_rows_path_is_bit_identical(monkeypatch):
+    """``occ_proj_from_lattice`` in bf16 with the one-pass lattice <-> rows kernel (default) and with the channel-first
+    copy + run copies (VER_LATTICE_ROWS=0): the same operands reach the same GEMMs -- outputs and every gradient equal."""
+    opl = pkg('dense_heads.occ_proj_lattice')
+    gen = torch.Generator(device='cpu').manual_seed(43)
+    C, Z, hh, wh = 768, 4, 30, 30
+    e0 = (torch.randn(4, 1, 2, hh, wh, 2, C, generator=gen) * 0.5).bfloat16().to(DEV)
+    up_bias = torch.randn(C, generator=gen).to(DEV)
+    weight = (torch.randn(4480, Z * C, generator=gen) * 0.02).to(DEV)
+    bias = torch.randn(4480, generator=gen).to(DEV)
+    res = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('VER_LATTICE_ROWS', mode)
+        e, ub, w, b = (t.clone().requires_grad_(True) for t in (e0, up_bias, weight, bias))
+        rows, plan = opl.occ_proj_from_lattice(e, ub, w, b)
+        g = torch.randn(rows.shape, generator=torch.Generator(device='cpu').manual_seed(5)).bfloat16().to(DEV)
+        rows.backward(g)
+        res[mode] = (rows.detach(), e.grad, ub.grad, w.grad, b.grad)
+    assert plan.row_map is not None
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
+
+
 def test_upsample_on_gpu_matches_conv_transpose():
     up = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(6)

@@ -318,6 +318,99 @@ __global__ __launch_bounds__(256) void k_lattice_transpose_v(T* __restrict__ cl,
     }
 }
 
+// ---- lattice (channels-last) <-> gathered operand rows of occ_proj, in ONE pass (bf16).
+// The raw .view of the reference (head:564) makes every operand row R runs of the channel-first lattice, and for the
+// geometries of interest the runs tile the flat lattice PERIODICALLY: flat index i = k * quarter + row * period + off, the
+// segment [seg_off, seg_off + seg_len) that holds `off` names the pattern group, and the element sits at column
+// k * seg_len + (off - seg_off) of that group's row (b * seg_rows + row).  k_lattice_transpose_v's channel-first side is a
+// contiguous run per channel; here the same 8-byte pieces go straight to / come straight from the operand rows, so the
+// channel-first copy of the lattice (1.06 GB per direction at 192 viewpoints) is never written or read.
+namespace {
+struct RowMap {
+    long quarter;
+    int period, nseg;
+    int seg_off[8], seg_len[8], seg_pitch[8], seg_rows[8];
+    long seg_base[8];
+};
+__device__ __forceinline__ long row_map_index(const RowMap& m, int b, unsigned flat) {
+    const unsigned k = flat / (unsigned)m.quarter;
+    const unsigned rem = flat - k * (unsigned)m.quarter;
+    const unsigned row = rem / (unsigned)m.period;
+    const int off = (int)(rem - row * (unsigned)m.period);
+    // (constant indices into the kernel-argument tables + selects: a lane-dependent index would put the struct in scratch)
+    int so = m.seg_off[0], sl = m.seg_len[0], sp = m.seg_pitch[0], sr = m.seg_rows[0];
+    long sb = m.seg_base[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+        if (j < m.nseg && off >= m.seg_off[j]) so = m.seg_off[j], sl = m.seg_len[j], sp = m.seg_pitch[j], sr = m.seg_rows[j], sb = m.seg_base[j];
+    return sb + ((long)b * sr + row) * sp + (long)k * sl + (off - so);
+}
+}  // namespace
+
+template <int LAYOUT, bool TO_ROWS, int CH>
+__global__ __launch_bounds__(256) void k_lattice_rows(uint16_t* __restrict__ cl, uint16_t* __restrict__ rows, RowMap map,
+                                                      int B, int Z, int H, int W, int C, int R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int VC = 8, VX = 4;
+    const int P = R * W;
+    const int ncb = (C + CH - 1) / CH;
+    int r = (int)(blockIdx.x / ncb);
+    const int hr = H / R;
+    const int y0 = (r % hr) * R;
+    r /= hr;
+    const int z = r % Z;
+    const int b = r / Z;
+    const int c0 = (int)(blockIdx.x % ncb) * CH;
+    const int nc = (C - c0) < CH ? (C - c0) : CH;
+    const int ncv = nc / VC, npv = P / VX;
+    unsigned* tile32 = reinterpret_cast<unsigned*>(smem);        // [CH][P / 2 (+ pad)] dwords of two neighbouring positions
+    const int P2 = P >> 1, wp32 = (P2 + 2) & ~1;
+    if (TO_ROWS) {
+        for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
+            const int p2 = i / ncv, cv = i - p2 * ncv;
+            const int p = 2 * p2, yy = p / W, x = p - yy * W;
+            const uint4 a = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC);
+            const uint4 q = *reinterpret_cast<const uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x + 1, B, Z, H, W) * C + c0 + cv * VC);
+            const unsigned aw[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.x, q.y, q.z, q.w};
+            unsigned* dst = tile32 + (cv * VC) * wp32 + p2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dst[(2 * k) * wp32] = __builtin_amdgcn_perm(qw[k], aw[k], 0x05040100u);
+                dst[(2 * k + 1) * wp32] = __builtin_amdgcn_perm(qw[k], aw[k], 0x07060302u);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nc * npv; i += 256) {
+            const int c = i / npv, pv = i - c * npv;
+            const uint2 u = *reinterpret_cast<const uint2*>(tile32 + c * wp32 + 2 * pv);
+            const unsigned flat = (unsigned)((((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
+            *reinterpret_cast<uint2*>(rows + row_map_index(map, b, flat)) = u;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nc * npv; i += 256) {
+            const int c = i / npv, pv = i - c * npv;
+            const unsigned flat = (unsigned)((((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
+            *reinterpret_cast<uint2*>(tile32 + c * wp32 + 2 * pv) = *reinterpret_cast<const uint2*>(rows + row_map_index(map, b, flat));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
+            const int p2 = i / ncv, cv = i - p2 * ncv;
+            const int p = 2 * p2, yy = p / W, x = p - yy * W;
+            const unsigned* srcw = tile32 + (cv * VC) * wp32 + p2;
+            unsigned d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = srcw[j * wp32];
+            uint4 a, q;
+            a.x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100u); q.x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302u);
+            a.y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100u); q.y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302u);
+            a.z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100u); q.z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302u);
+            a.w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100u); q.w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302u);
+            *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x, B, Z, H, W) * C + c0 + cv * VC) = a;
+            *reinterpret_cast<uint4*>(cl + cl_index<LAYOUT>(b, z, y0 + yy, x + 1, B, Z, H, W) * C + c0 + cv * VC) = q;
+        }
+    }
+}
+
 extern "C" int ver_convt_weight_forward(const float* weight, void* taps, long pairs, int dtype, void* stream) {
     VER_REQUIRE(pairs >= 0, VER_EINVAL, "ver_convt_weight_forward: negative size");
     VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_convt_weight_forward: dtype %d", dtype);
@@ -443,6 +536,65 @@ extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, l
 #undef VER_TR_L
 #undef VER_TR
     return ver_check_launch("ver_lattice_transpose");
+}
+
+extern "C" int ver_lattice_rows(void* channels_last, void* rows, long quarter, int period, int nseg, const int* seg_off,
+                                const int* seg_len, const long* seg_base, const int* seg_pitch, const int* seg_rows, int B,
+                                int Z, int H, int W, int C, int layout, int to_rows, int dtype, void* stream) {
+    VER_REQUIRE(B >= 0 && Z > 0 && H > 0 && W > 0 && C > 0, VER_EINVAL, "ver_lattice_rows: bad sizes");
+    VER_REQUIRE(dtype == VER_BF16, VER_EUNSUPPORTED, "ver_lattice_rows: bf16 lattices only (dtype %d)", dtype);
+    VER_REQUIRE(layout >= 0 && layout <= 3, VER_EINVAL, "ver_lattice_rows: layout %d", layout);
+    VER_REQUIRE(!(layout & 1) || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_lattice_rows: planar needs even H, W");
+    VER_REQUIRE(layout < 2 || Z == 4, VER_EUNSUPPORTED, "ver_lattice_rows: the z-split layouts are built for 4 z-layers");
+    VER_REQUIRE(nseg >= 1 && nseg <= 8 && seg_off && seg_len && seg_base && seg_pitch && seg_rows, VER_EINVAL,
+                "ver_lattice_rows: 1..8 segments with their tables");
+    const long L = (long)C * Z * H * W;
+    VER_REQUIRE(L < (1L << 31) && quarter > 0 && period > 0 && L % quarter == 0 && quarter % period == 0, VER_EINVAL,
+                "ver_lattice_rows: lattice of %ld elements, quarter %ld, period %d", L, quarter, period);
+    VER_REQUIRE(W % 4 == 0 && C % 8 == 0 && ((long)Z * H * W) % 4 == 0, VER_EUNSUPPORTED,
+                "ver_lattice_rows: W %% 4, C %% 8 (8-byte pieces along W, 16-byte channel vectors)");
+    RowMap m;
+    m.quarter = quarter, m.period = period, m.nseg = nseg;
+    int covered = 0;
+    for (int j = 0; j < 8; ++j) {
+        const bool on = j < nseg;
+        m.seg_off[j] = on ? seg_off[j] : 0, m.seg_len[j] = on ? seg_len[j] : 0, m.seg_pitch[j] = on ? seg_pitch[j] : 0;
+        m.seg_rows[j] = on ? seg_rows[j] : 0, m.seg_base[j] = on ? seg_base[j] : 0;
+        if (!on) continue;
+        VER_REQUIRE(seg_off[j] == covered && seg_len[j] > 0 && seg_len[j] % 4 == 0 && seg_pitch[j] % 4 == 0 && seg_base[j] % 4 == 0 &&
+                        seg_base[j] >= 0 && (long)seg_rows[j] * period == quarter && (L / quarter) * seg_len[j] <= seg_pitch[j],
+                    VER_EINVAL, "ver_lattice_rows: segment %d (offset %d, length %d, pitch %d, rows %d)", j, seg_off[j], seg_len[j],
+                    seg_pitch[j], seg_rows[j]);
+        covered += seg_len[j];
+    }
+    VER_REQUIRE(covered == period, VER_EINVAL, "ver_lattice_rows: the segments cover %d of the period %d", covered, period);
+    if (B == 0) return VER_OK;
+    VER_REQUIRE(channels_last && rows, VER_EINVAL, "ver_lattice_rows: null pointer argument");
+    VER_REQUIRE(((uintptr_t)channels_last & 15) == 0 && ((uintptr_t)rows & 7) == 0, VER_EINVAL, "ver_lattice_rows: alignment");
+    constexpr int kChV = 32;
+    VER_REQUIRE((size_t)kCh * ((size_t)W + 4) * 2 <= 64 * 1024, VER_EUNSUPPORTED, "ver_lattice_rows: W = %d too wide", W);
+    int R = 1;                                   // (tile shapes as in ver_lattice_transpose: long runs on the WRITE side)
+    if (to_rows)
+        for (int cand = 1; cand <= H; ++cand)
+            if (H % cand == 0 && (size_t)kChV * ((size_t)cand * W + 4) * 2 <= 48 * 1024 && cand * W <= 1200) R = cand;
+    const int chv = to_rows ? kChV : kCh;
+    const size_t lds = (size_t)chv * ((size_t)R * W + 4) * 2;
+    const dim3 grid((unsigned)((long)B * Z * (H / R) * ((C + chv - 1) / chv)));
+    hipStream_t st = (hipStream_t)stream;
+#define VER_LR(L_, TR)                                                                                                       \
+    hipLaunchKernelGGL((k_lattice_rows<L_, TR, (TR ? kChV : kCh)>), grid, dim3(256), lds, st, (uint16_t*)channels_last,       \
+                       (uint16_t*)rows, m, B, Z, H, W, C, R)
+#define VER_LR_L(TR)                         \
+    do {                                     \
+        if (layout == 0) VER_LR(0, TR);      \
+        else if (layout == 1) VER_LR(1, TR); \
+        else if (layout == 2) VER_LR(2, TR); \
+        else VER_LR(3, TR);                  \
+    } while (0)
+    if (to_rows) VER_LR_L(true); else VER_LR_L(false);
+#undef VER_LR_L
+#undef VER_LR
+    return ver_check_launch("ver_lattice_rows");
 }
 
 

@@ -25,6 +25,8 @@ accumulation over slices.  ``occ_branches`` is row-wise and runs in that order; 
 brings the 16-wide logits into the reference's voxel order.  The index tables are built once per
 geometry by brute force from the definition of the two raw views, so they hold for any (C,Z,H,W).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -122,6 +124,7 @@ def _device_plan(plan, device):
                 d.run_len = rl
                 d.run_start = torch.from_numpy(np.ascontiguousarray(g.gather[:, ::rl]).astype(np.int32)).to(device)
                 d.aug_idx = torch.from_numpy(np.ascontiguousarray(idx[:, d.n_cols:]).astype(np.int32)).to(device)
+        d.aug_tail = t(idx[:, d.n_cols:].reshape(-1) - L)          # the same columns as indices into [up_bias (C), 1, 0]
         d.cols = t(g.cols)
         d.ncols_by_token = [t(n) for n in g.ncols_by_token]
         d.chan = t(g.chan.reshape(-1))
@@ -130,7 +133,57 @@ def _device_plan(plan, device):
         off += d.n_rows
         dev.groups.append(d)
     dev._row_index = {}
+    dev.row_map = _periodic_row_map(plan, dev)
     return dev
+
+
+def _periodic_row_map(plan, dev):
+    """The run structure as ``ver_lattice_rows`` wants it, or None: every row of every group is R runs of one length, the
+    k-th run of row r of group g starts at flat lattice index k * (L / R) + r * period + offset_g, and the groups' runs tile
+    a period in order (vocc.py: 5 groups, runs of 204 | 204 | 192 | 180 | 180 = period 960, 2 880 rows per group)."""
+    L = plan.lattice_size
+    gs = list(zip(plan.groups, dev.groups))
+    if not gs or any(not d.run_len for _, d in gs) or L >= 2 ** 31:
+        return None
+    R = {d.n_cols // d.run_len for _, d in gs}
+    n_rows = {d.n_rows for _, d in gs}
+    if len(R) != 1 or len(n_rows) != 1:
+        return None
+    R, n_rows = R.pop(), n_rows.pop()
+    period = sum(d.run_len for _, d in gs)
+    if R > 8 or L % R or L // R != n_rows * period or len(gs) > 8:
+        return None
+    quarter = L // R
+    segs = []
+    for gi, (g, d) in enumerate(gs):
+        off = int(g.gather[0, 0])
+        want = (np.arange(R)[None, :, None] * quarter + np.arange(n_rows)[:, None, None] * period + off
+                + np.arange(d.run_len)[None, None, :]).reshape(n_rows, R * d.run_len)
+        if off >= period or off % 4 or d.run_len % 4 or not np.array_equal(g.gather, want):
+            return None
+        segs.append((off, d.run_len, gi))
+    segs.sort()
+    pos = 0
+    for off, rl, _ in segs:
+        if off != pos:
+            return None
+        pos += rl
+    return dict(quarter=quarter, period=period, n_rows=n_rows, seg_off=[s_[0] for s_ in segs], seg_len=[s_[1] for s_ in segs],
+                seg_group=[s_[2] for s_ in segs])
+
+
+def _row_map_for(plan, bs):
+    """(row map with the element offsets of a ``bs``-sample operand buffer, [(first element, elements) per group], total)."""
+    spans, total = [], 0
+    for d in plan.groups:
+        n = bs * d.n_rows * d.k_aug
+        spans.append((total, n))
+        total += n
+    rm = dict(plan.row_map)
+    rm['seg_base'] = [spans[gi][0] for gi in rm['seg_group']]
+    rm['seg_pitch'] = [plan.groups[gi].k_aug for gi in rm['seg_group']]
+    rm['seg_rows'] = [plan.groups[gi].n_rows for gi in rm['seg_group']]
+    return rm, spans, total
 
 
 def get_plan(C, Z, Hf, Wf, device):
@@ -190,18 +243,28 @@ class _OccProjLattice(torch.autograd.Function):
         dt = e.dtype
         out_dim = weight.shape[0]
         L = plan.lattice_size
-        lat = torch.empty(bs, (L + C + 2 + 7) // 8 * 8, dtype=dt, device=e.device)       # (rows 16-byte aligned)
-        lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                                # channel-first lattice
         use_hip = e.is_cuda and dt in (torch.float32, torch.bfloat16)
-        if use_hip:
-            from ..hipops import lattice_transpose
-            lattice_transpose(e.contiguous(), lat, (Hl, Wl), layout, True)
+        # bf16 on the GPU with the periodic run structure: the lattice goes straight into the operand rows of all groups
+        # (ver_lattice_rows) -- the channel-first copy of it (1.06 GB at 192 viewpoints) is neither written nor read
+        fused = use_hip and dt == torch.bfloat16 and plan.row_map is not None and os.environ.get('VER_LATTICE_ROWS', '1') == '1'
+        if fused:
+            from ..hipops import lattice_rows
+            row_map, spans, total = _row_map_for(plan, bs)
+            rows_buf = torch.empty(total, dtype=dt, device=e.device)
+            lattice_rows(e.contiguous(), rows_buf, row_map, (Hl, Wl), layout, True)
+            tail = torch.cat([up_bias.to(dt), torch.ones(1, dtype=dt, device=e.device), torch.zeros(1, dtype=dt, device=e.device)])
         else:
-            from .upsample import _to_plain
-            lat5.copy_(_to_plain(e, layout).permute(0, 4, 1, 2, 3))
-        lat[:, L:L + C] = up_bias.to(dt)
-        lat[:, L + C] = 1
-        lat[:, L + C + 1] = 0
+            lat = torch.empty(bs, (L + C + 2 + 7) // 8 * 8, dtype=dt, device=e.device)   # (rows 16-byte aligned)
+            lat5 = lat[:, :L].view(bs, C, Z, Hl, Wl)                            # channel-first lattice
+            if use_hip:
+                from ..hipops import lattice_transpose
+                lattice_transpose(e.contiguous(), lat, (Hl, Wl), layout, True)
+            else:
+                from .upsample import _to_plain
+                lat5.copy_(_to_plain(e, layout).permute(0, 4, 1, 2, 3))
+            lat[:, L:L + C] = up_bias.to(dt)
+            lat[:, L + C] = 1
+            lat[:, L + C + 1] = 0
         w = weight.to(dt)
         out = torch.empty(bs * plan.rows, out_dim, dtype=dt, device=e.device)
         operands, weights = [], []
@@ -210,7 +273,11 @@ class _OccProjLattice(torch.autograd.Function):
         with torch.autocast(weight.device.type, enabled=False):
             s_all = weight @ _token_matrix(plan, weight)                                   # [out, groups * Z]
         for gi, g in enumerate(plan.groups):
-            if use_hip and g.run_len:
+            if fused:
+                a = rows_buf[spans[gi][0]:spans[gi][0] + spans[gi][1]].view(bs * g.n_rows, g.k_aug)
+                # the augmentation columns (b_up of the row's channels | 1 | 0 ...) are the same for every sample
+                a.view(bs, g.n_rows, g.k_aug)[:, :, g.n_cols:] = tail.index_select(0, g.aug_tail).view(g.n_rows, g.k_aug - g.n_cols)
+            elif use_hip and g.run_len:
                 from ..hipops import run_gather
                 a = torch.empty(bs * g.n_rows, g.k_aug, dtype=dt, device=e.device)
                 run_gather(lat, g.run_start, g.aug_idx, a, g.n_rows, g.run_len)
@@ -225,7 +292,7 @@ class _OccProjLattice(torch.autograd.Function):
                 torch.mm(a, wa.t(), out=out[bs * g.offset: bs * (g.offset + g.n_rows)])
             operands.append(a)
             weights.append(wa)
-        ctx.plan, ctx.shape, ctx.layout, ctx.e_shape = plan, (bs, Z, Hl, Wl, C), layout, tuple(e.shape)
+        ctx.plan, ctx.shape, ctx.layout, ctx.e_shape, ctx.fused = plan, (bs, Z, Hl, Wl, C), layout, tuple(e.shape), fused
         ctx.save_for_backward(weight, *operands, *weights)
         return out
 
@@ -239,15 +306,25 @@ class _OccProjLattice(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         dt = grad_out.dtype
         acc = torch.float64 if dt == torch.float64 else torch.float32       # parameter gradients
-        d_lat = torch.empty(bs, plan.lattice_size, dtype=dt, device=grad_out.device)
+        fused = ctx.fused
+        if fused:
+            row_map, spans, total = _row_map_for(plan, bs)
+            d_rows = torch.empty(total, dtype=dt, device=grad_out.device)
+        else:
+            d_lat = torch.empty(bs, plan.lattice_size, dtype=dt, device=grad_out.device)
         d_weight = torch.zeros(weight.shape, dtype=acc, device=weight.device)
         d_bias = torch.zeros(weight.shape[0], dtype=acc, device=weight.device)
         d_up = torch.zeros(C, dtype=acc, device=weight.device)
         d_tokens = []
-        for g, a, wa in zip(plan.groups, operands, weights):
+        for gi, (g, a, wa) in enumerate(zip(plan.groups, operands, weights)):
             go = grad_out[bs * g.offset: bs * (g.offset + g.n_rows)]
             # d(operand): data columns go back to their lattice positions (each written exactly once)
-            if d_lat.is_cuda and g.run_len and dt in (torch.float32, torch.bfloat16):
+            if fused:
+                d_all = d_rows[spans[gi][0]:spans[gi][0] + spans[gi][1]].view(bs * g.n_rows, g.k_aug)
+                with gemm_timed('head_gemm_dgrad', go.shape[0], go.shape[1], wa.shape[1]):
+                    torch.mm(go, wa, out=d_all)
+                d_const = d_all[:, g.n_cols:g.n_cols + Z]
+            elif d_lat.is_cuda and g.run_len and dt in (torch.float32, torch.bfloat16):
                 # the Z constant columns sit right behind the data columns of W_aug: ONE GEMM returns both (their own
                 # [rows, Z] product read all of `go` again for four output columns: 0.85 ms per group at 192 viewpoints,
                 # profiles/r04_gemm_ledger.csv); the run copies take the row pitch of the wider buffer as it is
@@ -268,6 +345,11 @@ class _OccProjLattice(torch.autograd.Function):
             d_bias += d_wa[:, g.n_cols + Z]
         # every constant column of a token receives that token's gradient: the adjoint of `weight @ membership`
         d_weight.addmm_(torch.cat(d_tokens, 1), _token_matrix(plan, d_weight).t())
+        if fused:
+            from ..hipops import lattice_rows
+            d_e = d_rows.new_empty(ctx.e_shape)
+            lattice_rows(d_e, d_rows, row_map, (Hl, Wl), ctx.layout, False)
+            return d_e, d_up, d_weight, d_bias, None
         d5 = d_lat.view(bs, C, Z, Hl, Wl)
         if d_lat.is_cuda and dt in (torch.float32, torch.bfloat16):
             from ..hipops import lattice_transpose

@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
@@ -22,7 +22,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
-           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_lattice_transpose', 'ver_run_gather',
+           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_lattice_transpose', 'ver_lattice_rows', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
@@ -533,6 +533,26 @@ def lattice_transpose(channels_last, channel_first, combined_hw, layout, to_chan
     _launch('ver_lattice_transpose', lambda: lib().ver_lattice_transpose(
         _p(cl), _p(cf), ctypes.c_long(cf.shape[1]), B, Z, H, W, C, int(layout), int(to_channel_first), dt,
         _stream()))
+
+
+def lattice_rows(channels_last, rows, row_map, combined_hw, layout, to_rows):
+    """ver_lattice_rows (no autograd): bf16 lattice (channels-last, layout 0-3) <-> ``rows``, ONE flat bf16 buffer that
+    holds the operand matrices of all pattern groups; ``row_map``: dict(quarter, period, seg_off, seg_len, seg_base,
+    seg_pitch, seg_rows) of dense_heads/occ_proj_lattice.py (element offsets into ``rows``)."""
+    cl, buf = _gpu(channels_last, 'channels_last'), _gpu(rows, 'rows')
+    if not (cl.is_contiguous() and buf.is_contiguous() and cl.dtype == torch.bfloat16 and buf.dtype == torch.bfloat16):
+        raise TypeError('lattice_rows: contiguous bf16 buffers required')
+    H, W = combined_hw
+    B, Z, C = _lattice_dims(cl, int(layout))
+    n = len(row_map['seg_off'])
+    need = max(b + B * r * p for b, r, p in zip(row_map['seg_base'], row_map['seg_rows'], row_map['seg_pitch']))
+    if buf.numel() < need:
+        raise ValueError('lattice_rows: rows buffer of %d elements, %d needed' % (buf.numel(), need))
+    ints = lambda k: (ctypes.c_int * n)(*[int(v) for v in row_map[k]])
+    base = (ctypes.c_long * n)(*[int(v) for v in row_map['seg_base']])
+    _launch('ver_lattice_rows', lambda: lib().ver_lattice_rows(
+        _p(cl), _p(buf), ctypes.c_long(int(row_map['quarter'])), int(row_map['period']), n, ints('seg_off'), ints('seg_len'),
+        base, ints('seg_pitch'), ints('seg_rows'), B, Z, H, W, C, int(layout), int(to_rows), 1, _stream()))
 
 
 def run_gather(image, run_start, aug_idx, rows, n_rows, run_len):

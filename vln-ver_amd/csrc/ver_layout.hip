@@ -332,18 +332,49 @@ struct RowMap {
     int seg_off[8], seg_len[8], seg_pitch[8], seg_rows[8];
     long seg_base[8];
 };
-__device__ __forceinline__ long row_map_index(const RowMap& m, int b, unsigned flat) {
-    const unsigned k = flat / (unsigned)m.quarter;
-    const unsigned rem = flat - k * (unsigned)m.quarter;
-    const unsigned row = rem / (unsigned)m.period;
-    const int off = (int)(rem - row * (unsigned)m.period);
-    // (constant indices into the kernel-argument tables + selects: a lane-dependent index would put the struct in scratch)
-    int so = m.seg_off[0], sl = m.seg_len[0], sp = m.seg_pitch[0], sr = m.seg_rows[0];
-    long sb = m.seg_base[0];
+// Per workgroup (one sample b, one (z, y0) spatial tile, CH channels): the flat index of a channel's first piece is split
+// into (k, row, off) ONCE per channel (two divisions by the first CH lanes, kept in LDS); a piece then adds its position,
+// wraps over at most a few periods and looks its segment up in a byte table over the period (4-element slots) -- ~20 VALU
+// operations per 8-byte piece.  (The first form divided and walked the segment table per piece: ~100 operations, and
+// both directions ran VALU-bound at 3.1 TB/s where ver_lattice_transpose moves 4.5.)
+struct RowMapLds {
+    int ch_k[128], ch_row[128], ch_off[128];
+    int seg_off[8], seg_len[8], seg_pitch[8];
+    long seg_base[8];                     // + b * seg_rows * seg_pitch
+    unsigned char slot_seg[1024];         // period / 4 slots
+};
+__device__ __forceinline__ void row_map_setup(RowMapLds& t, const RowMap& m, int b, int nc, long flat0, long flat_per_channel) {
+    const int tid = threadIdx.x;
+    if (tid < nc) {
+        const unsigned flat = (unsigned)(flat0 + tid * flat_per_channel);
+        const unsigned k = flat / (unsigned)m.quarter;
+        const unsigned rem = flat - k * (unsigned)m.quarter;
+        const unsigned row = rem / (unsigned)m.period;
+        t.ch_k[tid] = (int)k, t.ch_row[tid] = (int)row, t.ch_off[tid] = (int)(rem - row * (unsigned)m.period);
+    }
+    if (tid >= 128 && tid < 136) {
+        const int j = tid - 128;
+        int so = 0, sl = 0, sp = 0, sr = 0;
+        long sb = 0;
 #pragma unroll
-    for (int j = 1; j < 8; ++j)
-        if (j < m.nseg && off >= m.seg_off[j]) so = m.seg_off[j], sl = m.seg_len[j], sp = m.seg_pitch[j], sr = m.seg_rows[j], sb = m.seg_base[j];
-    return sb + ((long)b * sr + row) * sp + (long)k * sl + (off - so);
+        for (int q = 0; q < 8; ++q)
+            if (q == j) so = m.seg_off[q], sl = m.seg_len[q], sp = m.seg_pitch[q], sr = m.seg_rows[q], sb = m.seg_base[q];
+        t.seg_off[j] = so, t.seg_len[j] = sl, t.seg_pitch[j] = sp, t.seg_base[j] = sb + (long)b * sr * sp;
+    }
+    for (int sl4 = tid; sl4 < (m.period >> 2); sl4 += 256) {
+        const int off = sl4 << 2;
+        int sg = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q)
+            if (q < m.nseg && off >= m.seg_off[q]) sg = q;
+        t.slot_seg[sl4] = (unsigned char)sg;
+    }
+}
+__device__ __forceinline__ long row_map_piece(const RowMapLds& t, int period, int c, int piece_off) {
+    int off = t.ch_off[c] + piece_off, row = t.ch_row[c];
+    while (off >= period) off -= period, ++row;
+    const int sg = t.slot_seg[off >> 2];
+    return t.seg_base[sg] + (long)row * t.seg_pitch[sg] + t.ch_k[c] * t.seg_len[sg] + (off - t.seg_off[sg]);
 }
 }  // namespace
 
@@ -365,6 +396,8 @@ __global__ __launch_bounds__(256) void k_lattice_rows(uint16_t* __restrict__ cl,
     const int ncv = nc / VC, npv = P / VX;
     unsigned* tile32 = reinterpret_cast<unsigned*>(smem);        // [CH][P / 2 (+ pad)] dwords of two neighbouring positions
     const int P2 = P >> 1, wp32 = (P2 + 2) & ~1;
+    __shared__ RowMapLds lmap;
+    row_map_setup(lmap, map, b, nc, (((long)c0 * Z + z) * H + y0) * W, (long)Z * H * W);
     if (TO_ROWS) {
         for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
             const int p2 = i / ncv, cv = i - p2 * ncv;
@@ -383,14 +416,13 @@ __global__ __launch_bounds__(256) void k_lattice_rows(uint16_t* __restrict__ cl,
         for (int i = threadIdx.x; i < nc * npv; i += 256) {
             const int c = i / npv, pv = i - c * npv;
             const uint2 u = *reinterpret_cast<const uint2*>(tile32 + c * wp32 + 2 * pv);
-            const unsigned flat = (unsigned)((((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
-            *reinterpret_cast<uint2*>(rows + row_map_index(map, b, flat)) = u;
+            *reinterpret_cast<uint2*>(rows + row_map_piece(lmap, map.period, c, pv * VX)) = u;
         }
     } else {
+        __syncthreads();                                         // (the row map)
         for (int i = threadIdx.x; i < nc * npv; i += 256) {
             const int c = i / npv, pv = i - c * npv;
-            const unsigned flat = (unsigned)((((long)(c0 + c) * Z + z) * H + y0) * W + pv * VX);
-            *reinterpret_cast<uint2*>(tile32 + c * wp32 + 2 * pv) = *reinterpret_cast<const uint2*>(rows + row_map_index(map, b, flat));
+            *reinterpret_cast<uint2*>(tile32 + c * wp32 + 2 * pv) = *reinterpret_cast<const uint2*>(rows + row_map_piece(lmap, map.period, c, pv * VX));
         }
         __syncthreads();
         for (int i = threadIdx.x; i < P2 * ncv; i += 256) {
@@ -553,6 +585,8 @@ extern "C" int ver_lattice_rows(void* channels_last, void* rows, long quarter, i
                 "ver_lattice_rows: lattice of %ld elements, quarter %ld, period %d", L, quarter, period);
     VER_REQUIRE(W % 4 == 0 && C % 8 == 0 && ((long)Z * H * W) % 4 == 0, VER_EUNSUPPORTED,
                 "ver_lattice_rows: W %% 4, C %% 8 (8-byte pieces along W, 16-byte channel vectors)");
+    VER_REQUIRE(period <= 4096 && quarter % ((long)H * W) == 0, VER_EUNSUPPORTED,
+                "ver_lattice_rows: period %d > 4096 or a (c, z) plane of %d elements straddles two quarters", period, H * W);
     RowMap m;
     m.quarter = quarter, m.period = period, m.nseg = nseg;
     int covered = 0;

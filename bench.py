@@ -83,6 +83,8 @@ def parse():
                          'only): full_train = BASELINE configs[4] (vocc_full_train, bf16, 64 viewpoints per step), fp32 = the '
                          'default workload in fp32 at 8 viewpoints per step; empty string: none')
     ap.add_argument('--sub-steps', type=int, default=3)
+    ap.add_argument('--torch-optimizer', action='store_true',
+                    help='clip_grad_norm_ + torch.optim.AdamW(fused=True) instead of optim.ClipAdamW (ver_clip_adamw_step)')
     return ap.parse_args()
 
 
@@ -144,6 +146,26 @@ class FullTrainer(torch.nn.Module):
         outs = {k: (v.float() if torch.is_tensor(v) and k != 'occupancy_preds' else v) for k, v in outs.items()}
         losses = self.head.loss(gt_boxes, gt_labels, gt, outs)
         return sum(losses.values())
+
+
+def make_optimizer(params, own=True):
+    """-> (optimizer, update): the reference's step (vocc.py:268-274: AdamW lr 1e-4 / weight decay 0.01 behind
+    grad_clip max_norm) -- by default ``optim.ClipAdamW`` (clip + AdamW as one C-ABI call, ver_clip_adamw_step), with
+    ``--torch-optimizer`` torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True): the same arithmetic in four passes."""
+    if own:
+        opt = importlib.import_module('vln-ver_amd.optim').ClipAdamW(params, lr=1e-4, weight_decay=0.01, max_norm=300.0)
+
+        def update():
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+
+        def update():
+            torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:274 grad_clip max_norm
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+    return opt, update
 
 
 def build_model(args, dev):
@@ -318,7 +340,7 @@ def sub_record(base, name, dev, rank, world, distributed):
     if distributed:
         net = importlib.import_module('vln-ver_amd.ddp').wrap_ddp(model, device=dev, bf16_gradients=base.backend == 'nccl')
     params = [prm for prm in model.parameters() if prm.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    opt, update = make_optimizer(params, own=not base.torch_optimizer)
     graphed = None
     if full and not distributed and base.graph_full_train:
         # same kernels, same arithmetic, replayed: Hungarian targets, loss terms, clip and AdamW stay eager (graphs.py)
@@ -330,9 +352,7 @@ def sub_record(base, name, dev, rank, world, distributed):
         else:
             loss = net(feats, w2p, org, gt, *extra)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 300.0)
-        opt.step()
-        opt.zero_grad(set_to_none=True)
+        update()
         return loss
     for _ in range(3):                          # two priming steps (allocator, AdamW state) + 1 warm-up
         last = step()
@@ -414,7 +434,7 @@ def main():
     if distributed and train and not probe_unused:
         ddp = wrap(model)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True) if train else None
+    opt, update = make_optimizer(params, own=not args.torch_optimizer) if train else (None, None)
 
     # synthetic, HBM-resident inputs (different viewpoints per rank)
     w2p_np, org_np = syn.camera_batch(B, seed=1 + rank)
@@ -441,9 +461,7 @@ def main():
             def graph_step():
                 loss = sum(head.loss(gb, gl, g, graphed(f, w, o)).values())
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(params, 300.0)
-                opt.step()
-                opt.zero_grad(set_to_none=True)
+                update()
                 return loss
             return graph_step
 
@@ -451,9 +469,7 @@ def main():
             if train:
                 loss = ddp(f, w, o, g, gb, gl) if full else ddp(f, w, o, g)
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(params, 300.0)       # vocc.py:274 grad_clip max_norm
-                opt.step()
-                opt.zero_grad(set_to_none=True)
+                update()                                            # vocc.py:268-274: grad_clip + AdamW
                 return loss
             with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.dtype == 'bf16'):
                 emb = head(f, None, only_bev=True, world2pixel=w, origin=o)
@@ -472,7 +488,7 @@ def main():
             prm.grad = None
         params = [prm for prm in model.parameters() if prm.requires_grad]
         n_train = sum(prm.numel() for prm in params)
-        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        opt, update = make_optimizer(params, own=not args.torch_optimizer)
         if distributed:
             ddp = wrap(model)
     step = make_step(B)
@@ -642,6 +658,8 @@ def main():
                        'gradient_allreduce': (('RCCL, bf16-compressed 200 MB buckets' if args.backend == 'nccl'
                                                else args.backend) if distributed and train else None),
                        'trainable_params': n_train, 'tuned_gemm_table': tuned,
+                       'optimizer': (None if not train else 'torch clip_grad_norm_ + AdamW(fused)' if args.torch_optimizer
+                                     else 'optim.ClipAdamW (ver_clip_adamw_step)'),
                        'peak_hbm_gib': peak_gib,
                        'arithmetic': ('bf16 autocast GEMMs and lattices; multi-view gather on bf16 value tiles: packed-fp16 point '
                                       'accumulation (<= 8 terms per voxel, head, corner), fp32 after the corner fold; fp32 '

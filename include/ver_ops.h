@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 26
+#define VER_ABI_VERSION 27
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -482,6 +482,21 @@ int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int 
  */
 int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
                  int N, int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Gradient clipping by the global L2 norm + AdamW, one call per step (ABI 27).  Replaces, for fp32 parameters, the
+ * optimizer step the reference configures: mmcv OptimizerHook(grad_clip=dict(max_norm=..., norm_type=2)) in front of
+ * torch.optim.AdamW (projects/configs/verformer/vocc.py:268-274) -- torch.nn.utils.clip_grad_norm_ (coefficient
+ * min(1, max_norm / (norm + 1e-6))) followed by AdamW (decoupled weight decay, amsgrad off, bias corrections of `step`).
+ *   table        device array of 4 * n_tensors pointers: parameters | gradients | exp_avg | exp_avg_sq (all f32, same sizes)
+ *   sizes        device long [n_tensors]: elements per tensor
+ *   chunk_tensor, chunk_index   device int [n_chunks]: the tensor of every chunk of `chunk_elems` elements (a multiple of 4)
+ *                and the chunk's index inside that tensor
+ *   partial      device float [n_chunks] scratch; norm_out: device float receiving the gradient norm BEFORE clipping, or NULL
+ *   max_norm <= 0: no clipping.  Gradients are read, not rewritten.  step = 1 for the first update. */
+int ver_clip_adamw_step(void* const* table, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                        int n_tensors, int n_chunks, int chunk_elems, float* partial, float* norm_out, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, long step, void* stream);
 
 #ifdef __cplusplus
 }

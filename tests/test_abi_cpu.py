@@ -157,6 +157,19 @@ def test_argument_validation_of_the_gemm_entry_points():
     assert rc == -1 and b'quarter' in lib.ver_last_error()
     rc = lib.ver_lattice_rows(*rows(None, buf))
     assert rc == -1 and b'null' in lib.ver_last_error()
+    # ver_clip_adamw_step (ABI 27)
+    F = ctypes.c_float
+    adam = lambda tab, n=1, chunks=1, chunk=1024, step=1, lr=1e-3, b1=0.9: (
+        tab, tab, tab, tab, n, chunks, chunk, tab, None, F(1.0), F(lr), F(b1), F(0.999), F(1e-8), F(0.01), L(step), None)
+    assert lib.ver_clip_adamw_step(*adam(None, n=0, chunks=0)) == 0
+    rc = lib.ver_clip_adamw_step(*adam(buf, chunk=1022))
+    assert rc == -1 and b'bad sizes' in lib.ver_last_error()
+    rc = lib.ver_clip_adamw_step(*adam(buf, step=0))
+    assert rc == -1 and b'step 0' in lib.ver_last_error()
+    rc = lib.ver_clip_adamw_step(*adam(buf, b1=1.0))
+    assert rc == -1 and b'hyper-parameters' in lib.ver_last_error()
+    rc = lib.ver_clip_adamw_step(*adam(None))
+    assert rc == -1 and b'null' in lib.ver_last_error()
     # the MLP entries with the saved statistics: the rstd pointer must be 8-byte aligned and N < 2^28
     off = ctypes.cast(ctypes.addressof(buf) + 4, ctypes.c_void_p)
     rc = lib.ver_occ_mlp_forward_stats(buf, buf, buf, buf, off, L(4), 128, 16, ctypes.c_float(1e-5), 2, None)

@@ -1458,3 +1458,51 @@ def test_gemm_nn_equals_the_fp32_product(M, K, lda, c0, N, ldw, bias):
     assert torch.equal(wide[:, 8:8 + N], got) and float(wide[:, :8].min()) == 7.0 and float(wide[:, 8 + N:].min()) == 7.0
     with pytest.raises(RuntimeError):
         hip.gemm_nn(Af[:, :K - 16] if K > 80 else Af[:, :48], Wf[:K - 16 if K > 80 else 48, :N])      # K % 32 != 0
+
+
+# ------------------------------------------------------------------------------- the optimizer step of the bench
+@pytest.mark.parametrize('max_norm', [0.5, 1e9, 0.0])
+def test_clip_adamw_equals_clip_grad_norm_plus_torch_adamw(max_norm):
+    """``optim.ClipAdamW`` (ver_clip_adamw_step: global-norm clipping + AdamW in two launches) against
+    ``torch.nn.utils.clip_grad_norm_`` + ``torch.optim.AdamW`` over four steps: tensors of awkward sizes (1, 5, a 4-byte
+    aligned view, 1 000 003 elements, a matrix), clipping active (0.5), inactive (1e9) and off (0); the returned norm is the
+    unclipped gradient norm; parameters without a gradient are left alone."""
+    opt_mod = pkg('optim')
+    gen = torch.Generator(device='cpu').manual_seed(77)
+    shapes = [(1,), (5,), (1000003,), (33, 7), (257,)]
+    base = [torch.randn(s, generator=gen) for s in shapes]
+    flat = torch.randn(1031, generator=gen)
+
+    def make():
+        ps = [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+        buf = flat.clone().to(DEV)
+        ps.append(torch.nn.Parameter(buf[1:1025]))              # data pointer 4 bytes off a 16-byte boundary
+        ps.append(torch.nn.Parameter(torch.ones(9, device=DEV)))   # never receives a gradient
+        return ps
+    ours, ref = make(), make()
+    a = opt_mod.ClipAdamW(ours, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, max_norm=max_norm)
+    b = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    for it in range(4):
+        grads = [torch.randn(p.shape, generator=gen) * (10.0 if it == 2 else 1.0) for p in ours[:-1]]
+        for p, q, g in zip(ours, ref, grads):
+            p.grad = g.clone().to(DEV)
+            q.grad = g.clone().to(DEV)
+        want_norm = torch.linalg.vector_norm(torch.cat([g.reshape(-1) for g in grads]).double())
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(ref[:-1], max_norm)
+        b.step()
+        got_norm = a.step()
+        assert float(got_norm) == pytest.approx(float(want_norm), rel=1e-5)
+        for p, g in zip(ours, grads):
+            assert torch.equal(p.grad.cpu(), g)                    # gradients are read, not rewritten
+        # (a few fp32 roundings apart: torch forms the first moment as a lerp and divides by sqrt(bias correction 2))
+        near = lambda x, y: close(x.cpu(), y.cpu(), atol=2e-6 * max(float(y.abs().max()), 1e-30), rtol=2e-6)
+        for p, q in zip(ours, ref):
+            assert near(p.detach(), q.detach()), it
+        for p, q in zip(ours[:-1], ref[:-1]):
+            assert near(a.state[p]['exp_avg'], b.state[q]['exp_avg']) and near(a.state[p]['exp_avg_sq'], b.state[q]['exp_avg_sq'])
+    assert torch.equal(ours[-1].detach().cpu(), torch.ones(9)) and not a.state[ours[-1]]
+    cpu_p = torch.nn.Parameter(torch.ones(3))                      # no CPU path: loud
+    cpu_p.grad = torch.ones(3)
+    with pytest.raises(TypeError):
+        opt_mod.ClipAdamW([cpu_p], max_norm=1.0).step()

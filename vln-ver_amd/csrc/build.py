@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libver_hip.so')
-SOURCES = ['ver_abi.hip', 'ver_msda.hip', 'ver_sca.hip', 'ver_lattice.hip', 'ver_mlp.hip', 'ver_loss.hip', 'ver_occ_mlp.hip', 'ver_layout.hip', 'ver_addln.hip', 'ver_post.hip', 'ver_wgrad.hip', 'ver_gemm.hip']
+SOURCES = ['ver_abi.hip', 'ver_msda.hip', 'ver_sca.hip', 'ver_lattice.hip', 'ver_mlp.hip', 'ver_loss.hip', 'ver_occ_mlp.hip', 'ver_layout.hip', 'ver_addln.hip', 'ver_post.hip', 'ver_wgrad.hip', 'ver_gemm.hip', 'ver_optim.hip']
 HEADERS = ['ver_common.h', os.path.join('..', '..', 'include', 'ver_ops.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-munsafe-fp-atomics',
          '-Wall', '-Wno-unused-function']

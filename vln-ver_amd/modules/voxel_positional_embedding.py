@@ -37,7 +37,9 @@ class VoxelLearnedPositionalEncoding(BaseModule):
         y = self.row_embed(torch.arange(h, device=dev))
         z = self.z_embed(torch.arange(d, device=dev))
         pos = x[None, None, :, :] + y[None, :, None, :] + z[:, None, None, :]
-        return pos.permute(3, 0, 1, 2).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1, 1)
+        # (the reference repeats the encoding over the batch, :76-79; the same values as a stride-0 view -- the vocc.py encoder
+        #  never reads it, and a 192-viewpoint copy of it is 0.53 GB written per step)
+        return pos.permute(3, 0, 1, 2).unsqueeze(0).expand(mask.shape[0], -1, -1, -1, -1)
 
     def __repr__(self):
         return (f'{self.__class__.__name__}(num_feats={self.num_feats}, '

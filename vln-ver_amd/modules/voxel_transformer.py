@@ -78,7 +78,9 @@ class VoxelPerceptionTransformer(BaseModule):
         map_h = int(math.isqrt(nk))
         if map_h * map_h != nk:
             raise ValueError('feature maps must be square token grids, got %d tokens' % nk)
-        bev_queries = bev_queries.unsqueeze(1).repeat(1, bs, 1)
+        # [Nq,bs,C] as the reference builds it (:150), laid out sample-major: the encoder's [bs,Nq,C] view of it is then
+        # contiguous (its first residual and first projection read it without a strided copy)
+        bev_queries = bev_queries.unsqueeze(0).repeat(bs, 1, 1).permute(1, 0, 2)
         if bev_pos is not None:
             bev_pos = bev_pos.flatten(2).permute(2, 0, 1)
         shift = bev_queries.new_zeros(1, 3)

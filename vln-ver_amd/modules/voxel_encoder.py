@@ -101,7 +101,7 @@ class VoxelFormerEncoder(TransformerLayerSequence):
         bev_pos = bev_pos.permute(1, 0, 2) if bev_pos is not None else None
         intermediate = []
         value_lowp = None
-        if (torch.is_tensor(value) and value.is_cuda and value.dtype == torch.float32 and value.dim() == 4
+        if (kwargs.get('value_lowp') is None and torch.is_tensor(value) and value.is_cuda and value.dtype == torch.float32 and value.dim() == 4
                 and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16):
             # every layer's value_proj would cast the same fp32 feature maps to bf16 again: cast once and hand the
             # copy to the layers explicitly (it lives exactly as long as this call)

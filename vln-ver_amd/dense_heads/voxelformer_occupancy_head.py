@@ -337,11 +337,19 @@ class VoxelFormerOccupancyHead(BaseModule):
         Function: x [N, 128] rows in GEMM order, gt_occupancy in the reference's (Z, X, Y) voxel order."""
         from ..hipops import occ_mlp_focal_loss_sum
         _, n1, _, l2, n2, _, l3 = list(self.occ_branches)
-        gt = gt_occupancy.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)      # -> [bs, X*Y, Z]
+        lo = self.loss_occupancy
+        lo.check_label_range(gt_occupancy, self.occupancy_classes)      # (the same first-call host check as FocalLoss.forward)
+        # the labels are permuted into the GEMMs' row order and counted as BYTES (17 classes): int64 labels made the
+        # permutation and the count three passes over 0.77 GB each at 192 viewpoints (1.4 ms; now 0.5 with both conversions).
+        # The range check above sees the original values; a label >= 256 would wrap here (one < 0 or in (C, 255] still
+        # reaches the kernel's own check as an invalid label).
+        narrow = gt_occupancy.is_cuda and gt_occupancy.dtype == torch.int64 and self.occupancy_classes < 255
+        gt = gt_occupancy.to(torch.uint8) if narrow else gt_occupancy
+        gt = gt.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)                # -> [bs, X*Y, Z]
         gt = voxels_to_rows(gt, plan, bs).reshape(-1)
         avg = (gt < self.occupancy_classes).sum() * 1.0
-        lo = self.loss_occupancy
-        lo.check_label_range(gt, self.occupancy_classes)      # (the same first-call host check as FocalLoss.forward)
+        if narrow:
+            gt = gt.to(torch.int64)
         with torch.autocast('cuda', enabled=False):
             w2c, b2c = self._centered(l2.weight.float(), l2.bias.float())
             s = occ_mlp_focal_loss_sum(x.to(torch.bfloat16), n1.weight, n1.bias, w2c, b2c, n2.weight, n2.bias,

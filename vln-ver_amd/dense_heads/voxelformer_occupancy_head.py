@@ -347,7 +347,14 @@ class VoxelFormerOccupancyHead(BaseModule):
         gt = gt_occupancy.to(torch.uint8) if narrow else gt_occupancy
         gt = gt.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)                # -> [bs, X*Y, Z]
         gt = voxels_to_rows(gt, plan, bs).reshape(-1)
-        avg = (gt < self.occupancy_classes).sum() * 1.0
+        occupied = gt < self.occupancy_classes
+        if narrow and occupied.numel() % 8 == 0:
+            # the count of a 0/1 byte mask, eight bytes at a time: (word * 0x0101...01) >> 56 is the sum of the word's bytes
+            # (exact; the reduction kernel reads a bool tensor one byte per lane: 0.46 ms for 97 M labels against 0.05)
+            words = occupied.view(torch.uint8).view(torch.int64)
+            avg = ((words * 0x0101010101010101) >> 56).sum() * 1.0
+        else:
+            avg = occupied.sum() * 1.0
         if narrow:
             gt = gt.to(torch.int64)
         with torch.autocast('cuda', enabled=False):

@@ -338,10 +338,10 @@ struct RowMap {
 // operations per 8-byte piece.  (The first form divided and walked the segment table per piece: ~100 operations, and
 // both directions ran VALU-bound at 3.1 TB/s where ver_lattice_transpose moves 4.5.)
 struct RowMapLds {
-    int ch_k[128], ch_row[128], ch_off[128];
-    int seg_off[8], seg_len[8], seg_pitch[8];
+    int4 ch[128];                         // per channel of the tile: (k, row, off, -) of its first piece
+    int4 seg[8];                          // per segment: (seg_off, seg_len, seg_pitch, -)
     long seg_base[8];                     // + b * seg_rows * seg_pitch
-    unsigned char slot_seg[1024];         // period / 4 slots
+    unsigned char slot_seg[1024];         // period / 4 slots -> segment
 };
 __device__ __forceinline__ void row_map_setup(RowMapLds& t, const RowMap& m, int b, int nc, long flat0, long flat_per_channel) {
     const int tid = threadIdx.x;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void row_map_setup(RowMapLds& t, const RowMap& m, int
         const unsigned k = flat / (unsigned)m.quarter;
         const unsigned rem = flat - k * (unsigned)m.quarter;
         const unsigned row = rem / (unsigned)m.period;
-        t.ch_k[tid] = (int)k, t.ch_row[tid] = (int)row, t.ch_off[tid] = (int)(rem - row * (unsigned)m.period);
+        t.ch[tid] = make_int4((int)k, (int)row, (int)(rem - row * (unsigned)m.period), 0);
     }
     if (tid >= 128 && tid < 136) {
         const int j = tid - 128;
@@ -359,7 +359,8 @@ __device__ __forceinline__ void row_map_setup(RowMapLds& t, const RowMap& m, int
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (q == j) so = m.seg_off[q], sl = m.seg_len[q], sp = m.seg_pitch[q], sr = m.seg_rows[q], sb = m.seg_base[q];
-        t.seg_off[j] = so, t.seg_len[j] = sl, t.seg_pitch[j] = sp, t.seg_base[j] = sb + (long)b * sr * sp;
+        t.seg[j] = make_int4(so, sl, sp, 0);
+        t.seg_base[j] = sb + (long)b * sr * sp;
     }
     for (int sl4 = tid; sl4 < (m.period >> 2); sl4 += 256) {
         const int off = sl4 << 2;
@@ -370,11 +371,14 @@ __device__ __forceinline__ void row_map_setup(RowMapLds& t, const RowMap& m, int
         t.slot_seg[sl4] = (unsigned char)sg;
     }
 }
+// four LDS reads per 8-byte piece (channel record, slot byte, segment record, segment base)
 __device__ __forceinline__ long row_map_piece(const RowMapLds& t, int period, int c, int piece_off) {
-    int off = t.ch_off[c] + piece_off, row = t.ch_row[c];
+    const int4 ch = t.ch[c];
+    int off = ch.z + piece_off, row = ch.y;
     while (off >= period) off -= period, ++row;
     const int sg = t.slot_seg[off >> 2];
-    return t.seg_base[sg] + (long)row * t.seg_pitch[sg] + t.ch_k[c] * t.seg_len[sg] + (off - t.seg_off[sg]);
+    const int4 sp = t.seg[sg];
+    return t.seg_base[sg] + (long)row * sp.z + ch.x * sp.y + (off - sp.x);
 }
 }  // namespace
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 27
+#define VER_ABI_VERSION 28
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -320,6 +320,9 @@ int ver_focal_loss_forward(const void* logits, const int64_t* target, float* par
  *             `grad`, which may be the logits buffer itself -- for steps that need the loss and its gradient, not the logits */
 int ver_focal_loss_forward_grad(const void* logits, const int64_t* target, float* partial, void* grad, long N, int C,
                                 float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream);
+/* ... with the labels as bytes (C <= 254; ABI 28): what a caller that permutes and counts its labels as bytes hands over */
+int ver_focal_loss_forward_grad_u8(const void* logits, const uint8_t* target, float* partial, void* grad, long N, int C,
+                                   float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream);
 int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,
                             long N, int C, float gamma, float alpha, int dtype, void* stream);
 

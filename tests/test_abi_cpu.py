@@ -157,6 +157,9 @@ def test_argument_validation_of_the_gemm_entry_points():
     assert rc == -1 and b'quarter' in lib.ver_last_error()
     rc = lib.ver_lattice_rows(*rows(None, buf))
     assert rc == -1 and b'null' in lib.ver_last_error()
+    # ver_focal_loss_forward_grad_u8 (ABI 28): byte labels hold at most 254 classes
+    rc = lib.ver_focal_loss_forward_grad_u8(buf, buf, buf, buf, L(8), 256, ctypes.c_float(2.0), ctypes.c_float(0.25), 0, None, None)
+    assert rc == -1 and b'byte labels' in lib.ver_last_error()
     # ver_clip_adamw_step (ABI 27)
     F = ctypes.c_float
     adam = lambda tab, n=1, chunks=1, chunk=1024, step=1, lr=1e-3, b1=0.9: (

@@ -1460,6 +1460,38 @@ def test_gemm_nn_equals_the_fp32_product(M, K, lda, c0, N, ldw, bias):
         hip.gemm_nn(Af[:, :K - 16] if K > 80 else Af[:, :48], Wf[:K - 16 if K > 80 else 48, :N])      # K % 32 != 0
 
 
+def test_focal_forward_grad_with_byte_labels_is_bit_identical():
+    """ver_focal_loss_forward_grad_u8 (labels as bytes) against the int64-label entry on the same logits: the same partial
+    sums and the same in-place gradients, and 255 (a wrapped -1) is an invalid label that poisons the sum and raises the
+    device-side flag."""
+    import ctypes
+    hip = pkg('hipops')
+    L = hip.lib()
+    gen = torch.Generator(device='cpu').manual_seed(57)
+    n = 100003
+    logits = (torch.randn(n, 16, generator=gen) * 2).bfloat16().to(DEV)
+    lab = torch.randint(0, 17, (n,), generator=gen)
+    blocks = L.ver_focal_loss_blocks(ctypes.c_long(n), 16)
+    res = []
+    for labels, entry in ((lab.to(DEV), L.ver_focal_loss_forward_grad), (lab.to(torch.uint8).to(DEV), L.ver_focal_loss_forward_grad_u8)):
+        x = logits.clone()
+        partial = torch.zeros(blocks, dtype=torch.float32, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        rc = entry(hip._p(x), hip._p(labels), hip._p(partial), hip._p(x), ctypes.c_long(n), 16, ctypes.c_float(2.0),
+                   ctypes.c_float(0.25), 1, hip._p(flag), hip._stream())
+        assert rc == 0 and int(flag) == 0
+        res.append((partial.clone(), x))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    bad = lab.to(torch.uint8).to(DEV)
+    bad[17] = 255
+    partial = torch.zeros(blocks, dtype=torch.float32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    x = logits.clone()
+    assert L.ver_focal_loss_forward_grad_u8(hip._p(x), hip._p(bad), hip._p(partial), hip._p(x), ctypes.c_long(n), 16,
+                                             ctypes.c_float(2.0), ctypes.c_float(0.25), 1, hip._p(flag), hip._stream()) == 0
+    assert int(flag) == 1 and bool(torch.isnan(partial.sum()))
+
+
 # ------------------------------------------------------------------------------- the optimizer step of the bench
 @pytest.mark.parametrize('max_norm', [0.5, 1e9, 0.0])
 def test_clip_adamw_equals_clip_grad_norm_plus_torch_adamw(max_norm):

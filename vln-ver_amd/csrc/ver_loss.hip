@@ -106,8 +106,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // logits' dtype) to `grad`, which may be the logits buffer itself (a thread reads its eight logits before it writes their
 // gradients): a training step that needs the loss value and the gradient, not the logits, then has no separate backward
 // pass over the [N, C] tensor -- the consumer applies the scalar d(total) / d(loss sum) when it reads the gradient.
-template <bool BF16, bool G2, bool WG = false>
-__global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int64_t* __restrict__ target,
+template <bool BF16, bool G2, bool WG = false, typename LT = int64_t>
+__global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const LT* __restrict__ target,
                                                    float* __restrict__ partial, long nvec, int vec_per_row,
                                                    float gamma, float alpha, int* __restrict__ bad_labels,
                                                    void* grad = nullptr, int row_shift = -1) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             row[u] = row_of(v + u * stride);
-            t64[u] = target[row[u]];
+            t64[u] = (int64_t)target[row[u]];
             load_x8<BF16>(logits, v + u * stride, x[u]);
         }
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_focal_fwd(const void* logits, const int
         const long row = row_of(v);
         float x[8];
         load_x8<BF16>(logits, v, x);
-        one(v, row, target[row], x);
+        one(v, row, (int64_t)target[row], x);
     }
     // ... and raises a sticky device-side flag: callers that clean NaNs out of their losses (the head's nan_to_num,
     // as in the reference) still learn about it, from an asynchronous copy of one int
@@ -272,6 +272,32 @@ extern "C" int ver_focal_loss_forward_grad(const void* logits, const int64_t* ta
     }
 #undef VER_FOCAL_FWG
     return ver_check_launch("ver_focal_loss_forward_grad");
+}
+
+// the same with labels as BYTES (C <= 254): a caller that has permuted / counted its labels as bytes hands them over as they are
+// (8 bytes per label less to read here, no widening copy in front of the call); 255 -- a wrapped -1 -- is an invalid label
+extern "C" int ver_focal_loss_forward_grad_u8(const void* logits, const uint8_t* target, float* partial, void* grad, long N,
+                                              int C, float gamma, float alpha, int dtype, int32_t* bad_labels, void* stream) {
+    int rc = check_focal("ver_focal_loss_forward_grad_u8", logits, reinterpret_cast<const int64_t*>(target), N, C, dtype);
+    if (rc) return rc;
+    VER_REQUIRE(C <= 254, VER_EINVAL, "ver_focal_loss_forward_grad_u8: %d classes do not fit byte labels", C);
+    VER_REQUIRE(partial, VER_EINVAL, "ver_focal_loss_forward_grad_u8: null partial-sum buffer");
+    if (N == 0) return VER_OK;
+    VER_REQUIRE(grad && ((uintptr_t)grad & 15) == 0, VER_EINVAL, "ver_focal_loss_forward_grad_u8: grad must be a 16-byte aligned buffer");
+    const int blocks = ver_focal_loss_blocks(N, C);
+    const long nvec = N * (long)(C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const bool g2 = gamma == 2.0f;
+#define VER_FOCAL_FWG8(BF, G2)                                                                                              \
+    hipLaunchKernelGGL((k_focal_fwd<BF, G2, true, uint8_t>), dim3(blocks), dim3(256), 0, st, logits, target, partial, nvec, \
+                       C / 8, gamma, alpha, bad_labels, grad, row_shift_of(C / 8))
+    if (dtype == VER_BF16) {
+        if (g2) VER_FOCAL_FWG8(true, true); else VER_FOCAL_FWG8(true, false);
+    } else {
+        if (g2) VER_FOCAL_FWG8(false, true); else VER_FOCAL_FWG8(false, false);
+    }
+#undef VER_FOCAL_FWG8
+    return ver_check_launch("ver_focal_loss_forward_grad_u8");
 }
 
 extern "C" int ver_focal_loss_backward(const void* logits, const int64_t* target, const float* scale, void* grad,

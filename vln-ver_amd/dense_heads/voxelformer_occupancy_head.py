@@ -340,7 +340,7 @@ class VoxelFormerOccupancyHead(BaseModule):
         lo = self.loss_occupancy
         lo.check_label_range(gt_occupancy, self.occupancy_classes)      # (the same first-call host check as FocalLoss.forward)
         # the labels are permuted into the GEMMs' row order and counted as BYTES (17 classes): int64 labels made the
-        # permutation and the count three passes over 0.77 GB each at 192 viewpoints (1.4 ms; now 0.5 with both conversions).
+        # permutation and the count three passes over 0.77 GB each at 192 viewpoints (1.4 ms; now 0.3 with the narrowing copy).
         # The range check above sees the original values; a label >= 256 would wrap here (one < 0 or in (C, 255] still
         # reaches the kernel's own check as an invalid label).
         narrow = gt_occupancy.is_cuda and gt_occupancy.dtype == torch.int64 and self.occupancy_classes < 255
@@ -355,8 +355,7 @@ class VoxelFormerOccupancyHead(BaseModule):
             avg = ((words * 0x0101010101010101) >> 56).sum() * 1.0
         else:
             avg = occupied.sum() * 1.0
-        if narrow:
-            gt = gt.to(torch.int64)
+        # (the byte labels go to the kernel as they are: ver_focal_loss_forward_grad_u8)
         with torch.autocast('cuda', enabled=False):
             w2c, b2c = self._centered(l2.weight.float(), l2.bias.float())
             s = occ_mlp_focal_loss_sum(x.to(torch.bfloat16), n1.weight, n1.bias, w2c, b2c, n2.weight, n2.bias,

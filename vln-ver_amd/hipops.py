@@ -14,12 +14,12 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
            'ver_lattice_im2col', 'ver_lattice_col2im', 'ver_ln_relu_forward', 'ver_ln_relu_backward',
-           'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad',
+           'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad', 'ver_focal_loss_forward_grad_u8',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_lattice_transpose', 'ver_lattice_rows', 'ver_run_gather',
@@ -952,14 +952,17 @@ class OccMLPFocalLossFunction(Function):
         logits, rstd = out if ctx.has_rstd else (out, None)
         l2 = logits.view(-1, 16)
         n = l2.shape[0]
-        target = _gpu(target, 'target').to(torch.int64).contiguous()
+        target = _gpu(target, 'target')
+        as_bytes = target.dtype == torch.uint8                # (labels the caller has permuted / counted as bytes)
+        target = (target if as_bytes else target.to(torch.int64)).contiguous()
         if target.shape != (n,):
             raise ValueError('target must be [N]')
         blocks = lib().ver_focal_loss_blocks(ctypes.c_long(n), 16)
         partial = torch.zeros(blocks, dtype=torch.float32, device=x.device)
         flag = LabelRangeFlag.of(x.device)
         flag.poll()
-        _launch('ver_focal_loss_forward_grad', lambda: lib().ver_focal_loss_forward_grad(
+        entry = lib().ver_focal_loss_forward_grad_u8 if as_bytes else lib().ver_focal_loss_forward_grad
+        _launch('ver_focal_loss_forward_grad', lambda: entry(
             _p(l2), _p(target), _p(partial), _p(l2), ctypes.c_long(n), 16, ctypes.c_float(gamma), ctypes.c_float(alpha),
             1, _p(flag.dev), _stream()))                      # (in place: the logits buffer now holds d loss / d logits)
         flag.mirror(16)

@@ -422,7 +422,8 @@ def test_grouped_bf16_parameter_copies_equal_autocast(monkeypatch):
     # every gradient arrives, in fp32, on the master parameter, at the noise level of bf16.
     for k in g0:
         assert g1[k].dtype == torch.float32 and torch.isfinite(g1[k]).all(), k
-        assert worst[k] < 0.8, (k, worst[k])
+        # (an almost-zero gradient may differ by more than its own norm: judged on the absolute difference then)
+        assert worst[k] < 0.8 or float((g1[k] - g0[k]).abs().max()) < 1e-4 * max(1.0, float(g0[k].abs().max())), (k, worst[k])
     assert float(np.median(list(worst.values()))) < 8e-2
 
 

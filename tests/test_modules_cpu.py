@@ -165,3 +165,94 @@ def test_init_weights_chain_matches_reference_fixture():
     assert torch.allclose(sd['cls_branches.5.6.bias'], torch.from_numpy(g['cls_prior_bias']), atol=1e-7)
     assert torch.allclose(sd['occ_branches.6.bias'], torch.from_numpy(g['occ_prior_bias']), atol=1e-7)
     assert float(g['cls_prior_bias'][0]) == pytest.approx(-float(np.log(99.0)), abs=1e-6)
+
+
+# ------------------------------------------------------------------------------- host logic added in round 5
+def test_lent_parameters_swap_and_restore_on_cpu():
+    """modules/lowp_params.py without a GPU: the bf16 copies are exact roundings of the masters laid out in one flat buffer,
+    the owning modules hold them (and the bf16 Linear path) only inside the context, gradients come back in fp32 on the
+    masters, a parameter the step does not use keeps ``grad is None``, and an exception inside the context still restores."""
+    lp = pkg('modules.lowp_params')
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 4))
+    mha = torch.nn.MultiheadAttention(16, 2)
+    spare = torch.nn.Linear(16, 3)
+    lent = lp.LowpParams([net, mha, spare])
+    assert len(lent.slots) == 2 * 2 + 2 + 2 + 2 and all(o % 128 == 0 for o in lent.offsets)
+    assert not lent.applies(torch.zeros(1))                                   # CPU tensors: autocast's own casts
+    x = torch.randn(5, 3, 8)
+    with lent.lent():
+        assert net[0].weight.dtype == torch.bfloat16 and net[1].weight.dtype == torch.float32
+        assert torch.equal(net[0].weight, net[0]._parameters['weight']) and 'forward' in net[0].__dict__
+        assert 'forward' not in mha.out_proj.__dict__                        # MultiheadAttention calls F.linear itself
+        assert torch.equal(net[0].weight.float(), net[0].weight.float().bfloat16().float())
+        y = net[0](x)                                                        # the lent bf16 Linear
+        assert y.dtype == torch.bfloat16 and tuple(y.shape) == (5, 3, 16)
+        y.float().sum().backward()
+    want = torch.nn.functional.linear(x.bfloat16(), net[0].weight.detach().bfloat16(), net[0].bias.detach().bfloat16())
+    assert torch.equal(y.detach(), want)
+    assert isinstance(net[0].weight, torch.nn.Parameter) and net[0].weight.dtype == torch.float32 and 'forward' not in net[0].__dict__
+    assert net[0].weight.grad.dtype == torch.float32 and tuple(net[0].weight.grad.shape) == (16, 8)
+    assert torch.allclose(net[0].bias.grad, torch.full((16,), 15.0))
+    assert net[2].weight.grad is None and spare.weight.grad is None and mha.in_proj_weight.grad is None
+    with pytest.raises(ZeroDivisionError):
+        with lent.lent():
+            1 / 0
+    assert net[0].weight.dtype == torch.float32 and 'forward' not in net[0].__dict__
+
+
+def test_box_denormalisation_over_whole_rows_equals_the_sliced_form():
+    """``VoxelFormerOccupancyHead._denormalize`` (sigmoid + affine on columns 0, 1, 4 of whole rows) against the reference's
+    slice-and-concatenate form (head:590-606), values and gradients, for fp32 and for bf16 branch outputs (promotion to the
+    reference points' fp32 as in the reference)."""
+    head = pkg('dense_heads.voxelformer_occupancy_head').VoxelFormerOccupancyHead
+    torch.manual_seed(0)
+    rng = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+    def sliced(tmp, reference):
+        xy = (tmp[..., 0:2] + reference[..., 0:2]).sigmoid()
+        zc = (tmp[..., 4:5] + reference[..., 2:3]).sigmoid()
+        x = xy[..., 0:1] * (rng[3] - rng[0]) + rng[0]
+        y = xy[..., 1:2] * (rng[4] - rng[1]) + rng[1]
+        z = zc * (rng[5] - rng[2]) + rng[2]
+        return torch.cat([x, y, tmp[..., 2:4], z, tmp[..., 5:]], -1)
+    tmp = torch.randn(6, 2, 5, 10, requires_grad=True)
+    ref = torch.randn(6, 2, 5, 3, requires_grad=True)
+    a, b = sliced(tmp, ref), head._denormalize(tmp, ref, rng)
+    assert torch.allclose(a, b, atol=1e-6, rtol=1e-6)
+    w = torch.randn_like(a)
+    for ga, gb in zip(torch.autograd.grad((a * w).sum(), [tmp, ref]), torch.autograd.grad((b * w).sum(), [tmp, ref])):
+        assert torch.allclose(ga, gb, atol=1e-6, rtol=1e-6)
+    tb = tmp.detach().bfloat16()
+    a, b = sliced(tb, ref.detach()), head._denormalize(tb, ref.detach(), rng)
+    assert a.dtype == b.dtype == torch.float32 and torch.allclose(a, b, atol=1e-6, rtol=1e-6)
+
+
+def test_occ_proj_run_structure_of_the_vocc_geometry_is_periodic():
+    """The table ``ver_lattice_rows`` runs on (dense_heads/occ_proj_lattice.py::_periodic_row_map), derived on the host: for
+    768 channels on the 4 x 60 x 60 lattice the raw view's runs tile the flat lattice with period 960 (204 | 204 | 192 | 180 |
+    180), 2 880 rows per group; the element offsets of a 3-sample operand buffer follow the groups' order; a geometry without
+    that structure has no table."""
+    opl = pkg('dense_heads.occ_proj_lattice')
+    plan = opl.get_plan(768, 4, 120, 120, 'cpu')
+    rm = plan.row_map
+    assert rm is not None and rm['period'] == 960 and rm['quarter'] == 768 * 60 * 60 and rm['n_rows'] == 2880
+    assert rm['seg_off'] == [0, 204, 408, 600, 780] and rm['seg_len'] == [204, 204, 192, 180, 180]
+    full, spans, total = opl._row_map_for(plan, 3)
+    assert total == sum(3 * g.n_rows * g.k_aug for g in plan.groups) and [s for s, _ in spans] == sorted(s for s, _ in spans)
+    for off, ln, gi, base, pitch, rows in zip(full['seg_off'], full['seg_len'], full['seg_group'], full['seg_base'], full['seg_pitch'], full['seg_rows']):
+        g = plan.groups[gi]
+        assert ln == g.run_len and pitch == g.k_aug and rows == g.n_rows and base == spans[gi][0] and base % 8 == 0
+    small = opl.get_plan(16, 4, 40, 48, 'cpu')
+    assert small is None or small.row_map is None
+
+
+def test_clip_adamw_has_no_cpu_path():
+    opt_mod = pkg('optim')
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.ones(3)
+    with pytest.raises(TypeError):
+        opt_mod.ClipAdamW([p], max_norm=1.0).step()
+    with pytest.raises(NotImplementedError):
+        opt_mod.ClipAdamW([dict(params=[torch.nn.Parameter(torch.ones(1))]), dict(params=[torch.nn.Parameter(torch.ones(1))])])
+    assert float(opt_mod.ClipAdamW([torch.nn.Parameter(torch.ones(2))]).step()) == 0.0     # nothing has a gradient

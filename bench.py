@@ -124,7 +124,8 @@ class LiftTrainer(torch.nn.Module):
             for s in range(0, bs, self.micro):
                 nb = min(self.micro, bs - s)
                 # (logits stay in the GEMMs' row order, the targets are permuted to match: same loss, same gradients)
-                total = total + self.head.occupancy_loss_from_volume(emb[s:s + nb], gt[s:s + nb]) * nb
+                part = emb if nb == bs else emb[s:s + nb]          # (the whole batch: the tensor itself, with its bf16 side copy)
+                total = total + self.head.occupancy_loss_from_volume(part, gt[s:s + nb]) * nb
         return total / bs
 
 

@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from ..modules.bricks import BaseModule, const_tensor
+from ..modules.bricks import BaseModule, const_tensor, lowp_view
 from ..modules.voxel_decoder import inverse_sigmoid
 from ..registry import (HEADS, build_bbox_coder, build_loss, build_positional_encoding,
                         build_transformer)
@@ -245,6 +245,11 @@ class VoxelFormerOccupancyHead(BaseModule):
         ``rows_only`` (lattice path): return ``(logits [bs*X*Y, Z, classes] in GEMM row order, plan, bs)`` instead."""
         bs = voxel_embed.shape[0]
         c = self.embed_dims
+        # under bf16 autocast the encoder's last LayerNorm wrote the bf16 copy of its output next to the fp32 one
+        # (bricks.residual_layer_norm): the lattice path would make exactly that copy again (and widen its gradient)
+        lowp = lowp_view(voxel_embed)
+        if lowp is not voxel_embed and lowp.shape == voxel_embed.shape and lowp.is_contiguous():
+            voxel_embed = lowp
         voxel_embed = voxel_embed.contiguous()
         if self.refine_occ:
             x = voxel_embed.view(bs, c, self.bev_z, self.bev_h, self.bev_w)          # raw view :558

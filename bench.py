@@ -257,10 +257,14 @@ def measured_traffic(kernels, B):
     return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, os.path.basename(files[-1])
 
 
-def cpu_baseline(head, syn, seconds):
+def cpu_baseline(head, syn, seconds, dev=None, dtype='bf16'):
     """The CPU oracle (oracle/ver_oracle.py = pinned restatement of the reference) on this host's cores: the vocc.py
     lifting path fwd+bwd at FULL size, one viewpoint per pass (the reference's samples_per_gpu=1): 1 untimed warm-up
-    pass, then timed passes until `seconds` are spent (at least 5, at most 10); value = 1 / median pass time."""
+    pass, then timed passes until `seconds` are spent (at least 5, at most 10); value = 1 / median pass time.
+    The warm-up pass doubles as a PARITY PROBE of the run that was just timed (`dev` given): the product evaluates the same
+    viewpoint, labels and (post-step) parameters on the GPU in the bench's arithmetic -- one forward + backward of the
+    training kernels, dropout off -- and `loss_oracle`, `loss_gpu`, `rel_diff` (+ the gradient norms over the path's
+    parameters) go on the line; main() exits non-zero when the losses are more than 2e-2 apart."""
     oracle = importlib.import_module('oracle.ver_oracle')
     # all cores of a 256-thread host oversubscribe these small CPU ops (measured 6x slower than 8
     # threads); 16 is near the knee.  `cores` reports what was actually used.
@@ -280,23 +284,58 @@ def cpu_baseline(head, syn, seconds):
     feats = torch.from_numpy(syn.vit_features(1, seed=0))[0].unsqueeze(1)
     gt = torch.from_numpy(np.random.default_rng(3).integers(0, 17, size=504000))
 
-    def one_pass():
+    probe = {}
+
+    def one_pass(keep=False):
         t = time.perf_counter()
         _, occ = oracle.lifting_forward(p, feats, torch.from_numpy(w2p[0]), torch.from_numpy(org[0]))
         loss = oracle.focal_loss(occ[0], gt, avg_factor=(gt < 16).sum() * 1.0)
         loss.backward()
+        dt = time.perf_counter() - t
+        if keep:
+            probe['loss_oracle'] = float(loss)
+            probe['grad_norm_oracle'] = float(torch.sqrt(sum(v.grad.double().pow(2).sum() for k, v in p.items()
+                                                             if v.grad is not None and k in trained)))
         for v in p.values():
             v.grad = None
-        return time.perf_counter() - t
+        return dt
+
+    trained = {k for k, v in head.named_parameters() if v.requires_grad}
+    if dev is not None:
+        # the product on the same viewpoint / labels / parameters (before the oracle's threads are set: GPU work only)
+        was_training = head.training
+        head.eval()
+        for v in head.parameters():
+            v.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == 'bf16'):
+            emb = head(feats.to(dev), None, only_bev=True, world2pixel=torch.from_numpy(w2p).to(dev), origin=torch.from_numpy(org).to(dev))
+            loss_gpu = head.occupancy_loss_from_volume(emb, gt.to(dev)[None])
+        loss_gpu.backward()
+        torch.cuda.synchronize()
+        probe['loss_gpu'] = float(loss_gpu)
+        probe['grad_norm_gpu'] = float(torch.sqrt(sum(v.grad.double().pow(2).sum() for k, v in head.named_parameters()
+                                                      if v.grad is not None and k in trained)))
+        for v in head.parameters():
+            v.grad = None
+        head.train(was_training)
+        del emb, loss_gpu
 
     t0 = time.perf_counter()
-    warm = one_pass()
+    warm = one_pass(keep=True)
+    if dev is not None:
+        probe['rel_diff'] = abs(probe['loss_gpu'] - probe['loss_oracle']) / max(abs(probe['loss_oracle']), 1e-30)
+        probe['grad_norm_rel_diff'] = abs(probe['grad_norm_gpu'] - probe['grad_norm_oracle']) / max(probe['grad_norm_oracle'], 1e-30)
+        probe = {k: float('%.6g' % v) for k, v in probe.items()}
+        probe['probe'] = ('viewpoint seed 0 / rig seed 1 / labels seed 3 through the product at 1 viewpoint per step (%s, training '
+                          'kernels, dropout off) against the oracle\'s warm-up pass on the same post-step parameters' % dtype)
+    else:
+        probe = {}
     times = []
     while len(times) < 5 or (len(times) < 10 and time.perf_counter() - t0 + warm < seconds):
         times.append(one_pass())
     med = statistics.median(times)
     return dict(value=1.0 / med, unit='viewpoints/s', cores=torch.get_num_threads(), kind='port',
-                host_threads=host_threads, cpu_model=cpu_model, passes=len(times), warmup_passes=1,
+                host_threads=host_threads, cpu_model=cpu_model, passes=len(times), warmup_passes=1, **probe,
                 median_s=round(med, 3), min_s=round(min(times), 3), max_s=round(max(times), 3),
                 sample='%d timed single-viewpoint passes after 1 warm-up (median), vocc.py 15x15x4 -> 120x120x35x16 '
                        'lifting path fwd+bwd at full size, fp32, oracle/ver_oracle.py (torch-CPU, %d threads of %d), '
@@ -586,6 +625,7 @@ def main():
         for name in [x.strip() for x in args.sub_records.split(',') if x.strip()]:
             subs[name.partition(':')[0]] = sub_record(args, name, dev, rank, world, distributed)
 
+    exit_code = 0
     if rank == 0:
         kt = timer.summary()
         hit = hip.project_points(w2p, org, head.point_cloud_range, head.bev_z, head.bev_h, head.bev_w)
@@ -674,13 +714,20 @@ def main():
             'roofline': roof, 'roofline_other_kernels': others,
         }
         if world == 1 and not args.no_cpu_baseline and train and not full:
-            line['cpu_baseline'] = cpu_baseline(head, syn, args.cpu_seconds)
+            line['cpu_baseline'] = cpu_baseline(head, syn, args.cpu_seconds, dev, args.dtype)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
+        cb = line['cpu_baseline']
+        if cb and cb.get('rel_diff') is not None and not cb['rel_diff'] <= 2e-2:
+            print('bench.py: PARITY PROBE FAILED: loss on the GPU %.6g, oracle %.6g (rel. diff %.3g > 2e-2)'
+                  % (cb['loss_gpu'], cb['loss_oracle'], cb['rel_diff']), file=sys.stderr)
+            exit_code = 3
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == '__main__':

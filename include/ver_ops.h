@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VER_ABI_VERSION 28
+#define VER_ABI_VERSION 29
 
 #define VER_OK            0
 #define VER_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -500,6 +500,18 @@ int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* 
 int ver_clip_adamw_step(void* const* table, const long* sizes, const int* chunk_tensor, const int* chunk_index,
                         int n_tensors, int n_chunks, int chunk_elems, float* partial, float* norm_out, float max_norm,
                         float lr, float beta1, float beta2, float eps, float weight_decay, long step, void* stream);
+
+/* The same step with PER-TENSOR hyper-parameters and update counts (ABI 29; several parameter groups -- vocc.py:260-267
+ * `paramwise_cfg` gives img_backbone its own lr -- and parameters that received their first gradient at different steps;
+ * torch.optim.AdamW tracks `step` per parameter), everything the launch reads resident on the device so that a captured
+ * hipGraph of the step replays correctly:
+ *   hyper   device float [n_tensors][6] = lr, beta1, beta2, eps, weight_decay, (unused) of tensor t
+ *   steps   device int   [n_tensors]    = updates applied to tensor t so far; this call adds 1 to every entry and uses the
+ *                                         new value in the bias corrections 1 - beta^step
+ * The clip norm is global over all tensors, as in clip_grad_norm_; a non-finite norm gives a NaN factor (torch.clamp). */
+int ver_clip_adamw_step_tensors(void* const* table, const long* sizes, const int* chunk_tensor, const int* chunk_index,
+                                const float* hyper, int* steps, int n_tensors, int n_chunks, int chunk_elems, float* partial,
+                                float* norm_out, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -173,6 +173,13 @@ def test_argument_validation_of_the_gemm_entry_points():
     assert rc == -1 and b'hyper-parameters' in lib.ver_last_error()
     rc = lib.ver_clip_adamw_step(*adam(None))
     assert rc == -1 and b'null' in lib.ver_last_error()
+    # ver_clip_adamw_step_tensors (ABI 29): per-tensor hyper-parameters and device-side update counts
+    adam_t = lambda tab, n=1, chunks=1, chunk=1024, hyper=buf, steps=buf: (tab, tab, tab, tab, hyper, steps, n, chunks, chunk, tab, None, F(1.0), None)
+    assert lib.ver_clip_adamw_step_tensors(*adam_t(None, n=0, chunks=0)) == 0
+    rc = lib.ver_clip_adamw_step_tensors(*adam_t(buf, chunk=1022))
+    assert rc == -1 and b'bad sizes' in lib.ver_last_error()
+    rc = lib.ver_clip_adamw_step_tensors(*adam_t(buf, steps=None))
+    assert rc == -1 and b'null' in lib.ver_last_error()
     # the MLP entries with the saved statistics: the rstd pointer must be 8-byte aligned and N < 2^28
     off = ctypes.cast(ctypes.addressof(buf) + 4, ctypes.c_void_p)
     rc = lib.ver_occ_mlp_forward_stats(buf, buf, buf, buf, off, L(4), 128, 16, ctypes.c_float(1e-5), 2, None)

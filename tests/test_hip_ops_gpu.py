@@ -1538,3 +1538,74 @@ def test_clip_adamw_equals_clip_grad_norm_plus_torch_adamw(max_norm):
     cpu_p.grad = torch.ones(3)
     with pytest.raises(TypeError):
         opt_mod.ClipAdamW([cpu_p], max_norm=1.0).step()
+
+
+def test_clip_adamw_survives_state_reload_groups_late_parameters_and_nan():
+    """``optim.ClipAdamW`` against torch (round-5 advisor findings): (a) step, ``state_dict`` -> ``load_state_dict`` (new moment
+    tensors, steps as loaded), step again -- the RESTORED moments are the ones that keep moving; (b) a torch AdamW
+    checkpoint (one step tensor per parameter) loads; (c) two parameter groups with their own lr / weight decay
+    (vocc.py:260-267 paramwise_cfg) under ONE global clip norm; (d) a parameter whose first gradient arrives two steps
+    late gets its own bias corrections; (e) ``p.data`` moved to new storage is followed; (f) a NaN gradient poisons every
+    parameter, as ``clip_grad_norm_`` + AdamW does, instead of leaving the finite ones unclipped."""
+    opt_mod = pkg('optim')
+    gen = torch.Generator(device='cpu').manual_seed(78)
+    shapes = [(3000,), (17, 5), (40000,)]
+    base = [torch.randn(s, generator=gen) for s in shapes]
+    near = lambda x, y: close(x.cpu(), y.cpu(), atol=3e-6 * max(float(y.abs().max()), 1e-30), rtol=3e-6)
+
+    def make():
+        return [torch.nn.Parameter(b.clone().to(DEV)) for b in base]
+
+    def groups(ps):
+        return [dict(params=ps[:2], lr=3e-3, weight_decay=0.05), dict(params=ps[2:], lr=3e-4, weight_decay=0.0)]
+    ours, ref = make(), make()
+    a = opt_mod.ClipAdamW(groups(ours), betas=(0.9, 0.99), max_norm=0.7)
+    b = torch.optim.AdamW(groups(ref), betas=(0.9, 0.99))
+
+    def both(it, late=2):
+        for i, (p, q) in enumerate(zip(ours, ref)):
+            if i == 1 and it < late:                                # (d): no gradient for the first `late` steps
+                p.grad = q.grad = None
+                continue
+            g = torch.randn(p.shape, generator=gen)
+            p.grad, q.grad = g.clone().to(DEV), g.clone().to(DEV)
+        torch.nn.utils.clip_grad_norm_([q for q in ref if q.grad is not None], 0.7)
+        b.step()
+        a.step()
+        for p, q in zip(ours, ref):
+            assert near(p.detach(), q.detach()), it
+    for it in range(4):
+        both(it)
+    assert a.state[ours[0]]['step'] == 4 and a.state[ours[1]]['step'] == 2
+    # (a) reload our own state: new tensors behind the same parameters
+    a.load_state_dict(a.state_dict())
+    b.load_state_dict(b.state_dict())
+    both(4)
+    for p, q in zip(ours, ref):
+        assert near(a.state[p]['exp_avg'], b.state[q]['exp_avg']) and near(a.state[p]['exp_avg_sq'], b.state[q]['exp_avg_sq'])
+    # (b) a torch checkpoint into ours (step tensors) and ours into torch
+    a.load_state_dict(b.state_dict())
+    both(5)
+    b.load_state_dict(a.state_dict())
+    both(6)
+    assert a.state[ours[0]]['step'] == 7 and a.state[ours[1]]['step'] == 5
+    # (e) the parameter's storage moves
+    for p, q in zip(ours, ref):
+        p.data = p.data.clone()
+        q.data = q.data.clone()
+    both(7)
+    # a scheduler moves lr of one group
+    a.param_groups[1]['lr'] = b.param_groups[1]['lr'] = 1e-3
+    both(8)
+    # (f) one NaN in one gradient
+    for p, q in zip(ours, ref):
+        g = torch.randn(p.shape, generator=gen)
+        p.grad, q.grad = g.clone().to(DEV), g.clone().to(DEV)
+    ours[2].grad[5] = float('nan')
+    ref[2].grad[5] = float('nan')
+    torch.nn.utils.clip_grad_norm_(ref, 0.7)
+    b.step()
+    norm = a.step()
+    assert bool(torch.isnan(norm))
+    for p, q in zip(ours, ref):
+        assert bool(torch.isnan(q).all()) and bool(torch.isnan(p).all())

@@ -195,3 +195,27 @@ def test_voxel_msda_core_forward_backward(name):
     assert close(value.grad[:, ::3], g['grad_value'])
     assert close(loc.grad, g['grad_loc'])
     assert close(w.grad, g['grad_w'])
+
+
+def test_lifting_path_oracle_matches_the_reference_head_vectors():
+    """a10 pinned DIRECTLY: ``oracle.lifting_forward`` (encoder + ``occ_head_forward``, the reference's raw ``.view``s,
+    ConvTranspose3d stack, occ_proj, occ_branches; head:554-580) on the seed-7 vocc.py head against the logits the
+    reference's own ``VoxelFormerOccupancyHead.forward`` produced for the same parameters and inputs
+    (tests/golden/head_vocc.npz, make_golden_head.py) -- no product code between the oracle and the reference's vectors
+    (the package only names and seeds the parameters)."""
+    o = oracle()
+    syn = pkg('synthetic')
+    g = golden('head_vocc')
+    head = pkg('registry').build_head(cases.vocc_head_cfg())
+    code_weights = head.code_weights.detach().clone()
+    syn.load_seeded(head, 7)
+    head.code_weights.data.copy_(code_weights)
+    p = {k: v.detach().clone() for k, v in head.state_dict().items()}
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = syn.vit_features(2, seed=0)
+    with torch.no_grad():
+        bev, occ = o.lifting_forward(p, T(feats[0]).unsqueeze(1), T(w2p[0]), T(org[0]))
+    assert occ.shape == (1, 504000, 16)
+    assert maxdiff(bev[0, ::7], g['c3_b0_bev']) < TOL
+    assert close(occ[0, ::997], g['c3_b0_occ'], atol=1e-4, rtol=1e-4)
+    assert abs(float(occ.double().norm()) - float(g['c3_b0_occ_norm'])) < 1e-4 * float(g['c3_b0_occ_norm'])

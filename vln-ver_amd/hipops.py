@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # (VER_HIP_LIB: another build of the same ABI, e.g. the host-ASan build libver_hip_asan.so of tests/test_abi_cpu.py)
 LIB_PATH = os.environ.get('VER_HIP_LIB') or os.path.join(_PKG, 'libver_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', 'ver_msda_forward', 'ver_msda_backward',
            'ver_project_points', 'ver_hits_from_mask', 'ver_sca_zero_rows', 'ver_sca_head_major_supported',
            'ver_sca_forward', 'ver_sca_backward',
@@ -26,7 +26,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_clip_adamw_step')
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
 
 _lib = None
 

@@ -66,9 +66,11 @@ def parse():
                     help='viewpoints per GPU and step of the untimed-by-headline config.latency records (SURVEY 8d C4: '
                          'vocc.py runs samples_per_gpu=1); empty string: none')
     ap.add_argument('--latency-steps', type=int, default=10)
-    ap.add_argument('--graph-max-batch', type=int, default=4,
-                    help='config.latency records of the full multi-task workload up to this many viewpoints per step replay '
-                         'the head as hipGraphs (one rank only; 0: always eager)')
+    ap.add_argument('--graph-max-batch', type=int, default=8,
+                    help='config.latency records up to this many viewpoints per step are hipGraph replays (one rank only; 0: '
+                         'always eager): the lifting step as ONE graph of forward + loss + backward + ClipAdamW '
+                         '(graphs.GraphedLiftStep), the full multi-task workload with its head forward / backward as two graphs '
+                         '(graphs.GraphedHead; capped at 4 viewpoints there)')
     ap.add_argument('--graph-full-train', type=int, default=0,
                     help='config.full_train sub-record (64 viewpoints per step, one rank): 0 (default) = the eager step, whose '
                          'Hungarian assignment is started in forward() and solved on the host under the occupancy head '
@@ -494,6 +496,11 @@ def main():
         -- Hungarian targets, loss terms, clip, AdamW -- runs as in the eager step."""
         f, w, o, g = feats[:, :nb].contiguous(), w2p[:nb], org[:nb], gt[:nb]
         gb, gl = (gt_boxes[:nb], gt_labels[:nb]) if full else (None, None)
+        if graph and not full:
+            # the whole lifting step as one hipGraph (its construction runs three eager steps, then captures)
+            lift = importlib.import_module('vln-ver_amd.graphs').GraphedLiftStep(model, opt, f, w, o, g)
+            f, w, o, g = lift.inputs
+            return lambda: lift(f, w, o, g)
         if graph:
             graphed = importlib.import_module('vln-ver_amd.graphs').GraphedHead(
                 head, f, w, o, autocast_dtype=torch.bfloat16 if args.dtype == 'bf16' else None)
@@ -570,7 +577,9 @@ def main():
             continue
         # the full multi-task step is host bound at these sizes (~1 500 module calls + as many autograd nodes): on one
         # rank its forward / backward are replayed as hipGraphs; `graphed` in the record says which form was timed
-        small = make_step(nb, graph=full and not distributed and nb <= args.graph_max_batch)
+        graphed = not distributed and (nb <= min(args.graph_max_batch, 4) if full
+                                       else nb <= args.graph_max_batch and not args.torch_optimizer)
+        small = make_step(nb, graph=graphed)
         for _ in range(3):
             small()
         torch.cuda.synchronize()
@@ -587,7 +596,7 @@ def main():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ms = float(dt) / args.latency_steps * 1e3
         latency.append(dict(viewpoints_per_gpu_per_step=nb, steps=args.latency_steps, warmup=3,
-                            graphed=full and not distributed and nb <= args.graph_max_batch,
+                            graphed=graphed,
                             ms_per_step=round(ms, 3), viewpoints_per_s=round(nb * world / ms * 1e3, 2)))
 
     # config.host_fed: the step as the reference's detector drives it -- the six feature maps of every viewpoint arrive

@@ -269,6 +269,23 @@ int ver_convt_weight_backward(const void* grad_taps, float* grad_weight, long pa
  *       the offsets must be even too (4-byte loads; the layers' offsets row * ld + {0, co} are). */
 int ver_convt_weight_backward_blocks(const void* blocks, const long* block_offsets, long ld, const void* prev_bias,
                                      const void* grad_v, float* grad_weight, int ci, int co, int dtype, void* stream);
+/*   ver_convt_weight_forward_blocks (ABI 29): the forward twin -- the f32 ConvTranspose3d weight [ci*co][75] written STRAIGHT
+ *       into the weight matrices the class GEMMs of a lattice layer read: tap t's [ci x co] block goes to element offsets
+ *       block_offsets[2t], block_offsets[2t+1] (-1 = none) of `blocks` (row pitch ld, `dtype`): its "lower half" / "upper
+ *       half" slots in the class-stacked [sum K_c, 2 co] matrix.  Replaces ver_convt_weight_forward + a concatenation with the
+ *       constant rows + one row gather per parity class (dense_heads/upsample.py).  Even co / ld / offsets.
+ *   ver_blocks_vec_forward / _backward (ABI 29): a row vector through every [ci x ncols] block of such a stacked matrix:
+ *       vec[b][col] = sum_ci x[ci] * blocks[(block_rows[b] + ci) * ld + col]   (the previous layer's bias seen through every
+ *       tap, head:251-258's bias-valued odd positions: v = b_prev^T K[t] for all taps in one pass over the bf16 weights),
+ *       grad_x[ci] = sum_b sum_col blocks[(block_rows[b] + ci) * ld + col] * grad_vec[b][col].  x, grad_vec f32.  Both write
+ *       PARTIAL results that the caller adds up in order (no atomics, bitwise reproducible): vec is f32 [8][nblocks][ncols]
+ *       (8 slices of ci), grad_x f32 [nblocks][ci] (one row per block).  block_rows: device int64 [nblocks]. */
+int ver_convt_weight_forward_blocks(const float* weight, const long* block_offsets, long ld, void* blocks, int ci, int co,
+                                    int dtype, void* stream);
+int ver_blocks_vec_forward(const void* blocks, const long* block_rows, int nblocks, long ld, int ci, int ncols, const float* x,
+                           float* vec, int dtype, void* stream);
+int ver_blocks_vec_backward(const void* blocks, const long* block_rows, int nblocks, long ld, int ci, int ncols,
+                            const float* grad_vec, float* grad_x, int dtype, void* stream);
 int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,
                           int C, int layout, int to_channel_first, int dtype, void* stream);
 /*   ver_lattice_rows : ver_lattice_transpose and ver_run_gather / _scatter (below) in ONE pass, bf16: the lattice
@@ -471,6 +488,9 @@ int  ver_occ_predict(const void* logits, int dtype, long N, int C, float thresho
  * flags (experiments; 0 = default): bits 0-2 = prefetch distance in 16-row slabs, bit 3 = two slabs per phase.
  */
 int  ver_wgrad_tn_splits(long M, int Ka, int N);
+/*   the same choice knowing the widest row pitch ld = max(lda, ldg) in elements (ABI 29): a row chunk has to stay inside the
+ *   4-GiB range of a buffer offset, so wide rows need more chunks than the default cap of 45 000 rows assumes */
+int  ver_wgrad_tn_splits_ld(long M, int Ka, int N, long ld);
 long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits);
 int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int Ka, int N, void* out, long ldo,
                   int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream);
@@ -485,6 +505,13 @@ int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int 
  */
 int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
                  int N, int flags, void* stream);
+/*   the same product cut into K slices (ABI 29) for SKINNY operands -- the 450- and 1 800-row tap matrices of a
+ *   one-viewpoint step (vocc.py:222 samples_per_gpu = 1) give 12-42 output tiles, a fraction of the chip: every slice's
+ *   partial tile stays fp32 in `workspace` (f32 [splits][M][N]) and one pass adds them up, adds the bias and rounds once.
+ *   ver_gemm_nn_splits: the slice count the library would pick (1: no workspace needed).  Needs N % 4 == 0, ldc % 4 == 0. */
+int  ver_gemm_nn_splits(long M, int K, int N);
+int  ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
+                        int N, int splits, void* workspace, long workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Gradient clipping by the global L2 norm + AdamW, one call per step (ABI 27).  Replaces, for fp32 parameters, the

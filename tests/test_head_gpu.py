@@ -628,3 +628,76 @@ def test_graphed_head_replays_the_eager_forward_and_backward():
     o2 = gt_(fa, wa, oa)
     assert float((o2['all_cls_scores'] - c1).abs().max()) > 0         # dropout masks differ between replays
     assert torch.isfinite(sum(head.loss([T(boxes[:, :7]).to(DEV)], [T(labels).to(DEV)], gt_occ, o2).values()))
+
+
+class _LiftModel(torch.nn.Module):
+    """bench.py's LiftTrainer at one micro-batch: (feats, w2p, org, gt) -> occupancy loss."""
+
+    def __init__(self, head, autocast):
+        super().__init__()
+        self.head, self.autocast = head, autocast
+
+    def forward(self, feats, w2p, org, gt):
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=self.autocast):
+            emb = self.head(feats, None, only_bev=True, world2pixel=w2p, origin=org)
+            return self.head.occupancy_loss_from_volume(emb, gt)
+
+
+@pytest.mark.parametrize('autocast', [False, True])
+def test_graphed_lift_step_replays_the_eager_training_steps(autocast):
+    """graphs.GraphedLiftStep: forward + occupancy loss + backward + ``ClipAdamW`` of the lifting path as ONE hipGraph (the
+    reference's samples_per_gpu = 1 operating point, vocc.py:222).  Two identical heads take the same five steps on
+    alternating viewpoints -- one eagerly, one as 1 eager warm-up step + 4 replays (the inputs of replays 2 and 4 differ
+    from the ones captured with): the losses of every step, the update counts, and the parameters after the five steps
+    agree (the update of step k depends on AdamW's bias corrections 1 - beta^k: a replay that did not advance the
+    device-side counts would scale the step by 1.9x at k = 2)."""
+    import copy
+    syn, graphs, opt_mod = pkg('synthetic'), pkg('graphs'), pkg('optim')
+    base = _head(cases.vocc_head_cfg(), 7)
+    lift = ('transformer.encoder.', 'transformer.level_embeds', 'transformer.cams_embeds', 'voxel_embedding.', 'up_sample.',
+            'occ_proj.', 'occ_branches.')
+    for k, p in base.named_parameters():
+        p.requires_grad_(k.startswith(lift))
+    heads = [base, copy.deepcopy(base)]
+    before = {k: p.detach().clone() for k, p in base.named_parameters() if p.requires_grad}
+    w2p, org = syn.camera_batch(2, seed=1)
+    feats = T(syn.vit_features(2, seed=0)).to(DEV)
+    gts = T(np.random.default_rng(3).integers(0, 17, size=(2, 1, 504000))).to(DEV)
+    ins = [(feats[b].unsqueeze(1).contiguous(), T(w2p[b:b + 1]).to(DEV), T(org[b:b + 1]).to(DEV), gts[b]) for b in range(2)]
+    models = [_LiftModel(h, autocast) for h in heads]                 # (eval mode: no dropout, the steps are comparable)
+    opts = [opt_mod.ClipAdamW([p for p in h.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, max_norm=35.0)
+            for h in heads]
+    losses = [[], []]
+    for it in range(5):                                               # eager
+        opts[0].zero_grad(set_to_none=True)
+        loss = models[0](*ins[it % 2])
+        loss.backward()
+        opts[0].step()
+        losses[0].append(float(loss))
+    loss = None
+    step = graphs.GraphedLiftStep(models[1], opts[1], *ins[0], warmup=1)            # = step 0, eagerly, then the capture
+    for it in range(1, 5):
+        losses[1].append(float(step(*ins[it % 2])))
+    tol = 2e-3 if autocast else 1e-5
+    for a, b in zip(losses[0][1:], losses[1]):
+        assert abs(a - b) <= tol * abs(a), (losses[0], losses[1])
+    assert losses[0][1] != losses[0][3]                               # (the steps do move the loss: the comparison is not vacuous)
+    for p in heads[1].parameters():
+        if p.requires_grad:
+            assert opts[1].state[p]['step'] == 5
+    worst = 0.0
+    for (k, p), q in zip([(k, p) for k, p in heads[0].named_parameters() if p.requires_grad],
+                         [q for q in heads[1].parameters() if q.requires_grad]):
+        d_e, d_g = (p.detach() - before[k]).double(), (q.detach() - before[k]).double()
+        assert float(d_e.norm()) > 0
+        r = float((d_e - d_g).norm() / d_e.norm())
+        worst = max(worst, r)
+        # AdamW's early updates are ~ lr * sign(g): an element whose tiny gradient changes sign between two runs moves by
+        # 2 lr, so the bound is on the whole tensor's update, not element-wise
+        assert r < (0.2 if autocast else 0.05), (k, r)
+    print('graphed lifting step vs eager, %s: worst relative difference of a parameter update %.2e' % ('bf16' if autocast else 'fp32', worst))
+    # an eager step after the replays: the optimizer follows the new gradient buffers and counts on
+    opts[1].zero_grad(set_to_none=True)
+    models[1](*ins[1]).backward()
+    opts[1].step()
+    assert all(opts[1].state[p]['step'] == 6 for p in heads[1].parameters() if p.requires_grad)

@@ -1584,9 +1584,10 @@ def test_clip_adamw_survives_state_reload_groups_late_parameters_and_nan():
     for p, q in zip(ours, ref):
         assert near(a.state[p]['exp_avg'], b.state[q]['exp_avg']) and near(a.state[p]['exp_avg_sq'], b.state[q]['exp_avg_sq'])
     # (b) a torch checkpoint into ours (step tensors) and ours into torch
-    a.load_state_dict(b.state_dict())
-    both(5)
-    b.load_state_dict(a.state_dict())
+    import copy
+    a.load_state_dict(copy.deepcopy(b.state_dict()))        # (deep copies, like a checkpoint file: torch's loader keeps fp32 GPU
+    both(5)                                                  #  tensors as they are, and two optimizers would share their moments)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
     both(6)
     assert a.state[ours[0]]['step'] == 7 and a.state[ours[1]]['step'] == 5
     # (e) the parameter's storage moves
@@ -1609,3 +1610,70 @@ def test_clip_adamw_survives_state_reload_groups_late_parameters_and_nan():
     assert bool(torch.isnan(norm))
     for p, q in zip(ours, ref):
         assert bool(torch.isnan(q).all()) and bool(torch.isnan(p).all())
+
+
+@pytest.mark.parametrize('kind,ci,co,dtype', [('lat', 16, 8, torch.float32), ('lat', 768, 768, torch.bfloat16), ('l0', 24, 16, torch.bfloat16)])
+def test_class_stacked_weights_straight_from_the_parameter(kind, ci, co, dtype):
+    """ver_convt_weight_forward_blocks: the ConvTranspose3d weight (head:251-258) written into the class-stacked
+    [W_lo | W_hi] matrices of a Z = 4 lattice layer, against the passes it replaces (flipped taps -> row gathers per class,
+    dense_heads/upsample.py) -- pure data movement + one rounding: bit-exact; rows of the constant blocks untouched.
+    ver_blocks_vec_forward / _backward: a vector through every tap block of the stacked matrix (v = b_prev^T K[t]) and its
+    adjoint, against the batched products over the tap tensor."""
+    hip, up = pkg('hipops'), pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(91)
+    w = torch.randn(ci, co, 3, 5, 5, generator=gen)
+    k = up._corr_weight(w, dtype)                                               # [75, ci, co] (CPU: flip + permute)
+    rows = k.reshape(75 * ci, co)
+    if kind == 'l0':
+        _, _, lo, hi = up._layer0_z4_plan(ci, 'cpu')
+        want = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)
+        got = hip.convt_weight_forward_blocks(w.to(DEV), up._block_offsets('l0', ci, co, torch.device(DEV)),
+                                              torch.full((50 * ci, 2 * co), 7.0, dtype=dtype, device=DEV), ci, co)
+        assert torch.equal(got.cpu(), want)
+        return
+    plan, kt, total_rows, _, _ = up._layer_plan_z4(ci, 'cpu')
+    big = torch.cat([rows, torch.full((total_rows - 75 * ci, co), 7.0, dtype=dtype)])     # constant rows: a marker value
+    want = torch.cat([big.index_select(0, plan[cls][4]).view(-1, 2 * co) for cls in up._CLASSES])
+    stack = torch.full(want.shape, 7.0, dtype=dtype, device=DEV)
+    hip.convt_weight_forward_blocks(w.to(DEV), up._block_offsets('lat', ci, co, torch.device(DEV)), stack, ci, co)
+    assert torch.equal(stack.cpu(), want)
+    block_rows, tap_slot, const_rows, const_src = up._stack_tables_z4(ci, torch.device(DEV))
+    # every constant row of the stacked matrix is in const_rows, and nothing else is
+    marks = (stack.view(-1, co) == 7.0).all(1).nonzero().squeeze(1)
+    assert torch.equal(marks.sort().values, const_rows.sort().values)
+    x = torch.randn(ci, generator=gen)
+    v = hip.blocks_vec_forward(stack, block_rows, ci, x.to(DEV)).view(-1, co).index_select(0, tap_slot)
+    want_v = torch.einsum('c,tcd->td', x.double(), k.double())
+    assert close(v.cpu(), want_v, atol=1e-4 * float(want_v.abs().max()), rtol=1e-5)
+    dv = torch.randn(75, co, generator=gen)
+    dv2 = torch.zeros(100, co, device=DEV).index_copy_(0, tap_slot, dv.to(DEV)).view(50, 2 * co)
+    dx = hip.blocks_vec_backward(stack, block_rows, ci, dv2)
+    want_dx = torch.einsum('tcd,td->c', k.double(), dv.double())
+    assert close(dx.cpu(), want_dx, atol=1e-4 * float(want_dx.abs().max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize('M,K,lda,c0,N,splits', [(450, 38400, 38400, 0, 1536, None), (1800, 9536, 14464, 1696, 1536, None),
+                                                  (450, 6304, 14464, 4928, 1536, 5), (77, 2048, 2048, 0, 260, 4), (300, 4096, 4096, 0, 1536, 64)])
+def test_gemm_nn_split_over_k_for_skinny_operands(M, K, lda, c0, N, splits):
+    """ver_gemm_nn_splitk: the forward product of a lattice layer at the reference's own batch point (vocc.py:222, one viewpoint
+    per step: 450 / 1 800 rows) cut into K slices with fp32 partial tiles -- the library's choice of slices and explicit ones
+    (uneven last slice, more slices than 512-column pieces), a column range of a wider tap matrix, results into a column
+    range of a wider output; against the fp32 product rounded once, and against the one-pass kernel."""
+    hip = pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(M + K)
+    Af = torch.randn(M, lda, generator=gen).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(K, N, generator=gen) * 0.05).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, generator=gen).to(DEV)
+    A = Af[:, c0:c0 + K]
+    want = A.float() @ W.float() + b
+    if splits is None:
+        assert hip.gemm_nn_splits(M, K, N) > 1
+    wide = torch.full((M, N + 16), 7.0, device=DEV, dtype=torch.bfloat16)
+    got = hip.gemm_nn(A, W, b, out=wide[:, 8:8 + N], splits=splits)
+    from util import rel_l2
+    assert rel_l2(got.float(), want) < 3e-3
+    assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    assert float(wide[:, :8].min()) == 7.0 and float(wide[:, 8 + N:].min()) == 7.0
+    one = hip.gemm_nn(A, W, b, splits=1)
+    assert rel_l2(got.float(), one.float()) < 3e-3                       # (fp32 sums in another order, one rounding each)
+    assert hip.gemm_nn_splits(345600, 14304, 1536) == 1                   # the tall products stay one pass

@@ -253,6 +253,9 @@ def test_clip_adamw_has_no_cpu_path():
     p.grad = torch.ones(3)
     with pytest.raises(TypeError):
         opt_mod.ClipAdamW([p], max_norm=1.0).step()
-    with pytest.raises(NotImplementedError):
-        opt_mod.ClipAdamW([dict(params=[torch.nn.Parameter(torch.ones(1))]), dict(params=[torch.nn.Parameter(torch.ones(1))])])
+    # several parameter groups are fine (vocc.py:260-267 paramwise_cfg), one clip norm for all of them
+    two = opt_mod.ClipAdamW([dict(params=[torch.nn.Parameter(torch.ones(1))], lr=1e-3),
+                             dict(params=[torch.nn.Parameter(torch.ones(1))], lr=1e-4, max_norm=2.0)], max_norm=1.0)
+    with pytest.raises(ValueError, match='one max_norm'):
+        two.step()
     assert float(opt_mod.ClipAdamW([torch.nn.Parameter(torch.ones(2))]).step()) == 0.0     # nothing has a gradient

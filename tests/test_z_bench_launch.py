@@ -155,6 +155,57 @@ def test_two_ranks_allreduce_the_gradients_of_the_real_step(tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_apply_the_same_clipped_adamw_update_on_the_bucket_views(tmp_path):
+    """The rest of bench.py's N > 1 step that one GPU can check: after the all-reduce, ``optim.ClipAdamW`` reads the gradients
+    where DDP left them -- views into its buckets (``gradient_as_bucket_view=True``) -- on two gloo ranks sharing the GPU.
+    Both ranks must end with BIT-IDENTICAL parameters (same gradients, same deterministic norm, same arithmetic), equal to
+    a single-process step on the mean of the two ranks' single-process gradients, and the clip norm each gets back is the
+    norm of the all-reduced gradients (reference: OptimizerHook's clip_grad_norm_ + AdamW behind
+    MMDistributedDataParallel, apis/mmdet_train.py:71-80, vocc.py:268-274)."""
+    import torch
+    helper = os.path.join(ROOT, 'tests', 'ddp_grad_helper.py')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    singles = []
+    for r in (0, 1):
+        out = str(tmp_path / ('single%d.pt' % r))
+        proc = subprocess.run([sys.executable, helper, 'single', str(r), out], env=env, capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, proc.stderr[-4000:]
+        singles.append(out)
+    ref_out = str(tmp_path / 'single_update.pt')
+    proc = subprocess.run([sys.executable, helper, 'single_update', singles[0], singles[1], ref_out], env=env, capture_output=True,
+                          text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    out = str(tmp_path / 'ddp_update.pt')
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                           '--master-addr', '127.0.0.1', '--master-port', str(port), helper, 'ddp_update', out],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    r0, r1, ref = torch.load(out + '.0'), torch.load(out + '.1'), torch.load(ref_out)
+    assert r0['grad_views'] == len(r0['digest']) > 50                      # the optimizer did read bucket views
+    assert r0['digest'] == r1['digest']                                    # bit-identical parameters on both ranks
+    assert r0['clip_norm'] == r1['clip_norm']
+    assert abs(r0['clip_norm'] - r0['grad_norm']) <= 1e-5 * r0['grad_norm']
+    assert abs(r0['clip_norm'] - ref['clip_norm']) <= 1e-5 * ref['clip_norm']
+    assert r0['clip_norm'] > 10 * 1e-3                                      # (the clip at 1e-3 was active)
+    lr, off = 1e-4, 0
+    for k, want in ref['sample'].items():
+        d = (r0['sample'][k] - want).abs()
+        # the first AdamW step moves every element by ~lr * sign(g): elements whose gradient is within rounding of zero may
+        # differ by up to 2 lr between two evaluations of the same mean; everything else to fp32 rounding
+        assert float(d.max()) <= 2.001 * lr, (k, float(d.max()))
+        off += int((d > 1e-3 * lr).sum())
+    total = sum(v.numel() for v in ref['sample'].values())
+    assert off <= 2e-3 * total, (off, total)
+    print('two-rank ClipAdamW update: clip norm %.6g, %d of %d sampled parameters more than 1e-3 lr from the single-process step'
+          % (r0['clip_norm'], off, total))
+
+
+@pytest.mark.gpu
 def test_bf16_compressed_gradients_under_rccl_equal_the_rounded_single_process_gradients(tmp_path):
     """The gradient path bench.py uses for N > 1 -- RCCL communicator + DDP buckets + `bf16_compress_hook`
     (vln-ver_amd/ddp.py:62-69; reference: MMDistributedDataParallel, apis/mmdet_train.py:71-80) -- checked NUMERICALLY on

@@ -14,7 +14,9 @@
 //   * W is streamed in 16-row slabs and read through ds_read_b64_tr_b16 exactly as both operands of k_wgrad_tn;
 //   * a phase is 32 of K (two MFMA k-steps: 8 + 8 fragment reads, 4 LDS-DMA pieces, 16 MFMAs per wave), the ring holds
 //     four phases (128 KB), pieces are requested two phases ahead;
-//   * no split over K (K = 6 304 .. 38 400 here: 197+ phases per tile); tiles are dealt to the XCDs in contiguous
+//   * no split over K for the tall products (K = 6 304 .. 38 400 here: 197+ phases per tile; skinny ones -- the 450- and
+//     1 800-row operands of a one-viewpoint step, 12-42 tiles -- are cut into K slices with fp32 partial tiles, see
+//     ver_gemm_nn_splitk); tiles are dealt to the XCDs in contiguous
 //     ranges, the N tiles of one row block next to each other, so that the 32 tiles in flight on an XCD share their A
 //     rows and W columns in its L2.
 #include "ver_common.h"
@@ -56,6 +58,8 @@ struct GemmArgs {
     __bf16* C;
     long lda, ldw, ldc, M;
     int K, N, tiles_n, T, per_xcd;
+    int S, Kc;              // split over K (skinny products: a one-viewpoint step has 450 / 1 800 rows, 12-42 tiles):
+    float* ws;              //   S slices of Kc columns, fp32 partial tiles [S][M][N], added up by k_gemm_reduce
 };
 
 struct GemmLane {
@@ -137,19 +141,21 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     // block b runs on XCD b % 8; an XCD works through a contiguous range of tiles (N tiles of a row block adjacent)
-    const int tile = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= p.per_xcd || tile >= p.T) return;
+    const int item = (int)(blockIdx.x & 7) * p.per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= p.per_xcd || item >= p.T * p.S) return;
+    const int split = item / p.T, tile = item - split * p.T;
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
     const long row0 = (long)mt * kTile;
-    const int nphase = p.K / 32;
+    const int k0 = split * p.Kc, klen = min(p.Kc, p.K - k0);
+    const int nphase = klen / 32;
 
-    // A: rows row0 .. row0 + 255 (past M: zeros by the buffer range), the K columns of the operand
-    const __bf16* ab = p.A + row0 * p.lda;
-    const long abytes = ((p.M - row0 - 1) * p.lda + p.K) * 2;
+    // A: rows row0 .. row0 + 255 (past M: zeros by the buffer range), this slice's columns of the operand
+    const __bf16* ab = p.A + row0 * p.lda + k0;
+    const long abytes = ((p.M - row0 - 1) * p.lda + klen) * 2;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
-    // W: columns nt * 256 .., all K rows (behind the last element: zeros)
-    const __bf16* wb = p.W + (long)nt * kTile;
-    const long wbytes = ((long)(p.K - 1) * p.ldw + p.N - (long)nt * kTile) * 2;
+    // W: columns nt * 256 .., the slice's rows (behind the last element: zeros)
+    const __bf16* wb = p.W + (long)k0 * p.ldw + (long)nt * kTile;
+    const long wbytes = ((long)(klen - 1) * p.ldw + p.N - (long)nt * kTile) * 2;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)max(0L, min(wbytes, 0xFFFFFFFFL)), 0x00020000);
     GemmLane c;
     {
@@ -215,6 +221,24 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    if (p.S > 1) {
+        // partial tile of this K slice -> workspace (fp32, [S][M][N]); bias and rounding happen in k_gemm_reduce
+        float* out = p.ws + (long)split * p.M * p.N;
+        const long i0 = row0 + 128 * wr + 4 * (lane >> 5);
+        const int j0 = nt * kTile + 64 * wc + (lane & 31);
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j = j0 + 32 * jt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long i = i0 + 32 * it + (r & 3) + 8 * (r >> 2);
+                    if (i < p.M && j < p.N) out[i * p.N + j] = acc[it][jt][r];
+                }
+            }
+        return;
+    }
     // C tile: register r of tile (it, jt) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31.  Buffer stores:
     // one 32-bit lane offset + a scalar row offset per store; rows past M fall outside the range and are dropped, columns
     // past N are sent there on purpose.
@@ -237,15 +261,64 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
             }
     }
 }
+// C[i][j] (bf16, row pitch ldc) = sum over the S partial products + bias[j]; 4 columns per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void k_gemm_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                     __bf16* __restrict__ c, long ldc, int S, long M, int N) {
+    const long n4 = M * N / 4;
+    const long stride = M * N;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        float4 acc = *reinterpret_cast<const float4*>(ws + 4 * e);
+        for (int s = 1; s < S; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + s * stride + 4 * e);
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+        const long i = (4 * e) / N;
+        const int j = (int)(4 * e - i * N);
+        if (bias) acc.x += bias[j], acc.y += bias[j + 1], acc.z += bias[j + 2], acc.w += bias[j + 3];
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 v;
+        v.x = (__bf16)acc.x, v.y = (__bf16)acc.y, v.z = (__bf16)acc.z, v.w = (__bf16)acc.w;
+        *reinterpret_cast<bf16x4*>(c + i * ldc + j) = v;
+    }
+}
+
+// K slices of a skinny product: enough workgroups to fill the chip (>= ~192), slices of at least 512 columns (16 phases: the
+// fill / drain of the ring is ~6), whole phases of 32
+int pick_k_splits(long M, int K, int N) {
+    const long tiles = ((M + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
+    if (tiles >= 96 || K < 2048 || N % 4) return 1;
+    int s = (int)((224 + tiles - 1) / tiles);
+    if (s > K / 512) s = K / 512;
+    if (s > 64) s = 64;
+    return s < 2 ? 1 : s;
+}
 }  // namespace
+
+extern "C" int ver_gemm_nn_splits(long M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 1;
+    return pick_k_splits(M, K, N);
+}
+
+extern "C" int ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M,
+                                  int K, int N, int splits, void* workspace, long workspace_bytes, void* stream);
 
 extern "C" int ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M,
                            int K, int N, int flags, void* stream) {
+    VER_REQUIRE(flags == 0, VER_EINVAL, "ver_gemm_nn: unknown flags 0x%x", flags);
+    return ver_gemm_nn_splitk(a, lda, w, ldw, bias, c, ldc, M, K, N, 1, nullptr, 0, stream);
+}
+
+extern "C" int ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M,
+                                  int K, int N, int splits, void* workspace, long workspace_bytes, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VER_REQUIRE(M >= 0 && K > 0 && N > 0, VER_EINVAL, "ver_gemm_nn: bad sizes M=%ld K=%d N=%d", M, K, N);
     if (M == 0) return VER_OK;
     VER_REQUIRE(a && w && c, VER_EINVAL, "ver_gemm_nn: null pointer argument");
-    VER_REQUIRE(flags == 0, VER_EINVAL, "ver_gemm_nn: unknown flags 0x%x", flags);
+    VER_REQUIRE(splits >= 1 && splits <= 1024, VER_EINVAL, "ver_gemm_nn: %d K slices", splits);
+    VER_REQUIRE(splits == 1 || (workspace && workspace_bytes >= (long)splits * M * N * (long)sizeof(float) && N % 4 == 0 && ldc % 4 == 0 &&
+                                ((uintptr_t)c & 7) == 0 && ((uintptr_t)workspace & 15) == 0),
+                VER_EINVAL, "ver_gemm_nn: %d K slices need an fp32 workspace of %ld bytes, N and ldc multiples of 4", splits,
+                (long)splits * M * N * (long)sizeof(float));
     VER_REQUIRE(lda >= K && ldw >= N && ldc >= N, VER_EINVAL, "ver_gemm_nn: row pitch smaller than the row");
     VER_REQUIRE(K % 32 == 0 && K >= 64, VER_EUNSUPPORTED, "ver_gemm_nn: K = %d must be a multiple of 32 (>= 64)", K);
     VER_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0, VER_EUNSUPPORTED,
@@ -265,9 +338,18 @@ extern "C" int ver_gemm_nn(const void* a, long lda, const void* w, long ldw, con
     p.N = N;
     p.tiles_n = (N + kTile - 1) / kTile;
     p.T = (int)((M + kTile - 1) / kTile) * p.tiles_n;
-    p.per_xcd = (p.T + 7) / 8;
+    // whole phases per slice; the last slice takes what is left (K % 32 == 0)
+    p.Kc = splits == 1 ? K : ((K + splits - 1) / splits + 31) / 32 * 32;
+    p.S = splits == 1 ? 1 : (K + p.Kc - 1) / p.Kc;
+    p.ws = (float*)workspace;
+    p.per_xcd = (p.T * p.S + 7) / 8;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_gemm_nn: LDS attribute: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)(8 * p.per_xcd)), dim3(512), kLdsBytes, st, p);
+    if (p.S > 1) {
+        long grid = (M * N / 4 + 255) / 256;
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, bias, (__bf16*)c, ldc, p.S, M, N);
+    }
     return ver_check_launch("ver_gemm_nn");
 }

@@ -19,6 +19,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 constexpr int kTaps = 75;
 constexpr int kPairs = 64;       // (ci, co) pairs per workgroup
 }  // namespace
+#define VER_BLOCKS_VEC_SLICES 8  // ci slices of ver_blocks_vec_forward (= rows of its partial result, include/ver_ops.h)
 
 // w [P][75] fp32 -> k [75][P] (bf16 or fp32), P = Ci*Co, tap order flipped
 template <bool BF16>
@@ -140,6 +141,97 @@ __global__ __launch_bounds__(256) void k_convt_weight_bwd_blocks2(const uint16_t
     }
     __syncthreads();
     for (int i = threadIdx.x; i < np * kTaps; i += 256) dw[p0 * kTaps + i] = tile[i];
+}
+
+// The forward twin of k_convt_weight_bwd_blocks: the ConvTranspose3d weight w [P][75] fp32 goes STRAIGHT into the weight
+// matrices the class GEMMs of a z-split lattice layer read -- tap t's [Ci x Co] block is written at up to two places of one
+// row-major buffer (element offsets off[t][0..1], -1 = none; row pitch ld): its "lower half" and "upper half" slots in the
+// class-stacked [sum K_c, 2 Co] matrix (the same table the backward reads its gradient from).  Replaces the tap tensor
+// [75, Ci, Co], a concatenation of it with the constant rows (88 MB each way) and one row gather per parity class.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_convt_weight_fwd_blocks(const float* __restrict__ w, const long* __restrict__ off, long ld,
+                                                                 void* __restrict__ dst, long P, int Co) {
+    constexpr int kP2 = 2 * kPairs;
+    __shared__ float tile[kP2 * kTaps + 1];
+    __shared__ long offs[2 * kTaps];
+    const long p0 = (long)blockIdx.x * kP2;
+    const int np = (int)((P - p0) < kP2 ? (P - p0) : kP2);
+    if (threadIdx.x < 2 * kTaps) offs[threadIdx.x] = off[threadIdx.x];
+    for (int i = threadIdx.x; i < np * kTaps; i += 256) tile[i] = w[p0 * kTaps + i];
+    __syncthreads();
+    const int p = 2 * (threadIdx.x & 63);
+    if (p >= np) return;                                  // (P is even: both pairs of a lane exist together)
+    const long pair = p0 + p;
+    const long ci = pair / Co, co = pair - ci * Co;       // co even, co + 1 < Co
+    const long row = ci * ld + co;
+    for (int t = threadIdx.x >> 6; t < kTaps; t += 4) {
+        const int a = t / 25, bb = (t / 5) % 5, c = t % 5;
+        const int f = ((2 - a) * 5 + (4 - bb)) * 5 + (4 - c);
+        const float v0 = tile[p * kTaps + f], v1 = tile[(p + 1) * kTaps + f];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long o = offs[2 * t + h];
+            if (o < 0) continue;
+            if (BF16)
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(dst) + o + row) =
+                    (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+            else
+                *reinterpret_cast<float2*>(reinterpret_cast<float*>(dst) + o + row) = make_float2(v0, v1);
+        }
+    }
+}
+
+// part[z][b][col] = sum_{ci in slice z} x[ci] * S[rows[b] + ci][col]: a row vector through every [Ci x ncols] block of a
+// stacked weight matrix (the previous layer's bias seen through every tap, v = b_prev^T K[t], for all taps at once).
+// grid (ncols / 512, blocks, ci slices); a lane owns two adjacent columns; the caller adds the slices up in order (no
+// atomics: the result is bitwise reproducible).
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_blocks_vec_fwd(const void* __restrict__ S, const long* __restrict__ rows, long ld,
+                                                        int Ci, int ncols, const float* __restrict__ x, float* __restrict__ vec) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (col >= ncols) return;
+    const int b = blockIdx.y;
+    const int per = (Ci + gridDim.z - 1) / gridDim.z;
+    const int c0 = blockIdx.z * per, c1 = min(Ci, c0 + per);
+    float a0 = 0.f, a1 = 0.f;
+    const long base = rows[b] * ld + col;
+    for (int ci = c0; ci < c1; ++ci) {
+        const float xv = x[ci];
+        if (BF16) {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(S) + base + (long)ci * ld);
+            a0 += xv * __uint_as_float(u << 16), a1 += xv * __uint_as_float(u & 0xffff0000u);
+        } else {
+            const float2 u = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(S) + base + (long)ci * ld);
+            a0 += xv * u.x, a1 += xv * u.y;
+        }
+    }
+    *reinterpret_cast<float2*>(vec + ((long)blockIdx.z * gridDim.y + b) * ncols + col) = make_float2(a0, a1);
+}
+
+// adjoint in x: part[b][ci] = sum_col S[rows[b] + ci][col] * dvec[b][col] (the caller adds the blocks up in order).  One
+// wavefront per (block, ci) row.
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_blocks_vec_bwd(const void* __restrict__ S, const long* __restrict__ rows, long ld,
+                                                        int Ci, int ncols, int nblocks, const float* __restrict__ dvec,
+                                                        float* __restrict__ dx) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= (long)nblocks * Ci) return;
+    const int b = (int)(r / Ci), ci = (int)(r - (long)b * Ci);
+    const long base = (rows[b] + ci) * ld;
+    const float* dv = dvec + (long)b * ncols;
+    float acc = 0.f;
+    for (int col = 2 * (threadIdx.x & 63); col < ncols; col += 128) {
+        if (BF16) {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(S) + base + col);
+            acc += __uint_as_float(u << 16) * dv[col] + __uint_as_float(u & 0xffff0000u) * dv[col + 1];
+        } else {
+            const float2 u = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(S) + base + col);
+            acc += u.x * dv[col] + u.y * dv[col + 1];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) dx[r] = acc;
 }
 
 // ---- lattice <-> channel-first rows.  One workgroup = one (b, z, y) row of W positions x 128 channels.
@@ -499,6 +591,62 @@ extern "C" int ver_convt_weight_backward_blocks(const void* blocks, const long* 
         hipLaunchKernelGGL(k_convt_weight_bwd_blocks<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, blocks, block_offsets,
                            ld, prev_bias, grad_v, grad_weight, pairs, co);
     return ver_check_launch("ver_convt_weight_backward_blocks");
+}
+
+extern "C" int ver_convt_weight_forward_blocks(const float* weight, const long* block_offsets, long ld, void* blocks, int ci,
+                                              int co, int dtype, void* stream) {
+    VER_REQUIRE(ci >= 0 && co >= 0 && ld >= co, VER_EINVAL, "ver_convt_weight_forward_blocks: bad sizes (ci %d co %d ld %ld)", ci, co, ld);
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_convt_weight_forward_blocks: dtype %d", dtype);
+    const long pairs = (long)ci * co;
+    if (pairs == 0) return VER_OK;
+    VER_REQUIRE(weight && block_offsets && blocks, VER_EINVAL, "ver_convt_weight_forward_blocks: null pointer argument");
+    VER_REQUIRE(co % 2 == 0 && ld % 2 == 0 && ((uintptr_t)blocks & 7) == 0, VER_EUNSUPPORTED,
+                "ver_convt_weight_forward_blocks: even co and ld and an 8-byte aligned destination (pairs of adjacent columns are "
+                "written together; block offsets must be even too)");
+    const unsigned nb = (unsigned)((pairs + 2 * kPairs - 1) / (2 * kPairs));
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_convt_weight_fwd_blocks<true>, dim3(nb), dim3(256), 0, (hipStream_t)stream, weight, block_offsets, ld,
+                           blocks, pairs, co);
+    else
+        hipLaunchKernelGGL(k_convt_weight_fwd_blocks<false>, dim3(nb), dim3(256), 0, (hipStream_t)stream, weight, block_offsets, ld,
+                           blocks, pairs, co);
+    return ver_check_launch("ver_convt_weight_forward_blocks");
+}
+
+extern "C" int ver_blocks_vec_forward(const void* blocks, const long* block_rows, int nblocks, long ld, int ci, int ncols,
+                                      const float* x, float* vec, int dtype, void* stream) {
+    VER_REQUIRE(nblocks >= 0 && ci >= 0 && ncols >= 0 && ld >= ncols, VER_EINVAL, "ver_blocks_vec_forward: bad sizes");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_blocks_vec_forward: dtype %d", dtype);
+    if (nblocks == 0 || ncols == 0) return VER_OK;
+    VER_REQUIRE(blocks && block_rows && x && vec, VER_EINVAL, "ver_blocks_vec_forward: null pointer argument");
+    VER_REQUIRE(ncols % 2 == 0 && ld % 2 == 0 && ((uintptr_t)blocks & 7) == 0 && nblocks <= 65535, VER_EUNSUPPORTED,
+                "ver_blocks_vec_forward: even ncols / ld, an 8-byte aligned matrix and at most 65 535 blocks");
+    hipStream_t st = (hipStream_t)stream;
+    const int slices = VER_BLOCKS_VEC_SLICES;
+    const dim3 grid((unsigned)((ncols / 2 + 255) / 256), (unsigned)nblocks, (unsigned)slices);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_blocks_vec_fwd<true>, grid, dim3(256), 0, st, blocks, block_rows, ld, ci, ncols, x, vec);
+    else
+        hipLaunchKernelGGL(k_blocks_vec_fwd<false>, grid, dim3(256), 0, st, blocks, block_rows, ld, ci, ncols, x, vec);
+    return ver_check_launch("ver_blocks_vec_forward");
+}
+
+extern "C" int ver_blocks_vec_backward(const void* blocks, const long* block_rows, int nblocks, long ld, int ci, int ncols,
+                                       const float* grad_vec, float* grad_x, int dtype, void* stream) {
+    VER_REQUIRE(nblocks >= 0 && ci >= 0 && ncols >= 0 && ld >= ncols, VER_EINVAL, "ver_blocks_vec_backward: bad sizes");
+    VER_REQUIRE(dtype == VER_F32 || dtype == VER_BF16, VER_EINVAL, "ver_blocks_vec_backward: dtype %d", dtype);
+    if (ci == 0 || nblocks == 0) return VER_OK;
+    VER_REQUIRE(blocks && block_rows && grad_vec && grad_x, VER_EINVAL, "ver_blocks_vec_backward: null pointer argument");
+    hipStream_t st = (hipStream_t)stream;
+    VER_REQUIRE(ncols % 2 == 0 && ld % 2 == 0 && ((uintptr_t)blocks & 7) == 0, VER_EUNSUPPORTED,
+                "ver_blocks_vec_backward: even ncols / ld and an 8-byte aligned matrix");
+    const long rows = (long)nblocks * ci;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == VER_BF16)
+        hipLaunchKernelGGL(k_blocks_vec_bwd<true>, dim3(grid), dim3(256), 0, st, blocks, block_rows, ld, ci, ncols, nblocks, grad_vec, grad_x);
+    else
+        hipLaunchKernelGGL(k_blocks_vec_bwd<false>, dim3(grid), dim3(256), 0, st, blocks, block_rows, ld, ci, ncols, nblocks, grad_vec, grad_x);
+    return ver_check_launch("ver_blocks_vec_backward");
 }
 
 extern "C" int ver_lattice_transpose(void* channels_last, void* channel_first, long cf_stride, int B, int Z, int H, int W,

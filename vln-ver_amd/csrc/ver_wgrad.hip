@@ -56,6 +56,9 @@ struct WgradArgs {
     float* ws;          // [S][Ka][N] fp32 partial products
     long lda, ldg, M, Mc;
     int S, Ka, N, tiles_n, T;
+    void* out;          // S == 1: the tile goes straight to the result (row pitch ldo, bf16 or fp32), no workspace pass
+    long ldo;
+    int out_bf16;
 };
 
 struct WgradLane {          // per-lane constants of the main loop
@@ -234,8 +237,29 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead pieces nobody reads
 
     // partial tile -> workspace: register r of tile (it, jt) is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
-    float* out = p.ws + (long)chunk * p.Ka * p.N;
     const int i0 = mt * kTile + 128 * wr + 4 * (lane >> 5), j0 = nt * kTile + 64 * wc + (lane & 31);
+    if (p.S == 1 && p.out) {
+        // one row chunk: there is nothing to add up -- the same fp32 sums, rounded once, straight into the result (a
+        // one-viewpoint step has 450 / 1 800 rows: the workspace round trip was 10 of its 12 bytes per element)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j = j0 + 32 * jt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = i0 + 32 * it + (r & 3) + 8 * (r >> 2);
+                    if (i < p.Ka && j < p.N) {
+                        if (p.out_bf16)
+                            reinterpret_cast<__bf16*>(p.out)[(long)i * p.ldo + j] = (__bf16)acc[it][jt][r];
+                        else
+                            reinterpret_cast<float*>(p.out)[(long)i * p.ldo + j] = acc[it][jt][r];
+                    }
+                }
+            }
+        return;
+    }
+    float* out = p.ws + (long)chunk * p.Ka * p.N;
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -280,23 +304,34 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
-int pick_splits(long M, int Ka, int N) {
+// rows of one chunk that keep every slab offset inside the 4-GiB range of a buffer offset, for row pitch `ld` elements
+// (the launcher's check: (Mc + 16 * kRing) * ld * 2 < 2^32, Mc rounded up to 2 * kSlabRows rows)
+long max_chunk_rows(long ld) {
+    if (ld <= 0) return 45000;
+    const long rows = (0xFFFFFFFFL / (ld * 2)) - 16 * kRing - 2 * kSlabRows - 1;
+    return rows < 45000 ? (rows > 2 * kSlabRows ? rows : 2 * kSlabRows) : 45000;
+}
+
+int pick_splits(long M, int Ka, int N, long ld = 0) {
+    const long cap = max_chunk_rows(ld);
     const long tiles = (long)((Ka + kTile - 1) / kTile) * ((N + kTile - 1) / kTile);
     // Cost model (microseconds, from the measurements in profiles/r05_wgrad_microbench.txt): rounds of 256 workgroups, each
     // one chunk of rows at 0.37 us per 16-row slab + 8 us of fill / drain / epilogue, plus 8 B of workspace traffic per
     // output element and chunk at ~3 TB/s.  Multiples of 8 chunks keep every XCD on its own rows (ties go to them; above
     // 32 768 rows nothing else is considered);
-    // a chunk has to stay inside the 4-GiB range of a buffer offset (45 000 rows at the widest operands here).
+    // a chunk has to stay inside the 4-GiB range of a buffer offset: at most `cap` rows (45 000 at the step's widest operands,
+    // fewer for a wider row pitch `ld`).
     static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     int best = 0;
     double best_us = 0.0;
     for (int s : cand) {
-        if (M / s > 45000) continue;
+        if ((M + s - 1) / s > cap) continue;
         if (s > 1 && M / s < 256) break;
         if (M > 32768 && s % 8) continue;       // (long row ranges: only the XCD-local form has been measured)
         const long rounds = (tiles * s + 255) / 256;
         const double slabs = (double)((M + s - 1) / s + 15) / 16.0;
-        double us = (double)rounds * (slabs * 0.37 + 8.0) + (double)s * (double)Ka * (double)N * 8.0 / 3.0e6;
+        // (one chunk: the tile goes straight to the result, ~2-4 B per element instead of 8 per chunk + the reduce)
+        double us = (double)rounds * (slabs * 0.37 + 8.0) + (s == 1 ? 0.25 : (double)s) * (double)Ka * (double)N * 8.0 / 3.0e6;
         if (s % 8 == 0) us *= 0.97;
         if (!best || us < best_us) {
             best = s;
@@ -305,7 +340,7 @@ int pick_splits(long M, int Ka, int N) {
     }
     if (!best) {
         best = 64;
-        while (best < 65536 && M / best > 45000) best *= 2;
+        while (best < 65536 && (M + best - 1) / best > cap) best *= 2;
     }
     return best;
 }
@@ -321,6 +356,11 @@ void launch_tn(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
 extern "C" int ver_wgrad_tn_splits(long M, int Ka, int N) {
     if (M <= 0 || Ka <= 0 || N <= 0) return 1;
     return pick_splits(M, Ka, N);
+}
+
+extern "C" int ver_wgrad_tn_splits_ld(long M, int Ka, int N, long ld) {
+    if (M <= 0 || Ka <= 0 || N <= 0) return 1;
+    return pick_splits(M, Ka, N, ld);
 }
 
 extern "C" long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits) {
@@ -340,7 +380,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
                 "ver_wgrad_tn: operands must be 16-byte aligned with row pitches that are multiples of 8 elements");
     VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
                 "ver_wgrad_tn: N and the output pitch must be multiples of 4");
-    const int S = splits > 0 ? splits : pick_splits(M, Ka, N);
+    const int S = splits > 0 ? splits : pick_splits(M, Ka, N, lda > ldg ? lda : ldg);
     VER_REQUIRE(S <= 65536, VER_EINVAL, "ver_wgrad_tn: %d row chunks", S);
     const long Mc = ((M + S - 1) / S + 2 * kSlabRows - 1) / (2 * kSlabRows) * (2 * kSlabRows);  // rows per chunk, whole phases
     VER_REQUIRE((Mc + 16 * kRing) * (lda > ldg ? lda : ldg) * 2 < 0xFFFFFFFFL, VER_EUNSUPPORTED,
@@ -360,6 +400,10 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
     p.N = N;
     p.tiles_n = (N + kTile - 1) / kTile;
     p.T = ((Ka + kTile - 1) / kTile) * p.tiles_n;
+    const bool direct = S == 1 && M > 0;
+    p.out = direct ? out : nullptr;
+    p.ldo = ldo;
+    p.out_bf16 = out_dtype == VER_BF16;
     hipError_t e = hipSuccess;
     if (M > 0) {
         switch (flags & 15) {
@@ -375,6 +419,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
         e = hipMemsetAsync(workspace, 0, (size_t)S * Ka * N * sizeof(float), st);
         if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn: memset: %s", hipGetErrorString(e));
     }
+    if (direct) return ver_check_launch("ver_wgrad_tn");
     const long n4 = (long)Ka * N / 4;
     long grid = (n4 + 255) / 256;
     if (grid > 8192) grid = 8192;

@@ -25,10 +25,78 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
+
+from . import _cpu_algebra
+from ._cpu_algebra import (ZS_PLAIN, ZS_PLANAR, ZS_PLANAR_SPLIT, ZS_SPLIT, plain_to_planar, plain_to_planar_zs,  # noqa: F401
+                           plain_to_zs, planar_to_plain, planar_zs_to_plain, zs_to_plain)
 
 KERNEL = (3, 5, 5)
 GEOM = dict(stride=(1, 2, 2), padding=(2, 4, 4), dilation=(2, 2, 2), output_padding=(0, 1, 1))
+_HIP_DTYPES = (torch.float32, torch.bfloat16)
+
+
+class _HipAlgebra:
+    """The data-movement operations of the lattice algebra on the HIP kernels (GPU tensors; fp32 / bf16 -- other dtypes of a
+    GPU tensor, e.g. an fp64 check on the device, go through the torch formulation).  Same signatures as ``_cpu_algebra``."""
+
+    @staticmethod
+    def corr_weight(weight, dtype):
+        if weight.dtype == torch.float32 and dtype in _HIP_DTYPES:
+            from ..hipops import convt_weight_taps
+            return convt_weight_taps(weight, dtype)                       # one LDS-tiled transpose each way
+        return _cpu_algebra.corr_weight(weight, dtype)
+
+    @staticmethod
+    def im2col(e, taps):
+        from ..hipops import lattice_im2col
+        return lattice_im2col(e.contiguous(), taps)
+
+    @staticmethod
+    def gather27(e, planar, a_mat, ci, hc, wc, taps, offs):
+        from ..hipops import lattice_gather
+        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), 1 if planar else 0)
+
+    @staticmethod
+    def scatter27(d_a, planar, shape, ci, hc, wc, taps, offs):
+        from ..hipops import lattice_scatter
+        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), 1 if planar else 0)
+
+    @staticmethod
+    def gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, const=None):
+        """``const`` = (table, column offsets): the kernel also writes the constant-pattern blocks of the four parity
+        classes.  -> True when it did."""
+        from ..hipops import lattice_gather
+        if const is not None and e.dtype in _HIP_DTYPES:
+            lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2, const_rows=const[0], const_offset=const[1])
+            return True
+        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2)
+        return False
+
+    @staticmethod
+    def scatter_z4(d_a, layout, shape, taps, offs, ci, hc, wc):
+        from ..hipops import lattice_scatter
+        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), layout, row_z=2)
+
+    @staticmethod
+    def channels_last(x0, dt):
+        b, c, z, h, w = x0.shape
+        pos = z * h * w
+        if dt in _HIP_DTYPES:
+            vx = 4 if dt == torch.bfloat16 else 2
+            for wd in range(min(pos, 120), 0, -1):        # rows of the flattened positions: 8-byte multiples, tile <= 64 KB
+                if pos % wd == 0 and wd % vx == 0:
+                    return _ChannelsLast.apply(x0, dt, (pos // wd, wd))
+        return _cpu_algebra.channels_last(x0, dt)
+
+
+def _algebra(t):
+    """THE device switch of this module: the HIP kernels for a GPU tensor, the torch formulation (``_cpu_algebra``, what the
+    CPU suite checks in fp64) for a CPU tensor.  Nothing here is chosen by "extension missing": hipops raises."""
+    return _HipAlgebra if t.is_cuda else _cpu_algebra
+
+
+def _on_hip(t):
+    return _algebra(t) is _HipAlgebra
 
 
 def is_reference_geometry(conv):
@@ -39,13 +107,8 @@ def is_reference_geometry(conv):
 
 def _corr_weight(weight, dtype):
     """ConvTranspose weight [Ci,Co,3,5,5] -> correlation taps as ONE contiguous [75, Ci, Co]
-    tensor in the compute dtype, tap index = (a*5+b)*5+c, K[a,b,c] = Wt[:, :, 2-a, 4-b, 4-c]
-    (one cast + one gather kernel; the per-class tap subsets below are index_select's of it)."""
-    ci, co = weight.shape[:2]
-    if weight.is_cuda and weight.dtype == torch.float32 and dtype in (torch.float32, torch.bfloat16):
-        from ..hipops import convt_weight_taps
-        return convt_weight_taps(weight, dtype)                       # one LDS-tiled transpose each way
-    return weight.to(dtype).flip(2, 3, 4).permute(2, 3, 4, 0, 1).reshape(75, ci, co)
+    tensor in the compute dtype, tap index = (a*5+b)*5+c, K[a,b,c] = Wt[:, :, 2-a, 4-b, 4-c]."""
+    return _algebra(weight).corr_weight(weight, dtype)
 
 
 _IDX_CACHE = {}
@@ -60,19 +123,8 @@ def _tap_index(tap_ids, device):
 
 def _im2col(e, taps):
     """e [B,Z,H,W,C] channels-last; taps: list of (dz,dy,dx) offsets (zero outside the lattice)
-    -> [B*Z*H*W, len(taps)*C].  On the GPU one HIP kernel each way (ver_lattice_im2col /
-    ver_lattice_col2im); the slice-and-cat form below only serves CPU tensors in the algebra tests."""
-    if e.is_cuda:
-        from ..hipops import lattice_im2col
-        return lattice_im2col(e.contiguous(), taps)
-    b, z, h, w, c = e.shape
-    pz = max(abs(t[0]) for t in taps)
-    py = max(abs(t[1]) for t in taps)
-    px = max(abs(t[2]) for t in taps)
-    e_pad = F.pad(e, (0, 0, px, px, py, py, pz, pz))
-    cols = [e_pad[:, pz + dz:pz + dz + z, py + dy:py + dy + h, px + dx:px + dx + w, :] for dz, dy, dx in taps]
-    a = torch.cat(cols, dim=-1)
-    return a.reshape(-1, a.shape[-1])
+    -> [B*Z*H*W, len(taps)*C] (ver_lattice_im2col / ver_lattice_col2im on the GPU)."""
+    return _algebra(e).im2col(e, taps)
 
 
 _PATTERN_CACHE = {}
@@ -136,7 +188,7 @@ def _layer0(e, k, bias):
 # (plane 2pm+pn = positions (2y+pm, 2x+pn) of the (2H, 2W) lattice) and is consumed as such by the
 # next layer's gather kernel and by occ_proj -- the lattice is never interleaved.
 _PW = 80                                             # width of a constant block
-_CLASSES = ((0, 0), (0, 1), (1, 0), (1, 1))
+_CLASSES = _cpu_algebra.CLASSES
 
 
 def _group_of(dyi, dxi):
@@ -246,48 +298,13 @@ def _class_patterns(z, h, w, device, dtype):
     return _CLASS_PATTERN[key]
 
 
-def planar_to_plain(e):
-    """[4,B,Z,H,W,C] (plane 2pm+pn = positions (2y+pm, 2x+pn)) -> [B,Z,2H,2W,C]."""
-    _, b, z, h, w, c = e.shape
-    out = e.new_empty(b, z, 2 * h, 2 * w, c)
-    for p, (pm, pn) in enumerate(_CLASSES):
-        out[:, :, pm::2, pn::2] = e[p]
-    return out
-
-
-def plain_to_planar(e):
-    return torch.stack([e[:, :, pm::2, pn::2] for pm, pn in _CLASSES])
-
-
 def _gather27(e, planar, a_mat, ci, hc, wc):
-    taps = _tap27()
-    offs = [_block_offset(t, ci) for t in range(27)]
-    if e.is_cuda:
-        from ..hipops import lattice_gather
-        lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), 1 if planar else 0)
-        return
-    src = planar_to_plain(e) if planar else e
-    b, z = src.shape[:2]
-    pad = F.pad(src, (0, 0, 1, 1, 1, 1, 2, 2))
-    view = a_mat.view(b, z, hc, wc, -1)
-    for (dz, dy, dx), o in zip(taps, offs):
-        view[..., o:o + ci] = pad[:, 2 + dz:2 + dz + z, 1 + dy:1 + dy + hc, 1 + dx:1 + dx + wc]
+    _algebra(e).gather27(e, planar, a_mat, ci, hc, wc, _tap27(), [_block_offset(t, ci) for t in range(27)])
 
 
 def _scatter27(d_a, planar, shape, ci, hc, wc):
     """adjoint of _gather27: gradient of the source lattice (plain or planar like the source)."""
-    taps = _tap27()
-    offs = [_block_offset(t, ci) for t in range(27)]
-    if d_a.is_cuda:
-        from ..hipops import lattice_scatter
-        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), 1 if planar else 0)
-    b, z = (shape[1], shape[2]) if planar else (shape[0], shape[1])
-    pad = d_a.new_zeros(b, z + 4, hc + 2, wc + 2, ci)
-    view = d_a.view(b, z, hc, wc, -1)
-    for (dz, dy, dx), o in zip(taps, offs):
-        pad[:, 2 + dz:2 + dz + z, 1 + dy:1 + dy + hc, 1 + dx:1 + dx + wc] += view[..., o:o + ci]
-    plain = pad[:, 2:2 + z, 1:1 + hc, 1:1 + wc]
-    return plain_to_planar(plain).contiguous() if planar else plain.contiguous()
+    return _algebra(d_a).scatter27(d_a, planar, shape, ci, hc, wc, _tap27(), [_block_offset(t, ci) for t in range(27)])
 
 
 class _LatticeLayer(torch.autograd.Function):
@@ -380,33 +397,7 @@ def _layer_lattice(e, k, bias, prev_bias, planar):
 # W_lo = K[dz = 0], K[dz = +2] and W_hi = K[dz = -2], K[dz = 0].  A third fewer FLOPs in all three
 # layers, a third of the tap-matrix traffic, N = 1536 instead of 768.  Lattices are kept Z-SPLIT,
 # [B, 2 (zl), H, W, 2 (zh), C] (z = 2*zh + zl): exactly the GEMM output [rows, 2*Co].
-ZS_PLAIN, ZS_PLANAR, ZS_SPLIT, ZS_PLANAR_SPLIT = 0, 1, 2, 3          # = hipops lattice layouts
 _PW2 = 2 * _PW                                                         # lo | hi constant blocks
-
-
-def zs_to_plain(e):
-    """[B,2,H,W,2,C] -> [B,4,H,W,C]"""
-    b, _, h, w, _, c = e.shape
-    return e.permute(0, 4, 1, 2, 3, 5).reshape(b, 4, h, w, c)
-
-
-def plain_to_zs(e):
-    b, z, h, w, c = e.shape
-    assert z == 4
-    return e.reshape(b, 2, 2, h, w, c).permute(0, 2, 3, 4, 1, 5).contiguous()
-
-
-def planar_zs_to_plain(e):
-    """[4,B,2,H,W,2,C] -> [B,4,2H,2W,C]"""
-    _, b, _, h, w, _, c = e.shape
-    out = e.new_empty(b, 4, 2 * h, 2 * w, c)
-    for p, (pm, pn) in enumerate(_CLASSES):
-        out[:, :, pm::2, pn::2] = zs_to_plain(e[p])
-    return out
-
-
-def plain_to_planar_zs(e):
-    return torch.stack([plain_to_zs(e[:, :, pm::2, pn::2]) for pm, pn in _CLASSES])
 
 
 def lattice_to_plain(e):
@@ -419,14 +410,7 @@ def lattice_to_plain(e):
     return e
 
 
-def _to_plain(e, layout):
-    return {ZS_PLAIN: lambda t: t, ZS_PLANAR: planar_to_plain, ZS_SPLIT: zs_to_plain,
-            ZS_PLANAR_SPLIT: planar_zs_to_plain}[layout](e)
-
-
-def _from_plain(e, layout):
-    return {ZS_PLAIN: lambda t: t.contiguous(), ZS_PLANAR: lambda t: plain_to_planar(t).contiguous(),
-            ZS_SPLIT: plain_to_zs, ZS_PLANAR_SPLIT: lambda t: plain_to_planar_zs(t).contiguous()}[layout](e)
+_to_plain, _from_plain = _cpu_algebra.to_plain, _cpu_algebra.from_plain
 
 
 _CONST_ROWS4 = {}
@@ -448,38 +432,14 @@ def _const_rows_z4(ci, hc, wc, device, dtype):
 
 
 def _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=False):
-    """rows (b, zl, y, x); tap (dz in {0,2}, dy, dx) reads input layer zl + dz.  ``with_const`` (GPU): the kernel also writes
-    the constant-pattern blocks of the four parity classes (else the caller fills them)."""
-    if e.is_cuda:
-        from ..hipops import lattice_gather
-        if with_const:
-            table, coffs = _const_rows_z4(ci, hc, wc, e.device, e.dtype)
-            lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2, const_rows=table, const_offset=coffs)
-        else:
-            lattice_gather(e.contiguous(), a_mat, taps, offs, (hc, wc), layout, row_z=2)
-        return
-    src = _to_plain(e, layout)
-    b = src.shape[0]
-    py = max(abs(t[1]) for t in taps)
-    px = max(abs(t[2]) for t in taps)
-    pad = F.pad(src, (0, 0, px, px, py, py))
-    view = a_mat.view(b, 2, hc, wc, -1)
-    for (dz, dy, dx), o in zip(taps, offs):
-        view[..., o:o + ci] = pad[:, dz:dz + 2, py + dy:py + dy + hc, px + dx:px + dx + wc]
+    """rows (b, zl, y, x); tap (dz in {0,2}, dy, dx) reads input layer zl + dz.  ``with_const``: ask for the constant-pattern
+    blocks of the four parity classes in the same pass.  -> True when they were written (else the caller fills them)."""
+    const = _const_rows_z4(ci, hc, wc, e.device, e.dtype) if with_const else None
+    return _algebra(e).gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, const)
 
 
 def _scatter_z4(d_a, layout, shape, taps, offs, ci, hc, wc):
-    if d_a.is_cuda:
-        from ..hipops import lattice_scatter
-        return lattice_scatter(d_a, d_a.new_empty(shape), taps, offs, (hc, wc), layout, row_z=2)
-    b = d_a.shape[0] // (2 * hc * wc)
-    py = max(abs(t[1]) for t in taps)
-    px = max(abs(t[2]) for t in taps)
-    pad = d_a.new_zeros(b, 4, hc + 2 * py, wc + 2 * px, ci)
-    view = d_a.view(b, 2, hc, wc, -1)
-    for (dz, dy, dx), o in zip(taps, offs):
-        pad[:, dz:dz + 2, py + dy:py + dy + hc, px + dx:px + dx + wc] += view[..., o:o + ci]
-    return _from_plain(pad[:, :, py:py + hc, px:px + wc], layout)
+    return _algebra(d_a).scatter_z4(d_a, layout, shape, taps, offs, ci, hc, wc)
 
 
 _L0Z4 = {}
@@ -547,15 +507,18 @@ class _Layer0Z4(torch.autograd.Function):
         """``raw``: the fp32 ConvTranspose3d weight [Ci,Co,3,5,5] instead of its taps ``k`` (GPU training steps): the
         backward then returns the weight's gradient straight from the GEMM's (``ver_convt_weight_backward_blocks``)."""
         b, z, h, w, ci = x.shape
-        if raw is not None:
-            k = _corr_weight(raw, x.dtype)
         ctx.raw = raw is not None
-        co = k.shape[-1]
+        co = raw.shape[1] if raw is not None else k.shape[-1]
         taps, offs, lo, hi = _layer0_z4_plan(ci, x.device)
         a_mat = x.new_empty(b * 2 * h * w, 50 * ci)
         _gather_z4(x, ZS_PLAIN, a_mat, taps, offs, ci, h, w)
-        rows = k.reshape(75 * ci, co)
-        wmat = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)        # [50 ci, 2 co]
+        if raw is not None:
+            # [W_lo | W_hi] written by ONE kernel from the fp32 parameter (no tap tensor, no row gathers)
+            from ..hipops import convt_weight_forward_blocks
+            wmat = convt_weight_forward_blocks(raw, _block_offsets('l0', ci, co, x.device), x.new_empty(50 * ci, 2 * co), ci, co)
+        else:
+            rows = k.reshape(75 * ci, co)
+            wmat = torch.cat([rows.index_select(0, lo), rows.index_select(0, hi)], 1)    # [50 ci, 2 co]
         out = mm_fwd(a_mat, wmat, bias=torch.cat([bias, bias]))
         ctx.save_for_backward(a_mat, wmat)
         ctx.geom = (tuple(x.shape), ci, co, h, w)
@@ -650,6 +613,45 @@ def _aug_rows_z4(ci, device):
     return _AUG_ROWS[key]
 
 
+_STACK_TABLES = {}
+
+
+def _stack_tables_z4(ci, device):
+    """Index tables of the class-stacked weight matrix S [sum K_c, 2 Co] of a Z = 4 lattice layer (rows: ``_class_rows_z4``),
+    viewed as S2 [2 sum K_c, Co] (row 2 r + half) where rows are addressed:
+    ``block_rows`` int64 [50]: first row of every tap block; ``tap_slot`` int64 [75]: 2 * block + half of ONE slot that
+    holds tap t (a tap with a = 1 sits in two: the lower half of j = 0 and the upper half of j = 1; the first is taken);
+    ``const_rows`` / ``const_src``: the S2 rows of all constant blocks and, for each, the row of [vaug (80) | zero row] it
+    holds (own block, matching half: K^T b_prev | bias | 0; everything else zero)."""
+    key = (ci, str(device))
+    if key not in _STACK_TABLES:
+        block_rows, tap_slot = [], np.full(75, -1, dtype=np.int64)
+        const_rows, const_src = [], []
+        for cls, (roff, segs) in _class_rows_z4(ci).items():
+            pm, pn = cls
+            for kind, val, r0 in segs:
+                if kind == 'b':
+                    dxi, dyi, j = _ORDER4[val]
+                    bb, cc = 2 * dyi - pm, 2 * dxi - pn
+                    i = len(block_rows)
+                    block_rows.append(roff + r0)
+                    for half, a in ((0, 1 + j), (1, j)):
+                        t = (a * 5 + bb) * 5 + cc
+                        if tap_slot[t] < 0:
+                            tap_slot[t] = 2 * i + half
+                else:
+                    own = val == cls
+                    for r in range(_PW2):                           # rows [P_lo (80) | P_hi (80)] of the block
+                        for half in range(2):
+                            const_rows.append(2 * (roff + r0 + r) + half)
+                            live = own and ((r < _PW and half == 0) or (r >= _PW and half == 1))
+                            const_src.append(r % _PW if live else _PW)
+        assert (tap_slot >= 0).all() and len(block_rows) == 50
+        t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int64)).to(device)
+        _STACK_TABLES[key] = (t(block_rows), t(tap_slot), t(const_rows), t(const_src))
+    return _STACK_TABLES[key]
+
+
 def _layer_plan_z4(ci, device):
     """Per class (c0, c1, lo, hi): one column range and the rows of the stacked weight matrix
     [75*ci taps | 4 x 80 (K^T b_prev | bias | 0) | zero rows] feeding the lower / upper output half."""
@@ -707,8 +709,6 @@ class _LatticeLayerZ4(torch.autograd.Function):
         -> planar z-split output [4,B,2,H,W,2,Co] (H, W = combined size of the input).
         ``raw``: the fp32 ConvTranspose3d weight [Ci,Co,3,5,5] instead of ``k`` (GPU training steps): the four class
         weight gradients are then written into one stacked buffer and turned into the weight's gradient by ONE kernel."""
-        if raw is not None:
-            k = _corr_weight(raw, e.dtype)
         ctx.raw = raw is not None
         if planar:
             _, b, _, hh, wh, _, ci = e.shape
@@ -716,14 +716,12 @@ class _LatticeLayerZ4(torch.autograd.Function):
         else:
             b, _, hc, wc, _, ci = e.shape
         layout = ZS_PLANAR_SPLIT if planar else ZS_SPLIT
-        co = k.shape[-1]
+        co = raw.shape[1] if raw is not None else k.shape[-1]
         dt = e.dtype
         plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, e.device)
         m = b * 2 * hc * wc
         a_mat = e.new_empty(m, kt)
-        on_gpu = e.is_cuda and dt in (torch.float32, torch.bfloat16)
-        _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=on_gpu)
-        if not on_gpu:
+        if not _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=True):
             pats = _class_patterns(4, hc, wc, e.device, dt)
             a3 = a_mat.view(b, 2 * hc * wc, kt)
             for (pm, pn), pat in zip(_CLASSES, pats):
@@ -731,19 +729,38 @@ class _LatticeLayerZ4(torch.autograd.Function):
                 halves = pat.view(2, 2 * hc * wc, _PW)              # output z = zl (lower), zl + 2 (upper)
                 a3[:, :, o:o + _PW] = halves[0]
                 a3[:, :, o + _PW:o + _PW2] = halves[1]
+        out = e.new_empty(4, m, 2 * co)
+        if raw is not None:
+            # Weight side of the step, which does not shrink with the batch (config.latency): the four class matrices
+            # [W_lo | W_hi] are ONE stacked buffer S [sum K_c, 2 Co] written straight from the fp32 parameter
+            # (ver_convt_weight_forward_blocks); v = b_prev^T K[t] for all taps is one pass over S
+            # (ver_blocks_vec_forward); the constant rows (K^T b_prev | bias | 0) go in by one indexed copy.  No tap
+            # tensor, no 88-MB concatenation, no row gather per class.
+            from ..hipops import blocks_vec_forward, convt_weight_forward_blocks
+            class_rows = _class_rows_z4(ci)
+            block_rows, tap_slot, const_rows, const_src = _stack_tables_z4(ci, e.device)
+            stack = e.new_empty(sum(plan[cls][1] - plan[cls][0] for cls in _CLASSES), 2 * co)
+            convt_weight_forward_blocks(raw, _block_offsets('lat', ci, co, e.device), stack, ci, co)
+            v = blocks_vec_forward(stack, block_rows, ci, prev_bias).view(-1, co).index_select(0, tap_slot)     # [75, Co] fp32
+            vaug = torch.cat([v.to(dt), bias.to(dt)[None], v.new_zeros(_PW - 75, co, dtype=dt)])                # + one zero row
+            stack.view(-1, co).index_copy_(0, const_rows, vaug.index_select(0, const_src))
+            for p, cls in enumerate(_CLASSES):
+                c0, c1 = plan[cls][:2]
+                r0 = class_rows[cls][0]
+                mm_fwd(a_mat[:, c0:c1], stack[r0:r0 + c1 - c0], out=out[p])
+            ctx.save_for_backward(a_mat, stack, prev_bias)
+            ctx.geom = (layout, tuple(e.shape), b, hc, wc, ci, co, total_rows)
+            return out.view(4, b, 2, hc, wc, 2, co)
         v = _bias_through_taps(prev_bias.to(dt), k)                               # [75, Co]
         vaug = torch.cat([v, bias.to(dt)[None], v.new_zeros(_PW - 76, co)])
         rows = torch.cat([k.reshape(75 * ci, co), vaug, vaug, vaug, vaug,
                           v.new_zeros(total_rows - 75 * ci - 4 * _PW, co)])
-        out = e.new_empty(4, m, 2 * co)
         ws = []
         for p, cls in enumerate(_CLASSES):
             c0, c1, lo, hi, lohi = plan[cls]
             w = rows.index_select(0, lohi).view(c1 - c0, 2 * co)          # [W_lo | W_hi], one gather
             mm_fwd(a_mat[:, c0:c1], w, out=out[p])
             ws.append(w)
-        # the class weight matrices are kept for the backward pass (0.17 GB per layer at Co = 768) instead of being
-        # gathered again there: weight-side work does not shrink with the batch (config.latency)
         ctx.save_for_backward(a_mat, k, prev_bias, *ws)
         ctx.geom = (layout, tuple(e.shape), b, hc, wc, ci, co, total_rows)
         return out.view(4, b, 2, hc, wc, 2, co)
@@ -751,9 +768,13 @@ class _LatticeLayerZ4(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         a_mat, k, prev_bias = ctx.saved_tensors[:3]
-        ws = ctx.saved_tensors[3:]
         layout, e_shape, b, hc, wc, ci, co, total_rows = ctx.geom
         plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, a_mat.device)
+        if ctx.raw:                                             # (k is the class-stacked weight matrix S here)
+            cr = _class_rows_z4(ci)
+            ws = [k[cr[cls][0]:cr[cls][0] + plan[cls][1] - plan[cls][0]] for cls in _CLASSES]
+        else:
+            ws = ctx.saved_tensors[3:]
         dt = a_mat.dtype
         m = a_mat.shape[0]
         g = grad_out.contiguous().view(4, m, 2 * co)
@@ -793,7 +814,11 @@ class _LatticeLayerZ4(torch.autograd.Function):
             d_v = d_vaug[:75].to(dt)
             pb = prev_bias.to(dt)
             d_raw = convt_weight_backward_blocks(stacked, _block_offsets('lat', ci, co, stacked.device), pb, d_v, ci, co)
-            d_prev = torch.bmm(k, d_v.unsqueeze(2)).sum(0).squeeze(1)
+            # d(b_prev) = sum_t K[t] d_v[t]: d_v scattered to ONE slot per tap of the stacked weights, one pass over them
+            from ..hipops import blocks_vec_backward
+            block_rows, tap_slot, _, _ = _stack_tables_z4(ci, stacked.device)
+            dv2 = d_vaug.new_zeros(2 * block_rows.numel(), co).index_copy_(0, tap_slot, d_vaug[:75])
+            d_prev = blocks_vec_backward(k, block_rows, ci, dv2.view(block_rows.numel(), 2 * co))
             return d_e, None, d_vaug[75].to(prev_bias.dtype), d_prev.to(prev_bias.dtype), None, d_raw
         d_rows = d_lo + d_hi
         n_data = 75 * ci
@@ -820,6 +845,10 @@ def gemm_timed(name, m, k, n):
 # faster in the library and stay there.  VER_OWN_GEMM=0: library everywhere.
 _OWN_GEMM = os.environ.get('VER_OWN_GEMM', '1') == '1'
 _OWN_GEMM_MIN_ROWS = 49152
+# ... and the skinny products of the small-batch steps (config.latency: 450 / 1 800 rows at one viewpoint per step) cut into K
+# slices: the library's best recorded solution runs (450 x 38 400) x (38 400 x 1 536) in 144 us on 12 workgroups, the weight
+# matrix alone streams in 15
+_OWN_GEMM_SKINNY_ROWS = 2048
 
 
 def mm_fwd(a, w, out=None, bias=None):
@@ -827,9 +856,11 @@ def mm_fwd(a, w, out=None, bias=None):
     row-major, optional bias [N]; ``out`` [M, N] is written when given."""
     m, k = a.shape
     n = w.shape[1]
-    if _OWN_GEMM and a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and m >= _OWN_GEMM_MIN_ROWS and k >= 2048:
-        from ..hipops import gemm_nn, gemm_nn_supported
-        if gemm_nn_supported(a, w) and (out is None or (out.stride(-1) == 1 and out.dtype == torch.bfloat16)):
+    if _OWN_GEMM and _on_hip(a) and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and k >= 2048 and \
+            (m >= _OWN_GEMM_MIN_ROWS or m <= _OWN_GEMM_SKINNY_ROWS):
+        from ..hipops import gemm_nn, gemm_nn_splits, gemm_nn_supported
+        if gemm_nn_supported(a, w) and (out is None or (out.stride(-1) == 1 and out.dtype == torch.bfloat16)) and \
+                (m >= _OWN_GEMM_MIN_ROWS or gemm_nn_splits(m, k, n) > 1):
             # (the library adds the bias as a bf16 vector: the same rounded values here)
             return gemm_nn(a, w, None if bias is None else bias.to(a.dtype).float(), out)
     with gemm_timed('head_gemm_fwd', m, k, n):
@@ -845,7 +876,7 @@ def rows_tn(a, g, out_dtype=None, out=None):
     operands streamed row-major into LDS, fragments through transposing LDS reads, fp32 partial sums over row chunks
     added up in fp32: 1.3 PFLOP/s where the library's T x N class reaches 1.05); everything else
     (fp32 / fp64, CPU tensors of the algebra tests) is a plain matmul."""
-    if a.is_cuda and a.dtype == torch.bfloat16 and g.dtype == torch.bfloat16:
+    if _on_hip(a) and a.dtype == torch.bfloat16 and g.dtype == torch.bfloat16:
         from ..hipops import wgrad_tn, wgrad_tn_supported
         if g.stride(-1) != 1 or g.stride(0) % 8:
             g = g.contiguous()
@@ -860,7 +891,7 @@ def rows_tn(a, g, out_dtype=None, out=None):
 def _compute_dtype(x):
     """bf16 under ``torch.autocast`` (im2col, GEMM operands and lattices all in bf16, fp32
     accumulation inside the GEMM), else the input's dtype."""
-    if x.is_cuda and torch.is_autocast_enabled('cuda'):
+    if _on_hip(x) and torch.is_autocast_enabled('cuda'):
         return torch.get_autocast_dtype('cuda')
     return x.dtype
 
@@ -891,14 +922,7 @@ class _ChannelsLast(torch.autograd.Function):
 
 
 def _channels_last(x0, dt):
-    b, c, z, h, w = x0.shape
-    pos = z * h * w
-    if x0.is_cuda and dt in (torch.float32, torch.bfloat16):
-        vx = 4 if dt == torch.bfloat16 else 2
-        for wd in range(min(pos, 120), 0, -1):            # rows of the flattened positions: 8-byte multiples, tile <= 64 KB
-            if pos % wd == 0 and wd % vx == 0:
-                return _ChannelsLast.apply(x0, dt, (pos // wd, wd))
-    return x0.permute(0, 2, 3, 4, 1).to(dt).contiguous()
+    return _algebra(x0).channels_last(x0, dt)
 
 
 def upsample_lattice(x0, weights, biases):
@@ -908,8 +932,7 @@ def upsample_lattice(x0, weights, biases):
     dt = _compute_dtype(x0)
     e = _channels_last(x0, dt)
     bs = [b.to(dt) for b in biases]
-    if e.shape[1] == 4 and e.is_cuda and dt in (torch.float32, torch.bfloat16) and \
-            all(w.is_cuda and w.dtype == torch.float32 for w in weights):
+    if e.shape[1] == 4 and _on_hip(e) and dt in _HIP_DTYPES and all(_on_hip(w) and w.dtype == torch.float32 for w in weights):
         # GPU: the layers take the ConvTranspose3d weights themselves (taps made inside, weight gradient made from the class
         # GEMMs' gradients by one kernel: the weight-side work of a step does not shrink with the batch)
         e = _Layer0Z4.apply(e, None, bs[0], weights[0])

@@ -346,10 +346,11 @@ class VoxelFormerOccupancyHead(BaseModule):
         lo.check_label_range(gt_occupancy, self.occupancy_classes)      # (the same first-call host check as FocalLoss.forward)
         # the labels are permuted into the GEMMs' row order and counted as BYTES (17 classes): int64 labels made the
         # permutation and the count three passes over 0.77 GB each at 192 viewpoints (1.4 ms; now 0.3 with the narrowing copy).
-        # The range check above sees the original values; a label >= 256 would wrap here (one < 0 or in (C, 255] still
-        # reaches the kernel's own check as an invalid label).
+        # The host-side range check above only runs on a module's first call: labels are clamped into [-1, 255] before the
+        # narrowing cast, so that an out-of-range value stays out of range as a byte (-1 -> 255, >= 256 -> 255: both reach
+        # the kernel's own check as invalid labels) instead of wrapping into a valid class.
         narrow = gt_occupancy.is_cuda and gt_occupancy.dtype == torch.int64 and self.occupancy_classes < 255
-        gt = gt_occupancy.to(torch.uint8) if narrow else gt_occupancy
+        gt = gt_occupancy.clamp(-1, 255).to(torch.uint8) if narrow else gt_occupancy
         gt = gt.reshape(bs, self.occ_zdim, plan.rows).permute(0, 2, 1)                # -> [bs, X*Y, Z]
         gt = voxels_to_rows(gt, plan, bs).reshape(-1)
         occupied = gt < self.occupancy_classes
@@ -420,8 +421,9 @@ class VoxelFormerOccupancyHead(BaseModule):
         common = dict(grid_length=grid_length, bev_pos=voxel_pos, img_metas=img_metas,
                       prev_bev=prev_bev, **kwargs)
         if only_bev or self.only_occ:
-            voxel_embed = self.transformer.get_voxel_features(
-                mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
+            with self._encoder_params(voxel_queries, bs):
+                voxel_embed = self.transformer.get_voxel_features(
+                    mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
             if only_bev:
                 return voxel_embed
             self._dump_volumes(voxel_embed, img_metas)
@@ -430,8 +432,9 @@ class VoxelFormerOccupancyHead(BaseModule):
                         flow_preds=None, enc_cls_scores=None, enc_bbox_preds=None,
                         enc_occupancy_preds=None)
         object_query_embeds = self.query_embedding.weight.to(dtype)
-        voxel_embed = self.transformer.get_voxel_features(
-            mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
+        with self._encoder_params(voxel_queries, bs):
+            voxel_embed = self.transformer.get_voxel_features(
+                mlvl_feats, voxel_queries, self.bev_z, self.bev_h, self.bev_w, **common)
         # (the detection half -- decoder, cls / reg branches, Hungarian cost matrices -- only reads the encoder output, and so
         #  does the occupancy head.  Running the former on a second HIP stream was measured in round 5: its ~1 500 small
         #  launches per direction do execute beside the occupancy head's GEMMs, but those fill every CU, the small kernels
@@ -445,10 +448,12 @@ class VoxelFormerOccupancyHead(BaseModule):
         elif self.add_layout:
             # head:458-474: the layout branch of the reference never upsamples -- plain [bs,Z,H,W,C] view,
             # occ_proj, occ_branches on the coarse grid (X*Y = bev_h*bev_w cells, occ_zdim layers)
-            occupancy = self._only_occ(bev_embed.permute(1, 0, 2))
+            occupancy = self._only_occ(voxel_embed)
         else:
-            occupancy = self.occupancy_from_volume(bev_embed.permute(1, 0, 2), rows_only=occupancy_rows)
-        self._dump_volumes(bev_embed.permute(1, 0, 2), img_metas)
+            # (the encoder output itself, [bs,Nq,C]: the tensor object that carries the bf16 side copy of the last LayerNorm
+            #  -- bev_embed.permute(1,0,2) is the same memory but a fresh view without it)
+            occupancy = self.occupancy_from_volume(voxel_embed, rows_only=occupancy_rows)
+        self._dump_volumes(voxel_embed, img_metas)
         out = dict(bev_embed=bev_embed, all_cls_scores=all_cls, all_bbox_preds=all_box,
                    all_layout_preds=torch.stack(layouts) if self.add_layout else None,
                    occupancy_preds=occupancy, flow_preds=None, enc_cls_scores=None,
@@ -456,6 +461,22 @@ class VoxelFormerOccupancyHead(BaseModule):
         if pending is not None:
             out['pending_targets'] = pending
         return out
+
+    # viewpoints per call up to which the encoder's 36 Linear parameters are lent as bf16 copies (one multi-tensor cast each
+    # way instead of ~70 launches of a few KB): the small-batch steps are bound by launch count, not by bytes
+    # (config.latency); larger batches keep the split weight gradient of bricks.tall_linear
+    lowp_encoder_max_batch = 16
+
+    def _encoder_params(self, like, bs):
+        """Under bf16 autocast in a training step at a small batch: the encoder's Linear parameters as bf16 copies made by one
+        multi-tensor cast (modules/lowp_params.py), like the detection half's."""
+        if bs > self.lowp_encoder_max_batch or os.environ.get('VER_LOWP_PARAMS', '1') != '1':
+            return contextlib.nullcontext()
+        lowp = getattr(self, '_lowp_encoder', None)
+        if lowp is None:
+            from ..modules.lowp_params import LowpParams
+            lowp = self.__dict__['_lowp_encoder'] = LowpParams([self.transformer.encoder])
+        return lowp.lent() if lowp.applies(like) else contextlib.nullcontext()
 
     def _detection_params(self, like):
         """Under bf16 autocast in a training step: the Linear parameters of the decoder and of the cls / reg branches as

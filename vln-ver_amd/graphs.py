@@ -1,4 +1,5 @@
-"""hipGraph replay of the head for small, launch-bound batches.
+"""hipGraph replay of the head (``GraphedHead``) and of the whole lifting step (``GraphedLiftStep``) for small, launch-bound
+batches.
 
 At the reference's own batch point (vocc.py: ``samples_per_gpu=1``) the full multi-task step is bound by the HOST: ~1 500
 module calls forward and as many autograd nodes backward, 13-16 ms + 23-28 ms of Python / dispatcher time around ~20 ms of
@@ -98,3 +99,68 @@ class GraphedHead:
             occ = (occ,) + self.module.row_plan
         return dict(bev_embed=bev, all_cls_scores=cls, all_bbox_preds=box, all_layout_preds=None, occupancy_preds=occ,
                     flow_preds=None, enc_cls_scores=None, enc_bbox_preds=None, enc_occupancy_preds=None)
+
+
+class GraphedLiftStep:
+    """One training step of the lifting path -- forward, occupancy loss, backward, gradient clipping + AdamW -- for ONE fixed
+    batch shape, captured as a single hipGraph and replayed: the reference's own operating point (vocc.py:222
+    ``samples_per_gpu=1``) is bound by the host in the eager step (~450 launches behind ~9 ms of Python / dispatcher time for
+    ~4 ms of GPU work).  Same kernels, same arithmetic as the eager step; dropout seeds come from the device generator and
+    advance per replay; ``optim.ClipAdamW`` keeps its pointer table, hyper-parameters and per-tensor update counts on the
+    device, so the captured update uses the right bias corrections on every replay (``optimizer.replayed()`` keeps the host's
+    counts in step, ``optimizer.refresh()`` uploads a learning rate a scheduler has moved).
+
+    ``model(feats, w2p, org, gt) -> scalar loss`` (bench.py's LiftTrainer); ``optimizer``: a ClipAdamW over the model's trainable
+    parameters.  Construction runs ``warmup`` REAL eager steps on the sample inputs (allocator, AdamW state, library
+    heuristics) before the capture -- they train the model like any other step.  One rank only: the gradient all-reduce of
+    DistributedDataParallel is not part of the graph.  ``loss = step(feats, w2p, org, gt)`` copies the inputs into the graph's
+    static buffers (unless they ARE those buffers: ``step.inputs``) and returns the graph's loss tensor, overwritten by the
+    next call."""
+
+    def __init__(self, model, optimizer, feats, world2pixel, origin, gt, warmup=3, check_live_losses=True):
+        if not feats.is_cuda:
+            raise RuntimeError('GraphedLiftStep needs GPU tensors (HIP graphs)')
+        if not hasattr(optimizer, 'prepare_capture'):
+            raise TypeError('GraphedLiftStep needs an optimizer whose step() can be captured (optim.ClipAdamW)')
+        self.model, self.optimizer = model, optimizer
+        self.inputs = tuple(t.detach().clone() for t in (feats, world2pixel, origin, gt))
+        self.training = model.training
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                 # (at least one: the optimizer state must exist before the capture)
+                optimizer.zero_grad(set_to_none=True)
+                loss = model(*self.inputs)
+                loss.backward()
+                optimizer.step()
+            loss = None
+            optimizer.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if check_live_losses:
+            gc.collect()
+            n = len(_live_losses())
+            if n:
+                raise RuntimeError('GraphedLiftStep: %d scalar tensor(s) with an autograd graph are still alive (losses of '
+                                   'earlier eager steps?); drop them before building the graph (see GraphedHead)' % n)
+        optimizer.prepare_capture()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss = model(*self.inputs)
+            loss.backward()
+            self.grad_norm = optimizer.step()
+            self.loss = loss.detach()
+        loss = None
+
+    def __call__(self, feats, world2pixel, origin, gt):
+        if self.model.training != self.training:
+            raise RuntimeError('GraphedLiftStep: model.training differs from capture time')
+        for dst, src in zip(self.inputs, (feats, world2pixel, origin, gt)):
+            if src is not dst:
+                if src.shape != dst.shape or src.dtype != dst.dtype:
+                    raise RuntimeError('GraphedLiftStep: input %s %s, captured with %s %s' % (tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
+                dst.copy_(src, non_blocking=True)
+        self.optimizer.refresh()
+        self.graph.replay()
+        self.optimizer.replayed()
+        return self.loss

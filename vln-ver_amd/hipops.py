@@ -22,11 +22,11 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_msda3d_forward', 'ver_msda3d_backward', 'ver_focal_loss_blocks', 'ver_focal_loss_forward', 'ver_focal_loss_forward_grad', 'ver_focal_loss_forward_grad_u8',
            'ver_focal_loss_backward', 'ver_occ_mlp_image_bytes', 'ver_occ_mlp_vector_floats', 'ver_occ_mlp_pack',
            'ver_occ_mlp_forward', 'ver_occ_mlp_backward', 'ver_occ_mlp_backward_fused', 'ver_lattice_gather', 'ver_lattice_scatter',
-           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_lattice_transpose', 'ver_lattice_rows', 'ver_run_gather',
+           'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_convt_weight_forward_blocks', 'ver_blocks_vec_forward', 'ver_blocks_vec_backward', 'ver_lattice_transpose', 'ver_lattice_rows', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
-           'ver_wgrad_tn_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
+           'ver_wgrad_tn_splits', 'ver_wgrad_tn_splits_ld', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
 
 _lib = None
 
@@ -502,6 +502,61 @@ def convt_weight_backward_blocks(blocks, block_offsets, prev_bias, grad_v, ci, c
         _p(src), _p(off), ctypes.c_long(src.stride(0)), _p(prev_bias) if prev_bias is not None else None,
         _p(grad_v) if grad_v is not None else None, _p(gw), int(ci), int(co), dt, _stream()))
     return gw
+
+
+def convt_weight_forward_blocks(weight, block_offsets, blocks, ci, co):
+    """ver_convt_weight_forward_blocks (no autograd): the fp32 ConvTranspose3d weight [Ci,Co,3,5,5] written into the
+    class-stacked weight matrix ``blocks`` [rows, ld] (fp32 or bf16, unit column stride): tap t at element offsets
+    ``block_offsets[t]`` (int64 [75,2] on the device, -1 = none).  Rows that hold no tap block are not touched."""
+    w = _gpu(weight, 'weight')
+    dst = _gpu(blocks, 'blocks')
+    if w.dtype != torch.float32 or not w.is_contiguous() or tuple(w.shape) != (ci, co, 3, 5, 5):
+        raise TypeError('convt_weight_forward_blocks: weight must be a contiguous fp32 [Ci, Co, 3, 5, 5]')
+    if dst.dim() != 2 or dst.stride(1) != 1 or dst.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('convt_weight_forward_blocks: blocks must be an fp32 / bf16 matrix with unit column stride')
+    off = _gpu(block_offsets, 'block_offsets')
+    if off.dtype != torch.int64 or tuple(off.shape) != (75, 2) or not off.is_contiguous():
+        raise TypeError('convt_weight_forward_blocks: block_offsets must be a contiguous int64 [75, 2]')
+    _launch('ver_convt_weight_forward_blocks', lambda: lib().ver_convt_weight_forward_blocks(
+        _p(w), _p(off), ctypes.c_long(dst.stride(0)), _p(dst), int(ci), int(co), 1 if dst.dtype == torch.bfloat16 else 0, _stream()))
+    return blocks
+
+
+def _blocks_vec_args(blocks, block_rows, name):
+    src = _gpu(blocks, 'blocks')
+    if src.dim() != 2 or src.stride(1) != 1 or src.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError('%s: blocks must be an fp32 / bf16 matrix with unit column stride' % name)
+    rows = _gpu(block_rows, 'block_rows')
+    if rows.dtype != torch.int64 or rows.dim() != 1 or not rows.is_contiguous():
+        raise TypeError('%s: block_rows must be a contiguous int64 vector' % name)
+    return src, rows
+
+
+def blocks_vec_forward(blocks, block_rows, ci, x):
+    """ver_blocks_vec_forward (no autograd): x fp32 [Ci] through every [Ci x ncols] block of ``blocks`` (first rows
+    ``block_rows``, int64 on the device) -> fp32 [nblocks, ncols]."""
+    src, rows = _blocks_vec_args(blocks, block_rows, 'blocks_vec_forward')
+    x = _gpu(x, 'x').float().contiguous()
+    if x.numel() != ci:
+        raise ValueError('blocks_vec_forward: x must have Ci elements')
+    part = torch.empty(8, rows.numel(), src.shape[1], dtype=torch.float32, device=src.device)      # 8 slices of ci
+    _launch('ver_blocks_vec_forward', lambda: lib().ver_blocks_vec_forward(
+        _p(src), _p(rows), int(rows.numel()), ctypes.c_long(src.stride(0)), int(ci), int(src.shape[1]), _p(x), _p(part),
+        1 if src.dtype == torch.bfloat16 else 0, _stream()))
+    return part.sum(0)
+
+
+def blocks_vec_backward(blocks, block_rows, ci, grad_vec):
+    """ver_blocks_vec_backward (no autograd): the adjoint of ``blocks_vec_forward`` in x: fp32 [Ci]."""
+    src, rows = _blocks_vec_args(blocks, block_rows, 'blocks_vec_backward')
+    gv = _gpu(grad_vec, 'grad_vec').float().contiguous()
+    if tuple(gv.shape) != (rows.numel(), src.shape[1]):
+        raise ValueError('blocks_vec_backward: grad_vec must be [nblocks, ncols]')
+    part = torch.empty(rows.numel(), ci, dtype=torch.float32, device=src.device)                     # one row per block
+    _launch('ver_blocks_vec_backward', lambda: lib().ver_blocks_vec_backward(
+        _p(src), _p(rows), int(rows.numel()), ctypes.c_long(src.stride(0)), int(ci), int(src.shape[1]), _p(gv), _p(part),
+        1 if src.dtype == torch.bfloat16 else 0, _stream()))
+    return part.sum(0)
 
 
 PLAIN, PLANAR, ZSPLIT, PLANAR_ZSPLIT = 0, 1, 2, 3      # lattice layouts of ver_lattice_gather / _transpose
@@ -1174,7 +1229,7 @@ def wgrad_tn(a, g, out_dtype=None, splits=0, flags=0, out=None):
         raise TypeError('wgrad_tn: out_dtype must be bf16 or fp32')
     L = lib()
     if splits <= 0:
-        splits = L.ver_wgrad_tn_splits(ctypes.c_long(m), ka, n)
+        splits = L.ver_wgrad_tn_splits_ld(ctypes.c_long(m), ka, n, ctypes.c_long(max(a.stride(0), g.stride(0))))
     nbytes = L.ver_wgrad_tn_workspace(ctypes.c_long(m), ka, n, splits)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=a.device)
     if out is None:
@@ -1196,9 +1251,15 @@ def gemm_nn_supported(a, w):
             and a.shape[1] % 32 == 0 and a.shape[1] >= 64)
 
 
-def gemm_nn(a, w, bias=None, out=None):
+def gemm_nn_splits(m, k, n):
+    """K slices ``gemm_nn`` would cut an [m, k] x [k, n] product into (1: one pass, no workspace): > 1 for skinny operands."""
+    return int(lib().ver_gemm_nn_splits(ctypes.c_long(m), int(k), int(n)))
+
+
+def gemm_nn(a, w, bias=None, out=None, splits=None):
     """``a @ w (+ bias)`` on ver_gemm_nn: a bf16 [M, K] (may be a column range of a wider row-major matrix), w bf16 [K, N]
-    row-major, bias fp32 [N] or None -> bf16 [M, N] (``out``: a bf16 matrix with unit column stride to write into)."""
+    row-major, bias fp32 [N] or None -> bf16 [M, N] (``out``: a bf16 matrix with unit column stride to write into).
+    ``splits``: K slices (None: the library's choice -- 1 except for skinny operands; fp32 partial tiles, added up once)."""
     if not gemm_nn_supported(a, w):
         raise RuntimeError('gemm_nn: unsupported operands %s %s / %s %s' % (tuple(a.shape), a.stride(), tuple(w.shape), w.stride()))
     m, k = a.shape
@@ -1209,7 +1270,13 @@ def gemm_nn(a, w, bias=None, out=None):
         raise RuntimeError('gemm_nn: out must be a bf16 [M, N] GPU matrix with unit column stride')
     if bias is not None:
         bias = _gpu(bias, 'bias').float().contiguous()
-    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn(
+    if splits is None:
+        splits = gemm_nn_splits(m, k, n)
+    if splits > 1 and (n % 4 or out.stride(0) % 4 or out.data_ptr() % 8):
+        splits = 1
+    ws = torch.empty(splits * m * n, dtype=torch.float32, device=a.device) if splits > 1 else None
+    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_splitk(
         _p(a), ctypes.c_long(a.stride(0)), _p(w), ctypes.c_long(w.stride(0)), _p(bias) if bias is not None else None,
-        _p(out), ctypes.c_long(out.stride(0)), ctypes.c_long(m), k, n, 0, _stream()), meta=dict(flops=2.0 * m * k * n))
+        _p(out), ctypes.c_long(out.stride(0)), ctypes.c_long(m), k, n, int(splits), _p(ws) if ws is not None else None,
+        ctypes.c_long(ws.numel() * 4 if ws is not None else 0), _stream()), meta=dict(flops=2.0 * m * k * n))
     return out

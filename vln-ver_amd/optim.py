@@ -103,7 +103,13 @@ class ClipAdamW(torch.optim.Optimizer):
                                  steps_dev=torch.empty(n, dtype=torch.int32, device=dev))
 
         def push(dst, array):
-            src = torch.from_numpy(array).pin_memory()
+            stage = getattr(self, '_stage', None)
+            if capturing and stage is not None and stage.numel() == array.size and array.dtype == np.int64:
+                src = stage                               # (pinned before the capture: no host allocation inside it)
+                src.numpy()[:] = array
+                self._stage = None
+            else:
+                src = torch.from_numpy(array).pin_memory()
             if capturing:
                 self._keep.append(src)
             dst.copy_(src.view(dst.shape), non_blocking=True)
@@ -162,15 +168,13 @@ class ClipAdamW(torch.optim.Optimizer):
     # ------------------------------------------------------------------ hipGraph support
     @torch.no_grad()
     def prepare_capture(self):
-        """Call right before capturing a graph that contains ``step()`` (gradients must exist): creates missing state and
-        makes hyper-parameters and update counts resident, so that the captured ``step()`` has nothing to upload but the
-        pointer table of the capture's own gradient buffers."""
-        ps, gs, hyper, _ = self._collect()
-        if ps:
-            states = [self.state[p] for p in ps]
-            ptrs = ([p.data_ptr() for p in ps] + [g.data_ptr() for g in gs] + [st['exp_avg'].data_ptr() for st in states]
-                    + [st['exp_avg_sq'].data_ptr() for st in states])
-            self._upload(ptrs, hyper, [st['step'] for st in states], ps[0].device, False)
+        """Call right before capturing a graph that contains ``step()``, after at least one eager step over the same set of
+        parameters (their state, hyper-parameters and update counts are then resident on the device): pins the staging
+        buffer the captured ``step()`` fills with the pointer table of the capture's own gradient buffers."""
+        n = sum(1 for group in self.param_groups for p in group['params'] if self.state.get(p))
+        if not n or self._dev is None or self._dev['n'] != n:
+            raise RuntimeError('ClipAdamW.prepare_capture(): run one eager step over the parameters of the step first')
+        self._stage = torch.empty(4 * n, dtype=torch.int64).pin_memory()
 
     def replayed(self, times=1):
         """A graph holding ``step()`` was replayed ``times`` times: advance the host's step counts to what the device holds."""
@@ -201,7 +205,13 @@ class ClipAdamW(torch.optim.Optimizer):
             d['hyper'] = hyper
 
     def load_state_dict(self, state_dict):
+        """A torch.optim.AdamW checkpoint loads too (per-parameter step tensors become ints on the next step); its
+        parameter groups carry no ``max_norm`` -- the groups REPLACE ours in torch's loader -- so keys a group lost get this
+        optimizer's constructor values back."""
         super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for k, v in self.defaults.items():
+                group.setdefault(k, v)
         self._dev = None             # (pointers and counts are compared on every step anyway; drop the buffers with the old state)
 
     def __setstate__(self, state):

@@ -509,6 +509,16 @@ int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* 
  *   one-viewpoint step (vocc.py:222 samples_per_gpu = 1) give 12-42 output tiles, a fraction of the chip: every slice's
  *   partial tile stays fp32 in `workspace` (f32 [splits][M][N]) and one pass adds them up, adds the bias and rounds once.
  *   ver_gemm_nn_splits: the slice count the library would pick (1: no workspace needed).  Needs N % 4 == 0, ldc % 4 == 0. */
+/*   the same product with an IMPLICIT operand (ABI 29): the tap matrix of a Z = 4 lattice layer is never written -- row r of
+ *   the product is cell (b, zl, y, x) of the combined (H, W) lattice (r = ((b 2 + zl) H + y) W + x; M = B 2 H W), its K axis
+ *   `ntaps` blocks of C channels, block t = the channel vector of cell (zl + dz, y + dy, x + dx) of the source lattice
+ *   (taps int [ntaps][3] = (dz in {0, 2}, dy, dx), HOST memory; zeros outside) -- what ver_lattice_gather would have copied,
+ *   read straight from the lattice by the kernel's LDS-DMA.  layout: 0 plain [B,4,H,W,C], 2 z-split, 3 planar z-split (as
+ *   ver_lattice_gather).  w bf16 [ntaps*C, ldw].  rowpos f32 [2 H W][N] or NULL: added to row r by its position r % (2 H W)
+ *   (the constant-pattern columns of the explicit tap matrix times their weight rows); bias f32 [N] or NULL.
+ *   Requirements: C % 32 == 0, ntaps <= 64, the source lattice below 2 GiB. */
+int  ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps, const void* w,
+                      long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N, void* stream);
 int  ver_gemm_nn_splits(long M, int K, int N);
 int  ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
                         int N, int splits, void* workspace, long workspace_bytes, void* stream);

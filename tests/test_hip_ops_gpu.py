@@ -1653,7 +1653,7 @@ def test_class_stacked_weights_straight_from_the_parameter(kind, ci, co, dtype):
 
 
 @pytest.mark.parametrize('M,K,lda,c0,N,splits', [(450, 38400, 38400, 0, 1536, None), (1800, 9536, 14464, 1696, 1536, None),
-                                                  (450, 6304, 14464, 4928, 1536, 5), (77, 2048, 2048, 0, 260, 4), (300, 4096, 4096, 0, 1536, 64)])
+                                                  (450, 6304, 14464, 4928, 1536, 5), (77, 2048, 2048, 0, 264, 4), (300, 4096, 4096, 0, 1536, 64)])
 def test_gemm_nn_split_over_k_for_skinny_operands(M, K, lda, c0, N, splits):
     """ver_gemm_nn_splitk: the forward product of a lattice layer at the reference's own batch point (vocc.py:222, one viewpoint
     per step: 450 / 1 800 rows) cut into K slices with fp32 partial tiles -- the library's choice of slices and explicit ones
@@ -1677,3 +1677,41 @@ def test_gemm_nn_split_over_k_for_skinny_operands(M, K, lda, c0, N, splits):
     one = hip.gemm_nn(A, W, b, splits=1)
     assert rel_l2(got.float(), one.float()) < 3e-3                       # (fp32 sums in another order, one rounding each)
     assert hip.gemm_nn_splits(345600, 14304, 1536) == 1                   # the tall products stay one pass
+
+
+@pytest.mark.parametrize('layout,B,hc,wc,C,N', [(2, 3, 6, 4, 64, 256), (3, 2, 6, 8, 96, 200), (0, 2, 5, 3, 64, 128), (3, 5, 30, 30, 768, 1536),
+                                                (2, 9, 15, 15, 768, 1536)])
+def test_gemm_nn_taps_equals_gather_then_gemm(layout, B, hc, wc, C, N):
+    """ver_gemm_nn_taps (implicit operand: the tap matrix of a Z = 4 lattice layer read straight from the lattice) against
+    ver_lattice_gather + ver_gemm_nn on the same lattice, taps and weights: the same fragments reach the same MFMAs in the
+    same order -- bit-exact; with the position table and the bias: one rounding of the same fp32 sum + table."""
+    hip, ups = pkg('hipops'), pkg('dense_heads.upsample')
+    gen = torch.Generator(device='cpu').manual_seed(97 + layout + B)
+    plain = torch.randn(B, 4, hc, wc, C, generator=gen).bfloat16()
+    e = ups._from_plain(plain, layout).contiguous().to(DEV)
+    if layout == 0:
+        taps = [(2 * j, bb - 2, cc - 2) for bb in range(5) for cc in range(5) for j in range(2)][:18]
+    else:
+        taps = [(2 * j, dy, dx) for dx in (-1, 0, 1) for dy in (-1, 0, 1) for j in range(2)]
+    nt = len(taps)
+    offs = [t * C for t in range(nt)]
+    m = B * 2 * hc * wc
+    a = torch.empty(m, nt * C, dtype=torch.bfloat16, device=DEV)
+    hip.lattice_gather(e, a, taps, offs, (hc, wc), layout, row_z=2)
+    w = (torch.randn(nt * C, N, generator=gen) * 0.05).bfloat16().to(DEV)
+    want = hip.gemm_nn(a, w, splits=1)
+    got = hip.gemm_nn_taps(e, layout, (hc, wc), taps, w)
+    assert torch.equal(got, want)
+    # a subset of the taps (a parity class reads 8-12 of the 18 blocks) through a row range of the weights
+    sub = taps[4:12]
+    want = hip.gemm_nn(a[:, 4 * C:12 * C], w[4 * C:12 * C], splits=1)
+    assert torch.equal(hip.gemm_nn_taps(e, layout, (hc, wc), sub, w[4 * C:12 * C]), want)
+    rowpos = torch.randn(2 * hc * wc, N, generator=gen).to(DEV)
+    bias = torch.randn(N, generator=gen).to(DEV)
+    wide = torch.full((m, N + 16), 7.0, device=DEV, dtype=torch.bfloat16)
+    got = hip.gemm_nn_taps(e, layout, (hc, wc), taps, w, rowpos=rowpos, bias=bias, out=wide[:, 8:8 + N])
+    ref = a.float() @ w.float() + rowpos.repeat(B, 1) + bias
+    from util import rel_l2
+    assert rel_l2(got.float(), ref) < 3e-3
+    assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    assert float(wide[:, :8].min()) == 7.0 and float(wide[:, 8 + N:].min()) == 7.0

@@ -51,6 +51,19 @@ __device__ __forceinline__ bf16x8 frag(i32x2 lo, i32x2 hi) {
     return __builtin_bit_cast(bf16x8, (i32x4)__builtin_shufflevector(lo, hi, 0, 1, 2, 3));
 }
 
+// Implicit operand (ver_gemm_nn_taps): A is never materialised -- row r of the product is cell (b, zl, y, x) of a Z = 4
+// lattice (r = ((b 2 + zl) H + y) W + x), its K axis `ntaps` blocks of C channels, block t = the C-vector of the neighbouring
+// cell (zl + dz[t], y + dy[t], x + dx[t]) of the SOURCE lattice (zeros outside): exactly the tap matrix ver_lattice_gather
+// writes, read straight from the lattice by the LDS-DMA (a tap block of a row is one contiguous 2 C-byte vector).
+struct TapArgs {
+    const __bf16* lattice;
+    long lattice_bytes;
+    int B, H, W, C, ntaps, P;           // H, W: the combined lattice = the rows' grid; P = 2 H W rows per viewpoint
+    const float* rowpos;                // [P][N] fp32 or null: added to row r's result by its position r % P (the constant
+                                        //   columns of the tap matrix x their weight rows, and the bias)
+    signed char dz[64], dy[64], dx[64];
+};
+
 struct GemmArgs {
     const __bf16* A;
     const __bf16* W;
@@ -60,6 +73,7 @@ struct GemmArgs {
     int K, N, tiles_n, T, per_xcd;
     int S, Kc;              // split over K (skinny products: a one-viewpoint step has 450 / 1 800 rows, 12-42 tiles):
     float* ws;              //   S slices of Kc columns, fp32 partial tiles [S][M][N], added up by k_gemm_reduce
+    TapArgs t;
 };
 
 struct GemmLane {
@@ -71,9 +85,69 @@ struct GemmLane {
     int dmaA, dmaW;         // offsets of this wave's pieces inside a stage
 };
 
-template <int ST>
+// byte offset of the C-vector of cell (b, z = zl + dz, y, x) in a source lattice of layout L (ver_lattice_gather's layouts:
+// 0 plain [B,4,H,W,C], 2 z-split [B,2,H,W,2,C], 3 planar z-split [4,B,2,H/2,W/2,2,C]); outside the lattice: an offset
+// beyond every buffer range (the DMA then writes zeros).  All lattices here are < 2 GiB (checked by the launcher).
+constexpr int kOutside = (int)0x80000000;
+template <int L>
+__device__ __forceinline__ int cell_off(const TapArgs& t, int b, int zl, int y, int x, int dz) {
+    if ((unsigned)y >= (unsigned)t.H || (unsigned)x >= (unsigned)t.W || b < 0) return kOutside;
+    const int j = dz >> 1;                                  // z = zl + dz, dz in {0, 2}: same zl, upper half j
+    int v;
+    if (L == 0)
+        v = ((b * 4 + zl + dz) * t.H + y) * t.W + x;
+    else if (L == 2)
+        v = ((((b * 2 + zl) * t.H + y) * t.W + x) << 1) + j;
+    else
+        v = (((((((y & 1) << 1 | (x & 1)) * t.B + b) * 2 + zl) * (t.H >> 1) + (y >> 1)) * (t.W >> 1) + (x >> 1)) << 1) + j;
+    return v * t.C * 2;
+}
+
+struct TapLane {                // implicit operand: this lane's two rows and the running tap / channel of its DMA stream
+    int b1, zl1, y1, x1, b2, zl2, y2, x2;
+    int vo1, vo2;               // byte offsets of the current tap's vectors (+ this lane's 16-byte chunk)
+    int chunk;                  // pch * 16
+    int tap, ch;                // wave-uniform: tap block and byte offset inside it of the NEXT piece to request
+};
+
+template <int L>
+__device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl) {
+    if (tl.tap < t.ntaps) {
+        const int dz = t.dz[tl.tap], dy = t.dy[tl.tap], dx = t.dx[tl.tap];
+        const int o1 = cell_off<L>(t, tl.b1, tl.zl1, tl.y1 + dy, tl.x1 + dx, dz);
+        const int o2 = cell_off<L>(t, tl.b2, tl.zl2, tl.y2 + dy, tl.x2 + dx, dz);
+        tl.vo1 = o1 == kOutside ? kOutside : o1 + tl.chunk;
+        tl.vo2 = o2 == kOutside ? kOutside : o2 + tl.chunk;
+    } else {
+        tl.vo1 = tl.vo2 = kOutside;                          // (pieces requested past the last phase: nobody reads them)
+    }
+}
+
+// this wave's two A pieces of one phase: explicit operand (IMPL < 0) or straight from the lattice
+template <int IMPL>
+__device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu_buffer_rsrc_t ra, int& soA, const TapArgs& t,
+                                          TapLane& tl) {
+    if constexpr (IMPL < 0) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, c.voA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dst + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
+        soA += 64;
+    } else {
+        const int ch = __builtin_amdgcn_readfirstlane(tl.ch);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, tl.vo1, ch, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dst + 1024), 16, tl.vo2, ch, 0, 0);
+        tl.ch = ch + 64;
+        if (tl.ch == 2 * t.C) {                              // next tap block: the lane's two source vectors move
+            tl.ch = 0;
+            tl.tap = __builtin_amdgcn_readfirstlane(tl.tap) + 1;
+            tap_offsets<IMPL>(t, tl);
+        }
+    }
+}
+
+
+template <int ST, int IMPL>
 __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const GemmLane& c, __amdgpu_buffer_rsrc_t ra,
-                                      __amdgpu_buffer_rsrc_t rw, int& soA, int& soW) {
+                                      __amdgpu_buffer_rsrc_t rw, int& soA, int& soW, const TapArgs& t, TapLane& tl) {
     // (the offset field of a DS instruction has 16 bits: stages 2-3 go through base registers 64 KiB up)
     constexpr int SB = (ST & 1) * kStageBytes;
     constexpr int UP = ST >= 2 ? 65536 : 0;
@@ -99,11 +173,9 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Gemm
     av[1][3] = row_read<SB + 6144>(a1);
     // LDS-DMA of the phase two ahead: this wave's 2 x 16 rows of the A image and its piece of each W slab
     constexpr int DS = ((ST + 2) % kStages) * kStageBytes;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS + c.dmaA), 16, c.voA, soA, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + DS + c.dmaA + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
+    request_a<IMPL>(lds + DS + c.dmaA, c, ra, soA, t, tl);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
-    soA += 64;
     soW += 2 * c.stepW;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's pieces of the NEXT phase have landed
     __builtin_amdgcn_s_barrier();
@@ -135,6 +207,7 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Gemm
     __builtin_amdgcn_s_barrier();
 }
 
+template <int IMPL>
 __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,9 +222,10 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     const int k0 = split * p.Kc, klen = min(p.Kc, p.K - k0);
     const int nphase = klen / 32;
 
-    // A: rows row0 .. row0 + 255 (past M: zeros by the buffer range), this slice's columns of the operand
-    const __bf16* ab = p.A + row0 * p.lda + k0;
-    const long abytes = ((p.M - row0 - 1) * p.lda + klen) * 2;
+    // A: rows row0 .. row0 + 255 (past M: zeros by the buffer range), this slice's columns of the operand -- or the whole
+    // source lattice (implicit operand: the per-lane offsets address the tap vectors)
+    const __bf16* ab = IMPL < 0 ? p.A + row0 * p.lda + k0 : p.t.lattice;
+    const long abytes = IMPL < 0 ? ((p.M - row0 - 1) * p.lda + klen) * 2 : p.t.lattice_bytes;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
     // W: columns nt * 256 .., the slice's rows (behind the last element: zeros)
     const __bf16* wb = p.W + (long)k0 * p.ldw + (long)nt * kTile;
@@ -184,6 +258,29 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
         c.offB0 = lbase + ((q >> 1) * 32 + (cl >> 2)) * 128 + lowch * 16 + (cl & 1) * 8 + wc * 1024;
         c.offB1 = c.offB0 ^ 64;
     }
+    TapLane tl = {};
+    if constexpr (IMPL >= 0) {
+        // this lane's two rows of the tile -> cells (b, zl, y, x); rows past M: no cell (every tap outside)
+        const int prow = 32 * wave + (lane >> 2);
+        const int hw = p.t.H * p.t.W;
+        auto decode = [&](long r, int& b, int& zl, int& y, int& x) {
+            if (r >= p.M) {
+                b = -1, zl = y = x = 0;
+                return;
+            }
+            b = (int)(r / p.t.P);
+            const int pos = (int)(r - (long)b * p.t.P);
+            zl = pos / hw;
+            const int rem = pos - zl * hw;
+            y = rem / p.t.W;
+            x = rem - y * p.t.W;
+        };
+        decode(row0 + prow, tl.b1, tl.zl1, tl.y1, tl.x1);
+        decode(row0 + prow + 16, tl.b2, tl.zl2, tl.y2, tl.x2);
+        tl.chunk = ((lane & 3) ^ ((prow >> 2) & 3)) * 16;
+        tl.tap = 0, tl.ch = 0;
+        tap_offsets<IMPL>(p.t, tl);
+    }
     f32x16 acc[4][2];
 #pragma unroll
     for (int it = 0; it < 4; ++it)
@@ -196,11 +293,9 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     // prologue: phases 0 and 1 in flight, phase 0 landed
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kStageBytes + c.dmaA), 16, c.voA, soA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kStageBytes + c.dmaA + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
+        request_a<IMPL>(lds + s * kStageBytes + c.dmaA, c, ra, soA, p.t, tl);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
-        soA += 64;
         soW += 2 * c.stepW;
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -209,15 +304,15 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
 
     int s = 0;
     for (; s + kStages <= nphase; s += kStages) {
-        phase<0>(lds, acc, c, ra, rw, soA, soW);
-        phase<1>(lds, acc, c, ra, rw, soA, soW);
-        phase<2>(lds, acc, c, ra, rw, soA, soW);
-        phase<3>(lds, acc, c, ra, rw, soA, soW);
+        phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+        phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+        phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+        phase<3, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
     }
     const int rem = nphase - s;
-    if (rem > 0) phase<0>(lds, acc, c, ra, rw, soA, soW);
-    if (rem > 1) phase<1>(lds, acc, c, ra, rw, soA, soW);
-    if (rem > 2) phase<2>(lds, acc, c, ra, rw, soA, soW);
+    if (rem > 0) phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+    if (rem > 1) phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+    if (rem > 2) phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -247,18 +342,34 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cb, 0, (int)max(0L, min(cbytes, 0xFFFFFFFFL)), 0x00020000);
     const int ldc2 = (int)(p.ldc * 2);
     const int vbase = (128 * wr + 4 * (lane >> 5)) * ldc2 + (64 * wc + (lane & 31)) * 2;
+    // implicit operand: + rowpos[row % P][j], the position-dependent constant part of the row's result (rows of a tile are
+    // consecutive: one conditional subtraction per row instead of a division)
+    const bool haspos = IMPL >= 0 && p.t.rowpos != nullptr;
+    const int pos0 = haspos ? (int)((row0 + 128 * wr + 4 * (lane >> 5)) % p.t.P) : 0;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
         const int j = nt * kTile + 64 * wc + 32 * jt + (lane & 31);
         const float bj = (p.bias && j < p.N) ? p.bias[j] : 0.0f;
         const int vo = j < p.N ? vbase + 64 * jt : -2;
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int it = 0; it < 4; ++it) {
+            float add[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const __bf16 v = (__bf16)(acc[it][jt][r] + bj);
+                add[r] = bj;
+                if (haspos) {
+                    int pp = pos0 + 32 * it + (r & 3) + 8 * (r >> 2);
+                    while (pp >= p.t.P) pp -= p.t.P;          // (at most once for P >= 256: the step's lattices have 450+)
+                    const long row = row0 + 128 * wr + 4 * (lane >> 5) + 32 * it + (r & 3) + 8 * (r >> 2);
+                    if (j < p.N && row < p.M) add[r] += p.t.rowpos[(long)pp * p.N + j];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const __bf16 v = (__bf16)(acc[it][jt][r] + add[r]);
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, v), rc, vo, (32 * it + (r & 3) + 8 * (r >> 2)) * ldc2, 0);
             }
+        }
     }
 }
 // C[i][j] (bf16, row pitch ldc) = sum over the S partial products + bias[j]; 4 columns per thread (N % 4 == 0)
@@ -343,13 +454,74 @@ extern "C" int ver_gemm_nn_splitk(const void* a, long lda, const void* w, long l
     p.S = splits == 1 ? 1 : (K + p.Kc - 1) / p.Kc;
     p.ws = (float*)workspace;
     p.per_xcd = (p.T * p.S + 7) / 8;
-    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    p.t = TapArgs{};
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm_nn<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_gemm_nn: LDS attribute: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(k_gemm_nn, dim3((unsigned)(8 * p.per_xcd)), dim3(512), kLdsBytes, st, p);
+    hipLaunchKernelGGL(k_gemm_nn<-1>, dim3((unsigned)(8 * p.per_xcd)), dim3(512), kLdsBytes, st, p);
     if (p.S > 1) {
         long grid = (M * N / 4 + 255) / 256;
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, bias, (__bf16*)c, ldc, p.S, M, N);
     }
     return ver_check_launch("ver_gemm_nn");
+}
+
+extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
+                                const void* w, long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N,
+                                void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VER_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && ntaps > 0, VER_EINVAL, "ver_gemm_nn_taps: bad sizes");
+    VER_REQUIRE(layout == 0 || layout == 2 || layout == 3, VER_EINVAL, "ver_gemm_nn_taps: layout %d (0 plain, 2 z-split, 3 planar z-split)", layout);
+    VER_REQUIRE(layout != 3 || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_gemm_nn_taps: planar needs even H, W");
+    if (B == 0) return VER_OK;
+    VER_REQUIRE(lattice && taps && w && c, VER_EINVAL, "ver_gemm_nn_taps: null pointer argument");
+    VER_REQUIRE(ntaps <= 64, VER_EUNSUPPORTED, "ver_gemm_nn_taps: %d taps (at most 64)", ntaps);
+    VER_REQUIRE(C % 32 == 0 && C >= 64, VER_EUNSUPPORTED, "ver_gemm_nn_taps: C = %d must be a multiple of 32 (>= 64)", C);
+    const long M = (long)B * 2 * H * W, lbytes = (long)B * 4 * H * W * C * 2;
+    const long K = (long)ntaps * C;
+    VER_REQUIRE(lbytes < 0x7FFFFFFFL, VER_EUNSUPPORTED, "ver_gemm_nn_taps: the source lattice (%ld bytes) exceeds the 2-GiB range of the tap offsets", lbytes);
+    VER_REQUIRE(ldw >= N && ldc >= N && ldw % 8 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)lattice & 15) == 0, VER_EUNSUPPORTED,
+                "ver_gemm_nn_taps: w must be 16-byte aligned with a row pitch that is a multiple of 8 elements");
+    VER_REQUIRE(K * ldw * 2 < 0xFFFFFFFFL && 256L * ldc * 2 < 0x7FFFFFFFL && K < 0x7FFFFFFFL, VER_EUNSUPPORTED,
+                "ver_gemm_nn_taps: a tile's operand range exceeds the 32-bit offsets");
+    GemmArgs p;
+    p.A = nullptr;
+    p.W = (const __bf16*)w;
+    p.bias = bias;
+    p.C = (__bf16*)c;
+    p.lda = 0;
+    p.ldw = ldw;
+    p.ldc = ldc;
+    p.M = M;
+    p.K = (int)K;
+    p.N = N;
+    p.tiles_n = (N + kTile - 1) / kTile;
+    p.T = (int)((M + kTile - 1) / kTile) * p.tiles_n;
+    p.Kc = (int)K;
+    p.S = 1;
+    p.ws = nullptr;
+    p.per_xcd = (p.T + 7) / 8;
+    p.t = TapArgs{};
+    p.t.lattice = (const __bf16*)lattice;
+    p.t.lattice_bytes = lbytes;
+    p.t.B = B, p.t.H = H, p.t.W = W, p.t.C = C, p.t.ntaps = ntaps, p.t.P = 2 * H * W;
+    p.t.rowpos = rowpos;
+    for (int i = 0; i < ntaps; ++i) {
+        const int dz = taps[3 * i], dy = taps[3 * i + 1], dx = taps[3 * i + 2];
+        VER_REQUIRE((dz == 0 || dz == 2) && dy >= -64 && dy <= 64 && dx >= -64 && dx <= 64, VER_EINVAL,
+                    "ver_gemm_nn_taps: tap %d = (%d, %d, %d): dz must be 0 or 2", i, dz, dy, dx);
+        p.t.dz[i] = (signed char)dz, p.t.dy[i] = (signed char)dy, p.t.dx[i] = (signed char)dx;
+    }
+    hipError_t e = hipSuccess;
+#define VER_GEMM_TAPS(L)                                                                                                  \
+    do {                                                                                                                  \
+        e = hipFuncSetAttribute((const void*)k_gemm_nn<L>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);       \
+        if (e == hipSuccess) hipLaunchKernelGGL(k_gemm_nn<L>, dim3((unsigned)(8 * p.per_xcd)), dim3(512), kLdsBytes, st, p); \
+    } while (0)
+    if (layout == 0) VER_GEMM_TAPS(0);
+    else if (layout == 2) VER_GEMM_TAPS(2);
+    else VER_GEMM_TAPS(3);
+#undef VER_GEMM_TAPS
+    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_gemm_nn_taps: LDS attribute: %s", hipGetErrorString(e));
+    return ver_check_launch("ver_gemm_nn_taps");
 }

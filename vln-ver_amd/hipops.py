@@ -26,7 +26,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_splits_ld', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_gemm_nn_taps', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
 
 _lib = None
 
@@ -1279,4 +1279,43 @@ def gemm_nn(a, w, bias=None, out=None, splits=None):
         _p(a), ctypes.c_long(a.stride(0)), _p(w), ctypes.c_long(w.stride(0)), _p(bias) if bias is not None else None,
         _p(out), ctypes.c_long(out.stride(0)), ctypes.c_long(m), k, n, int(splits), _p(ws) if ws is not None else None,
         ctypes.c_long(ws.numel() * 4 if ws is not None else 0), _stream()), meta=dict(flops=2.0 * m * k * n))
+    return out
+
+
+def gemm_nn_taps_supported(lattice, layout, w, c):
+    """What ``gemm_nn_taps`` takes: a contiguous bf16 lattice below 2 GiB in layout 0 / 2 / 3 with C % 32 == 0, a bf16 weight
+    matrix with 16-byte aligned rows."""
+    return (lattice.is_cuda and lattice.dtype == torch.bfloat16 and lattice.is_contiguous() and layout in (PLAIN, ZSPLIT, PLANAR_ZSPLIT)
+            and lattice.numel() * 2 < 2 ** 31 - 1 and c % 32 == 0 and c >= 64 and w.is_cuda and w.dtype == torch.bfloat16
+            and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0)
+
+
+def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, out=None):
+    """ver_gemm_nn_taps: ``tap_matrix(lattice) @ w (+ rowpos by row position) (+ bias)`` without the tap matrix: lattice bf16 in
+    layout 0 / 2 / 3 (see ``lattice_gather``), rows = the cells (b, zl, y, x) of the combined (H, W) lattice, taps a list of
+    (dz in {0, 2}, dy, dx), w bf16 [len(taps) * C, N] -> bf16 [B * 2 * H * W, N]."""
+    lat, w = _gpu(lattice, 'lattice'), _gpu(w, 'w')
+    H, W = combined_hw
+    B, _, C = _lattice_dims(lat, int(layout))
+    if not gemm_nn_taps_supported(lat, int(layout), w, C):
+        raise RuntimeError('gemm_nn_taps: unsupported operands %s layout %d / %s %s' % (tuple(lat.shape), layout, tuple(w.shape), w.stride()))
+    m, n = B * 2 * H * W, w.shape[1]
+    if w.shape[0] != len(taps) * C:
+        raise ValueError('gemm_nn_taps: w has %d rows, %d taps x %d channels expected' % (w.shape[0], len(taps), C))
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=lat.device)
+    if out.shape != (m, n) or out.dtype != torch.bfloat16 or out.stride(1) != 1 or not out.is_cuda:
+        raise RuntimeError('gemm_nn_taps: out must be a bf16 [M, N] GPU matrix with unit column stride')
+    if rowpos is not None:
+        rowpos = _gpu(rowpos, 'rowpos').float().contiguous()
+        if tuple(rowpos.shape) != (2 * H * W, n):
+            raise ValueError('gemm_nn_taps: rowpos must be [2 H W, N]')
+    if bias is not None:
+        bias = _gpu(bias, 'bias').float().contiguous()
+    flat = [int(v) for t in taps for v in t]
+    arr = (ctypes.c_int * len(flat))(*flat)
+    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_taps(
+        _p(lat), int(layout), int(B), int(H), int(W), int(C), arr, len(taps), _p(w), ctypes.c_long(w.stride(0)),
+        _p(rowpos) if rowpos is not None else None, _p(bias) if bias is not None else None, _p(out), ctypes.c_long(out.stride(0)),
+        int(n), _stream()), meta=dict(flops=2.0 * m * w.shape[0] * n))
     return out

@@ -494,6 +494,15 @@ int  ver_wgrad_tn_splits_ld(long M, int Ka, int N, long ld);
 long ver_wgrad_tn_workspace(long M, int Ka, int N, int splits);
 int  ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, long M, int Ka, int N, void* out, long ldo,
                   int out_dtype, int splits, int flags, void* workspace, long workspace_bytes, void* stream);
+/*   the same product with the IMPLICIT tap matrix of ver_gemm_nn_segments as A (ABI 29): out[Ka, N] = A^T g, A's columns =
+ *   the segments in order (taps int [nseg][3]: (dz, dy, dx) = C columns, (-1 - k, 0, 0) = the cw columns of pattern block k of
+ *   cst), rows = the cells of the combined (H, W) lattice, M = B 2 H W.  Segment widths must be multiples of 64 (a wave's
+ *   64-column LDS-DMA piece lies inside one segment): C % 64 == 0, cw % 64 == 0.  2 H W < 65 536, the source lattice below
+ *   2 GiB.  ver_wgrad_tn_segments_splits: the row-chunk count for `splits` = 0 (sizes the workspace f32 [splits][Ka][N]). */
+int  ver_wgrad_tn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int nseg, const void* cst,
+                           int ncst, int cw, const void* g, long ldg, int N, void* out, long ldo, int out_dtype, int splits,
+                           void* workspace, long workspace_bytes, void* stream);
+int  ver_wgrad_tn_segments_splits(int B, int H, int W, long Ka, int N, long ldg);
 
 /* Forward product of the same layers (ABI 24):  c[M, N] = a[M, K] w[K, N] (+ bias[N]), bf16 in, fp32 accumulation, bf16 out.
  * Replaces the `torch.mm(a_mat[:, c0:c1], w, out=...)` / `addmm` of dense_heads/upsample.py and the `a @ wa.t()` of
@@ -519,6 +528,14 @@ int  ver_gemm_nn(const void* a, long lda, const void* w, long ldw, const float* 
  *   Requirements: C % 32 == 0, ntaps <= 64, the source lattice below 2 GiB. */
 int  ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps, const void* w,
                       long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N, void* stream);
+/*   ... with constant-pattern segments between the tap blocks: a taps entry (-1 - k, 0, 0) stands for the `cw` columns of
+ *   block k of cst bf16 [2 H W][ncst][cw], which depend on the row's position r % (2 H W) only (the 0/1 patterns of the
+ *   bias-valued odd input positions and the ones column of dense_heads/upsample.py's class layout
+ *   [P00 | G1 | P10 | G2 | P11 | G3 | G4 | P01]); w then has sum-of-segment-widths rows, in segment order: the explicit
+ *   tap matrix's column ranges and class weight matrices as they are.  cw % 32 == 0. */
+int  ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
+                          const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos, const float* bias,
+                          void* c, long ldc, int N, void* stream);
 int  ver_gemm_nn_splits(long M, int K, int N);
 int  ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
                         int N, int splits, void* workspace, long workspace_bytes, void* stream);

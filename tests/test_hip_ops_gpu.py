@@ -1715,3 +1715,66 @@ def test_gemm_nn_taps_equals_gather_then_gemm(layout, B, hc, wc, C, N):
     assert rel_l2(got.float(), ref) < 3e-3
     assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
     assert float(wide[:, :8].min()) == 7.0 and float(wide[:, 8 + N:].min()) == 7.0
+
+
+@pytest.mark.parametrize('planar,B,hc', [(False, 3, 6), (True, 2, 8), (True, 4, 30)])
+def test_gemm_nn_segments_reads_the_class_ranges_of_the_tap_matrix(planar, B, hc):
+    """ver_gemm_nn_segments on the class layout of a Z = 4 lattice layer ([P00 | G1 | P10 | G2 | P11 | G3 | G4 | P01]: tap
+    blocks with constant-pattern blocks between them) against ver_lattice_gather (with the pattern blocks) + ver_gemm_nn on
+    every parity class's column range: the same operands in the same order -- bit-exact."""
+    hip, ups = pkg('hipops'), pkg('dense_heads.upsample')
+    C, N = 64, 256
+    gen = torch.Generator(device='cpu').manual_seed(101 + hc)
+    layout = ups.ZS_PLANAR_SPLIT if planar else ups.ZS_SPLIT
+    plain = torch.randn(B, 4, hc, hc, C, generator=gen).bfloat16()
+    e = ups._from_plain(plain, layout).contiguous().to(DEV)
+    plan, kt, _, taps, offs = ups._layer_plan_z4(C, torch.device(DEV))
+    m = B * 2 * hc * hc
+    a = torch.full((m, kt), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert ups._gather_z4(e, layout, a, taps, offs, C, hc, hc, with_const=True)
+    table, coffs = ups._const_rows_z4(C, hc, hc, torch.device(DEV), torch.bfloat16)
+    for cls in ups._CLASSES:
+        c0, c1 = plan[cls][:2]
+        segs = ups._class_segments_z4(cls, C)
+        w = (torch.randn(c1 - c0, N, generator=gen) * 0.1).bfloat16().to(DEV)
+        want = hip.gemm_nn(a[:, c0:c1], w, splits=1)
+        got = hip.gemm_nn_taps(e, layout, (hc, hc), segs, w, const_rows=table)
+        assert torch.equal(got, want), cls
+
+
+@pytest.mark.parametrize('planar,B,hc,C,splits', [(False, 3, 6, 64, 0), (True, 2, 8, 128, 3), (True, 3, 30, 768, 0), (False, 5, 15, 768, 0)])
+def test_wgrad_tn_segments_equals_gather_then_wgrad(planar, B, hc, C, splits):
+    """ver_wgrad_tn_segments (implicit tap matrix as the A of dW = A^T G) against ver_lattice_gather + ver_wgrad_tn on every
+    parity class's column range, same chunking: the same slabs reach the same MFMAs -- bit-exact in fp32; and layer 1's form
+    (plain source, 50 taps, no pattern blocks)."""
+    hip, ups = pkg('hipops'), pkg('dense_heads.upsample')
+    N = 256
+    gen = torch.Generator(device='cpu').manual_seed(103 + hc)
+    layout = ups.ZS_PLANAR_SPLIT if planar else ups.ZS_SPLIT
+    plain = torch.randn(B, 4, hc, hc, C, generator=gen).bfloat16()
+    e = ups._from_plain(plain, layout).contiguous().to(DEV)
+    plan, kt, _, taps, offs = ups._layer_plan_z4(C, torch.device(DEV))
+    m = B * 2 * hc * hc
+    a = torch.full((m, kt), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert ups._gather_z4(e, layout, a, taps, offs, C, hc, hc, with_const=True)
+    table, _ = ups._const_rows_z4(C, hc, hc, torch.device(DEV), torch.bfloat16)
+    g = torch.randn(m, N, generator=gen).bfloat16().to(DEV)
+    for cls in ups._CLASSES:
+        c0, c1 = plan[cls][:2]
+        segs = ups._class_segments_z4(cls, C)
+        s_ = splits or hip.lib().ver_wgrad_tn_splits_ld(__import__('ctypes').c_long(m), c1 - c0, N, __import__('ctypes').c_long(kt))
+        want = hip.wgrad_tn(a[:, c0:c1], g, out_dtype=torch.float32, splits=s_)
+        got = hip.wgrad_tn_segments(e, layout, (hc, hc), segs, g, out_dtype=torch.float32, const_rows=table, splits=s_)
+        assert torch.equal(got, want), cls
+        stacked = torch.full((c1 - c0 + 16, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        hip.wgrad_tn_segments(e, layout, (hc, hc), segs, g, out=stacked[8:8 + c1 - c0], const_rows=table)
+        from util import rel_l2
+        assert rel_l2(stacked[8:8 + c1 - c0].float(), want) < 3e-3 and float(stacked[:8].min()) == 7.0 and float(stacked[8 + c1 - c0:].min()) == 7.0
+    if C % 64 == 0 and not planar:
+        taps0, offs0, _, _ = ups._layer0_z4_plan(C, torch.device(DEV))
+        x = plain.contiguous().to(DEV)
+        a0 = torch.empty(m, 50 * C, dtype=torch.bfloat16, device=DEV)
+        ups._gather_z4(x, 0, a0, taps0, offs0, C, hc, hc)
+        want = hip.wgrad_tn(a0, g, out_dtype=torch.float32, splits=2)
+        got = hip.wgrad_tn_segments(x, 0, (hc, hc), taps0, g, out_dtype=torch.float32, splits=2)
+        assert torch.equal(got, want)

@@ -59,9 +59,13 @@ struct TapArgs {
     const __bf16* lattice;
     long lattice_bytes;
     int B, H, W, C, ntaps, P;           // H, W: the combined lattice = the rows' grid; P = 2 H W rows per viewpoint
-    const float* rowpos;                // [P][N] fp32 or null: added to row r's result by its position r % P (the constant
-                                        //   columns of the tap matrix x their weight rows, and the bias)
-    signed char dz[64], dy[64], dx[64];
+    const float* rowpos;                // [P][N] fp32 or null: added to row r's result by its position r % P
+    // constant-pattern segments (kind[t] = 1): CW columns that depend on the row's POSITION r % P only -- block dz[t] of
+    // cst [P][ncst][CW] bf16 (dense_heads/upsample.py: the 0/1 patterns of the bias-valued odd positions + the 1 column)
+    const __bf16* cst;
+    long cst_bytes;
+    int CW, ncst;
+    signed char kind[64], dz[64], dy[64], dx[64];
 };
 
 struct GemmArgs {
@@ -103,21 +107,32 @@ __device__ __forceinline__ int cell_off(const TapArgs& t, int b, int zl, int y, 
     return v * t.C * 2;
 }
 
-struct TapLane {                // implicit operand: this lane's two rows and the running tap / channel of its DMA stream
+struct TapLane {                // implicit operand: this lane's two rows and the running segment / channel of its DMA stream
     int b1, zl1, y1, x1, b2, zl2, y2, x2;
-    int vo1, vo2;               // byte offsets of the current tap's vectors (+ this lane's 16-byte chunk)
+    int pos1, pos2;             // r % P of the two rows (constant-pattern segments)
+    int vo1, vo2;               // byte offsets of the current segment's vectors (+ this lane's 16-byte chunk)
     int chunk;                  // pch * 16
-    int tap, ch;                // wave-uniform: tap block and byte offset inside it of the NEXT piece to request
+    int tap, ch;                // wave-uniform: segment and byte offset inside it of the NEXT piece to request
+    int seglen, is_cst;         // wave-uniform: bytes of the current segment; it is read from the pattern table
 };
 
 template <int L>
 __device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl) {
+    tl.is_cst = 0;
+    tl.seglen = 2 * t.C;
     if (tl.tap < t.ntaps) {
         const int dz = t.dz[tl.tap], dy = t.dy[tl.tap], dx = t.dx[tl.tap];
-        const int o1 = cell_off<L>(t, tl.b1, tl.zl1, tl.y1 + dy, tl.x1 + dx, dz);
-        const int o2 = cell_off<L>(t, tl.b2, tl.zl2, tl.y2 + dy, tl.x2 + dx, dz);
-        tl.vo1 = o1 == kOutside ? kOutside : o1 + tl.chunk;
-        tl.vo2 = o2 == kOutside ? kOutside : o2 + tl.chunk;
+        if (t.kind[tl.tap]) {
+            tl.is_cst = 1;
+            tl.seglen = 2 * t.CW;
+            tl.vo1 = tl.b1 < 0 ? kOutside : (tl.pos1 * t.ncst + dz) * t.CW * 2 + tl.chunk;
+            tl.vo2 = tl.b2 < 0 ? kOutside : (tl.pos2 * t.ncst + dz) * t.CW * 2 + tl.chunk;
+        } else {
+            const int o1 = cell_off<L>(t, tl.b1, tl.zl1, tl.y1 + dy, tl.x1 + dx, dz);
+            const int o2 = cell_off<L>(t, tl.b2, tl.zl2, tl.y2 + dy, tl.x2 + dx, dz);
+            tl.vo1 = o1 == kOutside ? kOutside : o1 + tl.chunk;
+            tl.vo2 = o2 == kOutside ? kOutside : o2 + tl.chunk;
+        }
     } else {
         tl.vo1 = tl.vo2 = kOutside;                          // (pieces requested past the last phase: nobody reads them)
     }
@@ -125,18 +140,23 @@ __device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl) {
 
 // this wave's two A pieces of one phase: explicit operand (IMPL < 0) or straight from the lattice
 template <int IMPL>
-__device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu_buffer_rsrc_t ra, int& soA, const TapArgs& t,
-                                          TapLane& tl) {
+__device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rcst,
+                                          int& soA, const TapArgs& t, TapLane& tl) {
     if constexpr (IMPL < 0) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, c.voA, soA, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dst + 1024), 16, c.voA, soA + c.stepA16, 0, 0);
         soA += 64;
     } else {
         const int ch = __builtin_amdgcn_readfirstlane(tl.ch);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, tl.vo1, ch, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dst + 1024), 16, tl.vo2, ch, 0, 0);
+        if (__builtin_amdgcn_readfirstlane(tl.is_cst)) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rcst, (lds_void*)dst, 16, tl.vo1, ch, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rcst, (lds_void*)(dst + 1024), 16, tl.vo2, ch, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, tl.vo1, ch, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(dst + 1024), 16, tl.vo2, ch, 0, 0);
+        }
         tl.ch = ch + 64;
-        if (tl.ch == 2 * t.C) {                              // next tap block: the lane's two source vectors move
+        if (tl.ch == __builtin_amdgcn_readfirstlane(tl.seglen)) {    // next segment: the lane's two source vectors move
             tl.ch = 0;
             tl.tap = __builtin_amdgcn_readfirstlane(tl.tap) + 1;
             tap_offsets<IMPL>(t, tl);
@@ -147,7 +167,8 @@ __device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu
 
 template <int ST, int IMPL>
 __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const GemmLane& c, __amdgpu_buffer_rsrc_t ra,
-                                      __amdgpu_buffer_rsrc_t rw, int& soA, int& soW, const TapArgs& t, TapLane& tl) {
+                                      __amdgpu_buffer_rsrc_t rw, int& soA, int& soW, const TapArgs& t, TapLane& tl,
+                                      __amdgpu_buffer_rsrc_t rcst) {
     // (the offset field of a DS instruction has 16 bits: stages 2-3 go through base registers 64 KiB up)
     constexpr int SB = (ST & 1) * kStageBytes;
     constexpr int UP = ST >= 2 ? 65536 : 0;
@@ -173,7 +194,7 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Gemm
     av[1][3] = row_read<SB + 6144>(a1);
     // LDS-DMA of the phase two ahead: this wave's 2 x 16 rows of the A image and its piece of each W slab
     constexpr int DS = ((ST + 2) % kStages) * kStageBytes;
-    request_a<IMPL>(lds + DS + c.dmaA, c, ra, soA, t, tl);
+    request_a<IMPL>(lds + DS + c.dmaA, c, ra, rcst, soA, t, tl);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + DS + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
     soW += 2 * c.stepW;
@@ -227,6 +248,8 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     const __bf16* ab = IMPL < 0 ? p.A + row0 * p.lda + k0 : p.t.lattice;
     const long abytes = IMPL < 0 ? ((p.M - row0 - 1) * p.lda + klen) * 2 : p.t.lattice_bytes;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcst = __builtin_amdgcn_make_buffer_rsrc((void*)(IMPL < 0 ? ab : p.t.cst), 0,
+                                                                          (int)(IMPL < 0 ? 0L : max(0L, min(p.t.cst_bytes, 0x7FFFFFFFL))), 0x00020000);
     // W: columns nt * 256 .., the slice's rows (behind the last element: zeros)
     const __bf16* wb = p.W + (long)k0 * p.ldw + (long)nt * kTile;
     const long wbytes = ((long)(klen - 1) * p.ldw + p.N - (long)nt * kTile) * 2;
@@ -277,6 +300,8 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
         };
         decode(row0 + prow, tl.b1, tl.zl1, tl.y1, tl.x1);
         decode(row0 + prow + 16, tl.b2, tl.zl2, tl.y2, tl.x2);
+        tl.pos1 = (tl.zl1 * p.t.H + tl.y1) * p.t.W + tl.x1;
+        tl.pos2 = (tl.zl2 * p.t.H + tl.y2) * p.t.W + tl.x2;
         tl.chunk = ((lane & 3) ^ ((prow >> 2) & 3)) * 16;
         tl.tap = 0, tl.ch = 0;
         tap_offsets<IMPL>(p.t, tl);
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     // prologue: phases 0 and 1 in flight, phase 0 landed
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        request_a<IMPL>(lds + s * kStageBytes + c.dmaA, c, ra, soA, p.t, tl);
+        request_a<IMPL>(lds + s * kStageBytes + c.dmaA, c, ra, rcst, soA, p.t, tl);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 16384 + c.dmaW), 16, c.voW, soW, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + s * kStageBytes + 24576 + c.dmaW), 16, c.voW, soW + c.stepW, 0, 0);
         soW += 2 * c.stepW;
@@ -304,15 +329,15 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
 
     int s = 0;
     for (; s + kStages <= nphase; s += kStages) {
-        phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
-        phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
-        phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
-        phase<3, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+        phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
+        phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
+        phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
+        phase<3, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
     }
     const int rem = nphase - s;
-    if (rem > 0) phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
-    if (rem > 1) phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
-    if (rem > 2) phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl);
+    if (rem > 0) phase<0, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
+    if (rem > 1) phase<1, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
+    if (rem > 2) phase<2, IMPL>(lds, acc, c, ra, rw, soA, soW, p.t, tl, rcst);
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -466,9 +491,19 @@ extern "C" int ver_gemm_nn_splitk(const void* a, long lda, const void* w, long l
     return ver_check_launch("ver_gemm_nn");
 }
 
+extern "C" int ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
+                                    const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos,
+                                    const float* bias, void* c, long ldc, int N, void* stream);
+
 extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
                                 const void* w, long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N,
                                 void* stream) {
+    return ver_gemm_nn_segments(lattice, layout, B, H, W, C, taps, ntaps, nullptr, 0, 0, w, ldw, rowpos, bias, c, ldc, N, stream);
+}
+
+extern "C" int ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
+                                    const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos,
+                                    const float* bias, void* c, long ldc, int N, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VER_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && ntaps > 0, VER_EINVAL, "ver_gemm_nn_taps: bad sizes");
     VER_REQUIRE(layout == 0 || layout == 2 || layout == 3, VER_EINVAL, "ver_gemm_nn_taps: layout %d (0 plain, 2 z-split, 3 planar z-split)", layout);
@@ -478,7 +513,15 @@ extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, i
     VER_REQUIRE(ntaps <= 64, VER_EUNSUPPORTED, "ver_gemm_nn_taps: %d taps (at most 64)", ntaps);
     VER_REQUIRE(C % 32 == 0 && C >= 64, VER_EUNSUPPORTED, "ver_gemm_nn_taps: C = %d must be a multiple of 32 (>= 64)", C);
     const long M = (long)B * 2 * H * W, lbytes = (long)B * 4 * H * W * C * 2;
-    const long K = (long)ntaps * C;
+    VER_REQUIRE(cst == nullptr || (ncst > 0 && ncst <= 64 && cw >= 32 && cw % 32 == 0 && ((uintptr_t)cst & 15) == 0), VER_EINVAL,
+                "ver_gemm_nn_segments: the constant-pattern table needs 1..64 blocks of a width that is a multiple of 32");
+    long K = 0;
+    for (int i = 0; i < ntaps; ++i) {
+        const bool is_cst = taps[3 * i] < 0;                 // (-1 - block, 0, 0): a constant-pattern segment
+        VER_REQUIRE(!is_cst || (cst && -1 - taps[3 * i] < ncst), VER_EINVAL, "ver_gemm_nn_segments: segment %d names pattern block %d of %d",
+                    i, -1 - taps[3 * i], cst ? ncst : 0);
+        K += is_cst ? cw : C;
+    }
     VER_REQUIRE(lbytes < 0x7FFFFFFFL, VER_EUNSUPPORTED, "ver_gemm_nn_taps: the source lattice (%ld bytes) exceeds the 2-GiB range of the tap offsets", lbytes);
     VER_REQUIRE(ldw >= N && ldc >= N && ldw % 8 == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)lattice & 15) == 0, VER_EUNSUPPORTED,
                 "ver_gemm_nn_taps: w must be 16-byte aligned with a row pitch that is a multiple of 8 elements");
@@ -506,11 +549,18 @@ extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, i
     p.t.lattice_bytes = lbytes;
     p.t.B = B, p.t.H = H, p.t.W = W, p.t.C = C, p.t.ntaps = ntaps, p.t.P = 2 * H * W;
     p.t.rowpos = rowpos;
+    p.t.cst = (const __bf16*)cst;
+    p.t.cst_bytes = cst ? (long)2 * H * W * ncst * cw * 2 : 0;
+    p.t.CW = cw, p.t.ncst = ncst;
     for (int i = 0; i < ntaps; ++i) {
         const int dz = taps[3 * i], dy = taps[3 * i + 1], dx = taps[3 * i + 2];
+        if (dz < 0) {
+            p.t.kind[i] = 1, p.t.dz[i] = (signed char)(-1 - dz), p.t.dy[i] = p.t.dx[i] = 0;
+            continue;
+        }
         VER_REQUIRE((dz == 0 || dz == 2) && dy >= -64 && dy <= 64 && dx >= -64 && dx <= 64, VER_EINVAL,
                     "ver_gemm_nn_taps: tap %d = (%d, %d, %d): dz must be 0 or 2", i, dz, dy, dx);
-        p.t.dz[i] = (signed char)dz, p.t.dy[i] = (signed char)dy, p.t.dx[i] = (signed char)dx;
+        p.t.kind[i] = 0, p.t.dz[i] = (signed char)dz, p.t.dy[i] = (signed char)dy, p.t.dx[i] = (signed char)dx;
     }
     hipError_t e = hipSuccess;
 #define VER_GEMM_TAPS(L)                                                                                                  \

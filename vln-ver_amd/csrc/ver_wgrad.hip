@@ -59,7 +59,57 @@ struct WgradArgs {
     void* out;          // S == 1: the tile goes straight to the result (row pitch ldo, bf16 or fp32), no workspace pass
     long ldo;
     int out_bf16;
+    // implicit A (ver_wgrad_tn_segments): the tap matrix of a Z = 4 lattice layer, never materialised (ver_gemm.hip: TapArgs)
+    const __bf16* lattice;
+    long lattice_bytes;
+    const __bf16* cst;  // constant-pattern table [P][ncst][CW] bf16
+    long cst_bytes;
+    int B, H, W, C, P, CW, ncst, nseg;
+    unsigned mhw, mw;   // ceil(2^32 / (H W)), ceil(2^32 / W): exact quotients of positions < 2^16 by one mulhi
+    int seg_start[65];  // first column of segment i (seg_start[nseg] = Ka); boundaries are multiples of 64
+    signed char kind[64], dz[64], dy[64], dx[64];
 };
+
+constexpr int kOutsideW = (int)0x80000000;
+template <int L>
+__device__ __forceinline__ int wcell_off(const WgradArgs& t, int b, int zl, int y, int x, int dz) {
+    if ((unsigned)y >= (unsigned)t.H || (unsigned)x >= (unsigned)t.W) return kOutsideW;
+    const int j = dz >> 1;
+    int v;
+    if (L == 0)
+        v = ((b * 4 + zl + dz) * t.H + y) * t.W + x;
+    else if (L == 2)
+        v = ((((b * 2 + zl) * t.H + y) * t.W + x) << 1) + j;
+    else
+        v = (((((((y & 1) << 1 | (x & 1)) * t.B + b) * 2 + zl) * (t.H >> 1) + (y >> 1)) * (t.W >> 1) + (x >> 1)) << 1) + j;
+    return v * t.C * 2;
+}
+
+struct WTapLane {       // implicit A: the wave's segment (its 64 columns lie in ONE) and the lane's running row of the DMA stream
+    int is_cst, dz, dy, dx;     // wave-uniform
+    int choff;                  // byte offset inside the segment's vector: first column of the wave's block + this lane's chunk
+    int b, pos;                 // viewpoint and position r % P of the NEXT row this lane requests (advances by 16 per slab)
+    long rows_left;             // rows of the operand from that row on (<= 0: past M)
+};
+
+template <int L>
+__device__ __forceinline__ int wtap_voffset(const WgradArgs& t, const WTapLane& tl) {
+    if (tl.rows_left <= 0 || tl.is_cst < 0) return kOutsideW;
+    if (tl.is_cst) return (tl.pos * t.ncst + tl.dz) * t.CW * 2 + tl.choff;
+    const int zl = (int)__umulhi((unsigned)tl.pos, t.mhw);
+    const int rem = tl.pos - zl * t.H * t.W;
+    const int y = (int)__umulhi((unsigned)rem, t.mw);
+    const int x = rem - y * t.W;
+    const int o = wcell_off<L>(t, tl.b, zl, y + tl.dy, x + tl.dx, tl.dz);
+    return o == kOutsideW ? kOutsideW : o + tl.choff;
+}
+
+template <int L>
+__device__ __forceinline__ void wtap_advance(const WgradArgs& t, WTapLane& tl) {
+    tl.pos += kSlabRows;
+    if (tl.pos >= t.P) tl.pos -= t.P, tl.b += 1;
+    tl.rows_left -= kSlabRows;
+}
 
 struct WgradLane {          // per-lane constants of the main loop
     int offA0, offA1, offB0, offB1;     // LDS byte addresses of the fragment reads in ring slot 0
@@ -90,16 +140,21 @@ __device__ __forceinline__ void read_slab(const WgradLane& c, i32x2 (&al)[4], i3
 }
 
 // One phase = KP slabs (ring slots PS*KP ..): fragments -> registers, LDS-DMA of the slabs PF ahead, 8 KP MFMAs.
-template <int PS, int KP, int PF>
+template <int PS, int KP, int PF, int IMPL>
 __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const WgradLane& c, __amdgpu_buffer_rsrc_t ra,
-                                      __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG) {
+                                      __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG, const WgradArgs& t, WTapLane& tl) {
     i32x2 al[KP][4], ah[KP][4], bl[KP][2], bh[KP][2];
     read_slab<PS * KP>(c, al[0], ah[0], bl[0], bh[0]);
     if constexpr (KP == 2) read_slab<PS * KP + 1>(c, al[KP - 1], ah[KP - 1], bl[KP - 1], bh[KP - 1]);
 #pragma unroll
     for (int u = 0; u < KP; ++u) {
         const int ds = (PS * KP + u + PF) % kRing;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        if constexpr (IMPL < 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, wtap_voffset<IMPL>(t, tl), 0, 0, 0);
+            wtap_advance<IMPL>(t, tl);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + ds * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
         soA += (unsigned)c.stepA;
         soG += (unsigned)c.stepG;
@@ -143,19 +198,20 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Wgra
     __builtin_amdgcn_s_barrier();
 }
 
-template <int PS, int KP, int PF>
+template <int PS, int KP, int PF, int IMPL>
 __device__ __forceinline__ void phases_from(int left, char* lds, f32x16 (&acc)[4][2], const WgradLane& c,
-                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG) {
+                                            __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG,
+                                            const WgradArgs& t, WTapLane& tl) {
     if constexpr (PS < kRing / KP) {
         if (left > PS * KP) {
-            phase<PS, KP, PF>(lds, acc, c, ra, rg, soA, soG);
-            phases_from<PS + 1, KP, PF>(left, lds, acc, c, ra, rg, soA, soG);
+            phase<PS, KP, PF, IMPL>(lds, acc, c, ra, rg, soA, soG, t, tl);
+            phases_from<PS + 1, KP, PF, IMPL>(left, lds, acc, c, ra, rg, soA, soG, t, tl);
         }
     }
 }
 
-template <int KP, int PF>
-__global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
+template <int KP, int PF, int IMPL>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p) {
     static_assert(PF >= KP && PF + (KP == 1 ? 2 : 4) <= kRing, "prefetch distance against the ring (WAR on the slot)");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -180,16 +236,39 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     const int nslab = (int)((rows + kSlabRows * KP - 1) / (kSlabRows * KP)) * KP;
 
     // LDS-DMA: wave w moves piece (row group w >> 2, 64-column block w & 3) of the A part and of the G part
-    const __bf16* ab = p.A + row0 * p.lda + (long)mt * kTile;
+    const __bf16* ab = IMPL < 0 ? p.A + row0 * p.lda + (long)mt * kTile : nullptr;
     const __bf16* gb = p.G + row0 * p.ldg + (long)nt * kTile;
     // buffer ranges end with the last valid element of the operand (column Ka / N of row M - 1): what lies behind reads
     // as zero, what lies beside a row (other columns of a wider matrix) only reaches outputs that are never stored
     const long abytes = ((p.M - row0 - 1) * p.lda + p.Ka - (long)mt * kTile) * 2;
     const long gbytes = ((p.M - row0 - 1) * p.ldg + p.N - (long)nt * kTile) * 2;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, (int)max(0L, min(gbytes, 0xFFFFFFFFL)), 0x00020000);
     WgradLane c;
     const int prow = lane >> 3, pch = (lane & 7) ^ (((prow >> 1) & 1) << 2);
+    // implicit A: the segment of this wave's 64 columns (boundaries are multiples of 64) -> its source (lattice or pattern
+    // table) and tap; the lane's first row
+    WTapLane tl = {};
+    bool a_cst = false;
+    if constexpr (IMPL >= 0) {
+        const int col0 = mt * kTile + 64 * (wave & 3);
+        int seg = -1;
+        for (int i = 0; i < p.nseg; ++i)
+            if (col0 >= p.seg_start[i] && col0 < p.seg_start[i + 1]) seg = i;
+        tl.is_cst = seg < 0 ? -1 : (int)p.kind[seg];            // (columns past Ka: nothing to read)
+        if (seg >= 0) {
+            tl.dz = p.dz[seg], tl.dy = p.dy[seg], tl.dx = p.dx[seg];
+            tl.choff = (col0 - p.seg_start[seg]) * 2 + pch * 16;
+        }
+        a_cst = tl.is_cst > 0;
+        const long r = row0 + 8 * (wave >> 2) + prow;
+        tl.b = (int)(r / p.P);
+        tl.pos = (int)(r - (long)tl.b * p.P);
+        tl.rows_left = min(p.M, row0 + p.Mc) - r;               // (a chunk ends where the next one starts)
+    }
+    const __amdgpu_buffer_rsrc_t ra =
+        IMPL < 0 ? __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000)
+                 : __builtin_amdgcn_make_buffer_rsrc((void*)(a_cst ? p.cst : p.lattice), 0,
+                                                     (int)max(0L, min(a_cst ? p.cst_bytes : p.lattice_bytes, 0x7FFFFFFFL)), 0x00020000);
     c.voA = (int)(((8 * (wave >> 2) + prow) * p.lda + 64 * (wave & 3)) * 2) + pch * 16;
     c.voG = (int)(((8 * (wave >> 2) + prow) * p.ldg + 64 * (wave & 3)) * 2) + pch * 16;
     c.stepA = (int)(kSlabRows * p.lda * 2);
@@ -221,7 +300,12 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     // prologue: slabs 0 .. PF-1 in flight, the first phase's slabs landed
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        if constexpr (IMPL < 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, wtap_voffset<IMPL>(p, tl), 0, 0, 0);
+            wtap_advance<IMPL>(p, tl);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
         soA += (unsigned)c.stepA;
         soG += (unsigned)c.stepG;
@@ -231,8 +315,8 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave group runs half a phase behind
 
     int s = 0;
-    for (; s + kRing <= nslab; s += kRing) phases_from<0, KP, PF>(kRing, lds, acc, c, ra, rg, soA, soG);
-    phases_from<0, KP, PF>(nslab - s, lds, acc, c, ra, rg, soA, soG);     // < 8 slabs left: wave-uniform exits
+    for (; s + kRing <= nslab; s += kRing) phases_from<0, KP, PF, IMPL>(kRing, lds, acc, c, ra, rg, soA, soG, p, tl);
+    phases_from<0, KP, PF, IMPL>(nslab - s, lds, acc, c, ra, rg, soA, soG, p, tl);     // < 8 slabs left: wave-uniform exits
     if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two groups match again
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the run-ahead pieces nobody reads
 
@@ -271,6 +355,17 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
                 if (i < p.Ka && j < p.N) out[(long)i * p.N + j] = acc[it][jt][r];
             }
         }
+}
+
+template <int KP, int PF>
+__global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
+    wgrad_body<KP, PF, -1>(p);
+}
+
+// the same kernel with the implicit tap matrix of a lattice in layout L as A (ver_wgrad_tn_segments)
+template <int L>
+__global__ __launch_bounds__(512) void k_wgrad_tn_seg(WgradArgs p) {
+    wgrad_body<1, 3, L>(p);
 }
 
 // out[i][j] (bf16 or fp32, row pitch ldo) = sum over the S partial products, fp32; 4 elements per thread
@@ -351,6 +446,11 @@ void launch_tn(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
 }
+template <int L>
+void launch_tn_segments(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
+    e = hipFuncSetAttribute((const void*)k_wgrad_tn_seg<L>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_wgrad_tn_seg<L>, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
+}
 }  // namespace
 
 extern "C" int ver_wgrad_tn_splits(long M, int Ka, int N) {
@@ -387,7 +487,7 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
                 "ver_wgrad_tn: a row chunk exceeds the 4-GiB range of a buffer offset (more splits)");
     VER_REQUIRE(workspace_bytes >= (long)S * Ka * N * (long)sizeof(float), VER_EINVAL, "ver_wgrad_tn: workspace of %ld bytes, %ld needed",
                 workspace_bytes, (long)S * Ka * N * (long)sizeof(float));
-    WgradArgs p;
+    WgradArgs p = {};
     p.A = (const __bf16*)a;
     p.G = (const __bf16*)g;
     p.ws = (float*)workspace;
@@ -428,4 +528,99 @@ extern "C" int ver_wgrad_tn(const void* a, long lda, const void* g, long ldg, lo
     else
         hipLaunchKernelGGL(k_wgrad_reduce<__bf16>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, (__bf16*)out, ldo, S, Ka, N);
     return ver_check_launch("ver_wgrad_tn");
+}
+
+extern "C" int ver_wgrad_tn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int nseg,
+                                     const void* cst, int ncst, int cw, const void* g, long ldg, int N, void* out, long ldo,
+                                     int out_dtype, int splits, void* workspace, long workspace_bytes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    VER_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && nseg > 0, VER_EINVAL, "ver_wgrad_tn_segments: bad sizes");
+    VER_REQUIRE(layout == 0 || layout == 2 || layout == 3, VER_EINVAL, "ver_wgrad_tn_segments: layout %d (0 plain, 2 z-split, 3 planar z-split)", layout);
+    VER_REQUIRE(layout != 3 || (H % 2 == 0 && W % 2 == 0), VER_EINVAL, "ver_wgrad_tn_segments: planar needs even H, W");
+    VER_REQUIRE(out && workspace && ((lattice && g && taps) || B == 0), VER_EINVAL, "ver_wgrad_tn_segments: null pointer argument");
+    VER_REQUIRE(out_dtype == VER_F32 || out_dtype == VER_BF16, VER_EINVAL, "ver_wgrad_tn_segments: out_dtype %d", out_dtype);
+    VER_REQUIRE(nseg <= 64, VER_EUNSUPPORTED, "ver_wgrad_tn_segments: %d segments (at most 64)", nseg);
+    VER_REQUIRE(C % 64 == 0 && (cst == nullptr || (ncst > 0 && ncst <= 64 && cw > 0 && cw % 64 == 0 && ((uintptr_t)cst & 15) == 0)),
+                VER_EUNSUPPORTED, "ver_wgrad_tn_segments: segment widths (C = %d, pattern blocks of %d) must be multiples of 64", C, cw);
+    const long M = (long)B * 2 * H * W, lbytes = (long)B * 4 * H * W * C * 2;
+    const int P = 2 * H * W;
+    VER_REQUIRE(P >= kSlabRows && P < 65536 && lbytes < 0x7FFFFFFFL, VER_EUNSUPPORTED,
+                "ver_wgrad_tn_segments: %d rows per viewpoint / a source lattice of %ld bytes (16 <= rows < 65536, below 2 GiB)", P, lbytes);
+    VER_REQUIRE(ldg >= N && ldo >= N && ldg % 8 == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)lattice & 15) == 0, VER_EUNSUPPORTED,
+                "ver_wgrad_tn_segments: g must be 16-byte aligned with a row pitch that is a multiple of 8 elements");
+    VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
+                "ver_wgrad_tn_segments: N and the output pitch must be multiples of 4");
+    WgradArgs p = {};
+    long Ka = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const int dz = taps[3 * i], dy = taps[3 * i + 1], dx = taps[3 * i + 2];
+        p.seg_start[i] = (int)Ka;
+        if (dz < 0) {
+            VER_REQUIRE(cst && -1 - dz < ncst, VER_EINVAL, "ver_wgrad_tn_segments: segment %d names pattern block %d of %d", i, -1 - dz, cst ? ncst : 0);
+            p.kind[i] = 1, p.dz[i] = (signed char)(-1 - dz);
+            Ka += cw;
+        } else {
+            VER_REQUIRE((dz == 0 || dz == 2) && dy >= -64 && dy <= 64 && dx >= -64 && dx <= 64, VER_EINVAL,
+                        "ver_wgrad_tn_segments: tap %d = (%d, %d, %d): dz must be 0 or 2", i, dz, dy, dx);
+            p.kind[i] = 0, p.dz[i] = (signed char)dz, p.dy[i] = (signed char)dy, p.dx[i] = (signed char)dx;
+            Ka += C;
+        }
+    }
+    p.seg_start[nseg] = (int)Ka;
+    VER_REQUIRE(Ka < 0x7FFFFFFFL, VER_EUNSUPPORTED, "ver_wgrad_tn_segments: %ld columns", Ka);
+    const int S = splits > 0 ? splits : pick_splits(M, (int)Ka, N, ldg);
+    VER_REQUIRE(S <= 65536, VER_EINVAL, "ver_wgrad_tn_segments: %d row chunks", S);
+    const long Mc = ((M + S - 1) / S + 2 * kSlabRows - 1) / (2 * kSlabRows) * (2 * kSlabRows);
+    VER_REQUIRE((Mc + 16 * kRing) * ldg * 2 < 0xFFFFFFFFL, VER_EUNSUPPORTED,
+                "ver_wgrad_tn_segments: a row chunk exceeds the 4-GiB range of a buffer offset (more splits)");
+    VER_REQUIRE(workspace_bytes >= (long)S * Ka * N * (long)sizeof(float), VER_EINVAL, "ver_wgrad_tn_segments: workspace of %ld bytes, %ld needed",
+                workspace_bytes, (long)S * Ka * N * (long)sizeof(float));
+    p.A = nullptr;
+    p.G = (const __bf16*)g;
+    p.ws = (float*)workspace;
+    p.lda = 0;
+    p.ldg = ldg;
+    p.M = M;
+    p.Mc = Mc;
+    p.S = S;
+    p.Ka = (int)Ka;
+    p.N = N;
+    p.tiles_n = (N + kTile - 1) / kTile;
+    p.T = (int)((Ka + kTile - 1) / kTile) * p.tiles_n;
+    const bool direct = S == 1 && M > 0;
+    p.out = direct ? out : nullptr;
+    p.ldo = ldo;
+    p.out_bf16 = out_dtype == VER_BF16;
+    p.lattice = (const __bf16*)lattice;
+    p.lattice_bytes = lbytes;
+    p.cst = (const __bf16*)cst;
+    p.cst_bytes = cst ? (long)P * ncst * cw * 2 : 0;
+    p.B = B, p.H = H, p.W = W, p.C = C, p.P = P, p.CW = cw, p.ncst = ncst, p.nseg = nseg;
+    p.mhw = (unsigned)((0x100000000UL + (unsigned long)(H * W) - 1) / (unsigned long)(H * W));
+    p.mw = (unsigned)((0x100000000UL + (unsigned long)W - 1) / (unsigned long)W);
+    hipError_t e = hipSuccess;
+    if (M > 0) {
+        if (layout == 0) launch_tn_segments<0>(p, p.T * S, st, e);
+        else if (layout == 2) launch_tn_segments<2>(p, p.T * S, st, e);
+        else launch_tn_segments<3>(p, p.T * S, st, e);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn_segments: LDS attribute: %s", hipGetErrorString(e));
+    } else {
+        e = hipMemsetAsync(workspace, 0, (size_t)S * Ka * N * sizeof(float), st);
+        if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_wgrad_tn_segments: memset: %s", hipGetErrorString(e));
+    }
+    if (direct) return ver_check_launch("ver_wgrad_tn_segments");
+    const long n4 = Ka * N / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (out_dtype == VER_F32)
+        hipLaunchKernelGGL(k_wgrad_reduce<float>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, (float*)out, ldo, S, (int)Ka, N);
+    else
+        hipLaunchKernelGGL(k_wgrad_reduce<__bf16>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)workspace, (__bf16*)out, ldo, S, (int)Ka, N);
+    return ver_check_launch("ver_wgrad_tn_segments");
+}
+
+extern "C" int ver_wgrad_tn_segments_splits(int B, int H, int W, long Ka, int N, long ldg) {
+    const long M = (long)B * 2 * H * W;
+    if (M <= 0 || Ka <= 0 || N <= 0) return 1;
+    return pick_splits(M, (int)Ka, N, ldg);
 }

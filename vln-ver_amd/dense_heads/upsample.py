@@ -187,7 +187,10 @@ def _layer0(e, k, bias):
 # Every class GEMM writes its own contiguous output plane: the result is PLANAR [4,B,Z,H,W,Co]
 # (plane 2pm+pn = positions (2y+pm, 2x+pn) of the (2H, 2W) lattice) and is consumed as such by the
 # next layer's gather kernel and by occ_proj -- the lattice is never interleaved.
-_PW = 80                                             # width of a constant block
+# width of a constant block: 75 pattern columns + the ones column, padded to 96 so that the lo | hi pair of a Z = 4 layer is 192
+# = 3 x 64 columns and every segment of the K axis starts on a multiple of 64 -- what the implicit operand loaders want
+# (ver_gemm_nn_segments: whole 32-column phases; ver_wgrad_tn_segments: a wave's 64-column piece inside ONE segment)
+_PW = 96
 _CLASSES = _cpu_algebra.CLASSES
 
 
@@ -594,6 +597,19 @@ def _class_rows_z4(ci):
         out[cls] = (roff, segs)
         roff += r
     return out
+
+
+def _class_segments_z4(cls, ci):
+    """The K axis of class ``cls`` as the segments ``hipops.gemm_nn_taps`` takes, in column order of the tap matrix: a tap
+    (dz, dy, dx) per block, ('c', p) for the constant-pattern block of class index p."""
+    segs = []
+    for kind, val in _class_layout_z4()[cls]:
+        if kind == 'b':
+            dxi, dyi, j = _ORDER4[val]
+            segs.append((2 * j, dyi - 1, dxi - 1))
+        else:
+            segs.append(('c', _CLASSES.index(val)))
+    return segs
 
 
 _AUG_ROWS = {}

@@ -25,8 +25,8 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_convt_weight_forward', 'ver_convt_weight_backward', 'ver_convt_weight_backward_blocks', 'ver_convt_weight_forward_blocks', 'ver_blocks_vec_forward', 'ver_blocks_vec_backward', 'ver_lattice_transpose', 'ver_lattice_rows', 'ver_run_gather',
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
-           'ver_wgrad_tn_splits', 'ver_wgrad_tn_splits_ld', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_gemm_nn_taps', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
+           'ver_wgrad_tn_splits', 'ver_wgrad_tn_splits_ld', 'ver_wgrad_tn_segments', 'ver_wgrad_tn_segments_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_gemm_nn_taps', 'ver_gemm_nn_segments', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
 
 _lib = None
 
@@ -1290,18 +1290,28 @@ def gemm_nn_taps_supported(lattice, layout, w, c):
             and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0)
 
 
-def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, out=None):
-    """ver_gemm_nn_taps: ``tap_matrix(lattice) @ w (+ rowpos by row position) (+ bias)`` without the tap matrix: lattice bf16 in
-    layout 0 / 2 / 3 (see ``lattice_gather``), rows = the cells (b, zl, y, x) of the combined (H, W) lattice, taps a list of
-    (dz in {0, 2}, dy, dx), w bf16 [len(taps) * C, N] -> bf16 [B * 2 * H * W, N]."""
+def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, out=None, const_rows=None):
+    """ver_gemm_nn_segments: ``tap_matrix(lattice) @ w (+ rowpos by row position) (+ bias)`` without the tap matrix: lattice
+    bf16 in layout 0 / 2 / 3 (see ``lattice_gather``), rows = the cells (b, zl, y, x) of the combined (H, W) lattice.  ``taps``:
+    the segments of the K axis in order -- (dz in {0, 2}, dy, dx) = the C channels of that neighbouring cell, or ('c', block) =
+    the columns of constant-pattern block ``block`` of ``const_rows`` bf16 [2 H W, blocks, width] (what ``lattice_gather``
+    copies into every viewpoint's rows).  w bf16 [sum of the segment widths, N] -> bf16 [B * 2 * H * W, N]."""
     lat, w = _gpu(lattice, 'lattice'), _gpu(w, 'w')
     H, W = combined_hw
     B, _, C = _lattice_dims(lat, int(layout))
     if not gemm_nn_taps_supported(lat, int(layout), w, C):
         raise RuntimeError('gemm_nn_taps: unsupported operands %s layout %d / %s %s' % (tuple(lat.shape), layout, tuple(w.shape), w.stride()))
     m, n = B * 2 * H * W, w.shape[1]
-    if w.shape[0] != len(taps) * C:
-        raise ValueError('gemm_nn_taps: w has %d rows, %d taps x %d channels expected' % (w.shape[0], len(taps), C))
+    ncst = cw = 0
+    if const_rows is not None:
+        const_rows = _gpu(const_rows, 'const_rows')
+        if not (const_rows.is_contiguous() and const_rows.dtype == torch.bfloat16 and const_rows.dim() == 3 and const_rows.shape[0] == 2 * H * W):
+            raise ValueError('gemm_nn_taps: const_rows must be a contiguous bf16 [2 H W, blocks, width] table')
+        ncst, cw = int(const_rows.shape[1]), int(const_rows.shape[2])
+    taps = [((-1 - int(t[1]), 0, 0) if t[0] == 'c' else t) for t in taps]
+    kdim = sum(cw if t[0] < 0 else C for t in taps)
+    if w.shape[0] != kdim:
+        raise ValueError('gemm_nn_taps: w has %d rows, the segments span %d columns' % (w.shape[0], kdim))
     if out is None:
         out = torch.empty(m, n, dtype=torch.bfloat16, device=lat.device)
     if out.shape != (m, n) or out.dtype != torch.bfloat16 or out.stride(1) != 1 or not out.is_cuda:
@@ -1314,8 +1324,57 @@ def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, 
         bias = _gpu(bias, 'bias').float().contiguous()
     flat = [int(v) for t in taps for v in t]
     arr = (ctypes.c_int * len(flat))(*flat)
-    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_taps(
-        _p(lat), int(layout), int(B), int(H), int(W), int(C), arr, len(taps), _p(w), ctypes.c_long(w.stride(0)),
-        _p(rowpos) if rowpos is not None else None, _p(bias) if bias is not None else None, _p(out), ctypes.c_long(out.stride(0)),
+    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_segments(
+        _p(lat), int(layout), int(B), int(H), int(W), int(C), arr, len(taps), _p(const_rows) if const_rows is not None else None,
+        ncst, cw, _p(w), ctypes.c_long(w.stride(0)), _p(rowpos) if rowpos is not None else None, _p(bias) if bias is not None else None, _p(out), ctypes.c_long(out.stride(0)),
         int(n), _stream()), meta=dict(flops=2.0 * m * w.shape[0] * n))
+    return out
+
+
+def _segment_args(lat, layout, combined_hw, taps, const_rows, name):
+    H, W = combined_hw
+    B, _, C = _lattice_dims(lat, int(layout))
+    ncst = cw = 0
+    if const_rows is not None:
+        const_rows = _gpu(const_rows, 'const_rows')
+        if not (const_rows.is_contiguous() and const_rows.dtype == torch.bfloat16 and const_rows.dim() == 3 and const_rows.shape[0] == 2 * H * W):
+            raise ValueError('%s: const_rows must be a contiguous bf16 [2 H W, blocks, width] table' % name)
+        ncst, cw = int(const_rows.shape[1]), int(const_rows.shape[2])
+    taps = [((-1 - int(t[1]), 0, 0) if t[0] == 'c' else t) for t in taps]
+    kdim = sum(cw if t[0] < 0 else C for t in taps)
+    flat = [int(v) for t in taps for v in t]
+    return B, H, W, C, const_rows, ncst, cw, kdim, (ctypes.c_int * len(flat))(*flat), len(taps)
+
+
+def wgrad_tn_segments_supported(lattice, layout, c, const_width, g):
+    """What ``wgrad_tn_segments`` takes (segment widths multiples of 64, the lattice below 2 GiB, 2 H W < 65 536 checked by
+    the library)."""
+    return (lattice.is_cuda and lattice.dtype == torch.bfloat16 and lattice.is_contiguous() and layout in (PLAIN, ZSPLIT, PLANAR_ZSPLIT)
+            and lattice.numel() * 2 < 2 ** 31 - 1 and c % 64 == 0 and const_width % 64 == 0 and g.is_cuda and g.dtype == torch.bfloat16
+            and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) % 8 == 0 and g.data_ptr() % 16 == 0 and g.shape[1] % 4 == 0)
+
+
+def wgrad_tn_segments(lattice, layout, combined_hw, taps, g, out_dtype=None, out=None, const_rows=None, splits=0):
+    """ver_wgrad_tn_segments: ``tap_matrix(lattice).t() @ g`` without the tap matrix (operands as ``gemm_nn_taps``): the weight
+    gradient of a lattice layer's class GEMM, [sum of the segment widths, N] in ``out_dtype`` (``out``: a matrix to write into)."""
+    lat, g = _gpu(lattice, 'lattice'), _gpu(g, 'g')
+    B, H, W, C, const_rows, ncst, cw, ka, arr, nseg = _segment_args(lat, layout, combined_hw, taps, const_rows, 'wgrad_tn_segments')
+    if not wgrad_tn_segments_supported(lat, int(layout), C, cw, g):
+        raise RuntimeError('wgrad_tn_segments: unsupported operands %s layout %d / %s %s' % (tuple(lat.shape), layout, tuple(g.shape), g.stride()))
+    if g.shape[0] != B * 2 * H * W:
+        raise ValueError('wgrad_tn_segments: g has %d rows, %d cells' % (g.shape[0], B * 2 * H * W))
+    n = g.shape[1]
+    out_dtype = out_dtype or (out.dtype if out is not None else lat.dtype)
+    if out is None:
+        out = torch.empty(ka, n, dtype=out_dtype, device=lat.device)
+    elif not (out.is_cuda and out.shape == (ka, n) and out.dtype == out_dtype and out.stride(1) == 1):
+        raise RuntimeError('wgrad_tn_segments: out must be a [Ka, N] GPU matrix of out_dtype with unit column stride')
+    L = lib()
+    if splits <= 0:
+        splits = L.ver_wgrad_tn_segments_splits(int(B), int(H), int(W), ctypes.c_long(ka), int(n), ctypes.c_long(g.stride(0)))
+    ws = torch.empty(splits * ka * n, dtype=torch.float32, device=lat.device)
+    _launch('ver_wgrad_tn', lambda: L.ver_wgrad_tn_segments(
+        _p(lat), int(layout), int(B), int(H), int(W), int(C), arr, nseg, _p(const_rows) if const_rows is not None else None, ncst, cw,
+        _p(g), ctypes.c_long(g.stride(0)), int(n), _p(out), ctypes.c_long(out.stride(0)), 1 if out_dtype == torch.bfloat16 else 0,
+        int(splits), _p(ws), ctypes.c_long(ws.numel() * 4), _stream()), meta=dict(flops=2.0 * g.shape[0] * ka * n))
     return out

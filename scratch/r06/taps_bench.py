@@ -60,3 +60,37 @@ out = torch.empty(m, N, dtype=torch.bfloat16, device=DEV)
 t_e = timeit(lambda: hip.gemm_nn(a, w, bias, out=out, splits=1))
 t_i = timeit(lambda: hip.gemm_nn_taps(e, 0, (hc, hc), taps, w, bias=bias, out=out))
 print('layer 1: gather %.3f ms + explicit GEMM %.3f ms = %.3f ms;  implicit GEMM %.3f ms (%.0f TFLOP/s)' % (t_g, t_e, t_g + t_e, t_i, 2.0 * m * 50 * C * N / t_i / 1e9))
+
+# ---- weight gradient: ver_wgrad_tn on the explicit tap matrix against ver_wgrad_tn_segments
+print('--- weight gradient')
+for name, layout, hc in (('layer 2', 2, 15), ('layer 3', 3, 30)):
+    m = B * 2 * hc * hc
+    shape = (4, B, 2, hc // 2, hc // 2, 2, C) if layout == 3 else (B, 2, hc, hc, 2, C)
+    e = torch.randn(shape, device=DEV).bfloat16()
+    a = torch.empty(m, kt, dtype=torch.bfloat16, device=DEV)
+    ups._gather_z4(e, layout, a, taps18, offs18, C, hc, hc, with_const=True)
+    table, _ = ups._const_rows_z4(C, hc, hc, torch.device(DEV), torch.bfloat16)
+    g = torch.randn(m, N, device=DEV).bfloat16()
+    tot_e = tot_i = 0.0
+    for cls in ups._CLASSES:
+        c0, c1 = plan[cls][:2]
+        segs = ups._class_segments_z4(cls, C)
+        out = torch.empty(c1 - c0, N, dtype=torch.bfloat16, device=DEV)
+        t_e = timeit(lambda: hip.wgrad_tn(a[:, c0:c1], g, out=out))
+        t_i = timeit(lambda: hip.wgrad_tn_segments(e, layout, (hc, hc), segs, g, out=out, const_rows=table))
+        fl = 2.0 * m * (c1 - c0) * N
+        print('%s class %s: explicit %.3f ms (%.0f TFLOP/s)   implicit %.3f ms (%.0f TFLOP/s)' % (name, cls, t_e, fl / t_e / 1e9, t_i, fl / t_i / 1e9), flush=True)
+        tot_e += t_e; tot_i += t_i
+    print('%s: explicit %.3f ms, implicit %.3f ms' % (name, tot_e, tot_i), flush=True)
+    del e, a, g
+hc = 15
+m = B * 2 * hc * hc
+taps, offs, lo, hi = ups._layer0_z4_plan(C, torch.device(DEV))
+e = torch.randn(B, 4, hc, hc, C, device=DEV).bfloat16()
+a = torch.empty(m, 50 * C, dtype=torch.bfloat16, device=DEV)
+ups._gather_z4(e, 0, a, taps, offs, C, hc, hc)
+g = torch.randn(m, N, device=DEV).bfloat16()
+out = torch.empty(50 * C, N, dtype=torch.bfloat16, device=DEV)
+t_e = timeit(lambda: hip.wgrad_tn(a, g, out=out))
+t_i = timeit(lambda: hip.wgrad_tn_segments(e, 0, (hc, hc), taps, g, out=out))
+print('layer 1: explicit %.3f ms (%.0f TFLOP/s), implicit %.3f ms (%.0f TFLOP/s)' % (t_e, 2.0 * m * 50 * C * N / t_e / 1e9, t_i, 2.0 * m * 50 * C * N / t_i / 1e9))

@@ -103,11 +103,11 @@ def _train_step(head, feats, w2p, org, gt):
 
 
 def test_training_step_at_192_viewpoints_equals_the_two_viewpoint_step(monkeypatch):
-    """The bench's step (bf16 autocast, fused MLP + focal loss, ``ver_gemm_nn`` / ``ver_wgrad_tn`` on 345 600-row operands,
+    """The bench's step (bf16 autocast, fused MLP + focal loss, ``ver_gemm_nn_segments`` / ``ver_wgrad_tn_segments`` on 345 600-row implicit operands,
     96.8 M-row MLP and loss launches) on 96 copies of two viewpoints and their labels: the loss is a mean over occupied
     voxels, so loss and EVERY parameter gradient must equal the two-viewpoint step's (which tests/test_head_gpu.py holds to
     the reference's gradient vectors) up to bf16 rounding of 96x larger sums -- and the same step with the library's GEMMs
-    in place of ``ver_gemm_nn`` (VER_OWN_GEMM=0) within rel. L2 5e-3 (two valid bf16 roundings of the lattices apart)."""
+    in place of the own kernels (VER_OWN_GEMM=0: explicit tap matrices, library forward) within rel. L2 5e-3 (two valid bf16 roundings of the lattices apart)."""
     ups = pkg('dense_heads.upsample')
     head = _head()
     lift = ('transformer.encoder.', 'transformer.level_embeds', 'transformer.cams_embeds', 'voxel_embedding.', 'up_sample.',
@@ -121,10 +121,14 @@ def test_training_step_at_192_viewpoints_equals_the_two_viewpoint_step(monkeypat
     gt = gt2.repeat(B_BENCH // 2, 1)
     calls = []
     hip = pkg('hipops')
-    real = hip.gemm_nn
-    monkeypatch.setattr(hip, 'gemm_nn', lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    real, real_w = hip.gemm_nn_taps, hip.wgrad_tn_segments
+    monkeypatch.setattr(hip, 'gemm_nn_taps', lambda *a, **k: (calls.append(('fwd', a[0].shape)), real(*a, **k))[1])
+    monkeypatch.setattr(hip, 'wgrad_tn_segments', lambda *a, **k: (calls.append(('wgrad', a[0].shape)), real_w(*a, **k))[1])
     loss, gb = _train_step(head, f, w, o, gt)
-    assert len(calls) >= 9 and max(s[0] for s in calls) == B_BENCH * 2 * 30 * 30, calls       # ver_gemm_nn did run, at M = 345 600
+    # the implicit-operand kernels did run: 1 + 4 + 4 forward products and as many weight gradients, layer 3's on the
+    # [4, 192, 2, 15, 15, 2, 768] lattice (345 600 rows)
+    assert sum(c[0] == 'fwd' for c in calls) == 9 and sum(c[0] == 'wgrad' for c in calls) == 9, calls
+    assert (4, B_BENCH, 2, 15, 15, 2, 768) in [tuple(c[1]) for c in calls]
     monkeypatch.setattr(ups, '_OWN_GEMM', False)
     n_before = len(calls)
     loss_lib, gl = _train_step(head, f, w, o, gt)
@@ -152,7 +156,7 @@ def test_training_step_at_192_viewpoints_equals_the_two_viewpoint_step(monkeypat
 
 
 # ------------------------------------------------------------------------------------------ kernels at the step's shapes
-M3, KT3, CO2 = B_BENCH * 2 * 30 * 30, 18 * 768 + 4 * 160, 1536          # layer 3: 345 600 rows, tap matrix pitch 14 464
+M3, KT3, CO2 = B_BENCH * 2 * 30 * 30, 18 * 768 + 4 * 192, 1536          # layer 3: 345 600 rows, tap matrix pitch 14 592
 
 
 def _randn_bf16(*shape, scale=1.0, seed=0):

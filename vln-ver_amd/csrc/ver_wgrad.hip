@@ -18,6 +18,7 @@
 //   * split over row chunks: block b runs on XCD b % 8 and XCD x works on chunks x, x + 8, ...: the rows of a chunk are
 //     fetched into ONE L2, where the ~32 tiles of the XCD that are in flight share them; fp32 partial tiles go to a
 //     workspace and k_wgrad_reduce adds them up in fp32 (no bf16 rounding of partial sums).
+#include <cstdlib>
 #include "ver_common.h"
 
 namespace {
@@ -65,7 +66,6 @@ struct WgradArgs {
     const __bf16* cst;  // constant-pattern table [P][ncst][CW] bf16
     long cst_bytes;
     int B, H, W, C, P, CW, ncst, nseg;
-    unsigned mhw, mw;   // ceil(2^32 / (H W)), ceil(2^32 / W): exact quotients of positions < 2^16 by one mulhi
     int seg_start[65];  // first column of segment i (seg_start[nseg] = Ka); boundaries are multiples of 64
     signed char kind[64], dz[64], dy[64], dx[64];
 };
@@ -85,30 +85,47 @@ __device__ __forceinline__ int wcell_off(const WgradArgs& t, int b, int zl, int 
     return v * t.C * 2;
 }
 
-struct WTapLane {       // implicit A: the wave's segment (its 64 columns lie in ONE) and the lane's running row of the DMA stream
-    int is_cst, dz, dy, dx;     // wave-uniform
-    int choff;                  // byte offset inside the segment's vector: first column of the wave's block + this lane's chunk
-    int b, pos;                 // viewpoint and position r % P of the NEXT row this lane requests (advances by 16 per slab)
-    long rows_left;             // rows of the operand from that row on (<= 0: past M)
+struct WTapLane {       // implicit A: the lane's running row of the DMA stream, addressed through its wave's offset table
+    int taddr;                  // LDS byte address of table[pos] for the row AFTER the ones already looked up
+    int boff;                   // b * (bytes per viewpoint) + the lane's byte offset inside the segment's vector
+    int bstep;                  // bytes per viewpoint (0 for a pattern segment)
+    int pend;                   // bstep when the entry at taddr belongs to the next viewpoint (applied when it is fetched)
+    int tend;                   // LDS byte address one past the wave's table (wrap -> next viewpoint)
+    int rows_left;              // rows of the operand from the next row to request on (<= 0: past the chunk / M)
+    int vo;                     // voffset of the next piece to request (made in the MFMA shadow of the phase before)
 };
 
+// The wave's offset table (one per 64-column block of the tile, 4 per workgroup, behind the ring in LDS): entry pos = byte
+// offset of the segment's vector for the row at position pos of viewpoint 0 (tap: the neighbouring cell's channel vector, or
+// kOutsideW outside the lattice; pattern block: its row of the pattern table).  A row's source is then ONE LDS read + one add
+// per slab: the per-slab decode (two quotients, the layout's index arithmetic, the bounds checks -- ~40 VALU instructions in
+// front of every 8 MFMAs) cost 20 ms of the 192-viewpoint step.
 template <int L>
-__device__ __forceinline__ int wtap_voffset(const WgradArgs& t, const WTapLane& tl) {
-    if (tl.rows_left <= 0 || tl.is_cst < 0) return kOutsideW;
-    if (tl.is_cst) return (tl.pos * t.ncst + tl.dz) * t.CW * 2 + tl.choff;
-    const int zl = (int)__umulhi((unsigned)tl.pos, t.mhw);
-    const int rem = tl.pos - zl * t.H * t.W;
-    const int y = (int)__umulhi((unsigned)rem, t.mw);
-    const int x = rem - y * t.W;
-    const int o = wcell_off<L>(t, tl.b, zl, y + tl.dy, x + tl.dx, tl.dz);
-    return o == kOutsideW ? kOutsideW : o + tl.choff;
+__device__ __forceinline__ int wtap_table_entry(const WgradArgs& t, int seg, int pos) {
+    if (seg < 0) return kOutsideW;                           // (columns past Ka: nothing to read)
+    if (t.kind[seg]) return (pos * t.ncst + t.dz[seg]) * t.CW * 2;
+    const int hw = t.H * t.W;
+    const int zl = pos / hw, rem = pos - zl * hw;
+    const int y = rem / t.W, x = rem - y * t.W;
+    return wcell_off<L>(t, 0, zl, y + t.dy[seg], x + t.dx[seg], t.dz[seg]);
 }
 
-template <int L>
-__device__ __forceinline__ void wtap_advance(const WgradArgs& t, WTapLane& tl) {
-    tl.pos += kSlabRows;
-    if (tl.pos >= t.P) tl.pos -= t.P, tl.b += 1;
+__device__ __forceinline__ int lds_read_b32(int addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// bookkeeping of one slab of the DMA stream, all VALU, placed in the MFMA shadow of a phase: the table entry fetched in this
+// phase (`tfetched`, valid behind the phase's lgkmcnt(0)) becomes the next piece's voffset; the address of the entry after
+// it is made ready for the next phase's fetch.
+__device__ __forceinline__ void wtap_step(const WgradArgs& t, WTapLane& tl, int tfetched) {
+    tl.boff += tl.pend;                                     // (the fetched entry's row may belong to the next viewpoint)
     tl.rows_left -= kSlabRows;
+    tl.vo = tl.rows_left > 0 ? (int)((unsigned)tfetched + (unsigned)tl.boff) : kOutsideW;
+    tl.taddr += 4 * kSlabRows;
+    tl.pend = 0;
+    if (tl.taddr >= tl.tend) tl.taddr -= 4 * t.P, tl.pend = tl.bstep;
 }
 
 struct WgradLane {          // per-lane constants of the main loop
@@ -144,6 +161,7 @@ template <int PS, int KP, int PF, int IMPL>
 __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const WgradLane& c, __amdgpu_buffer_rsrc_t ra,
                                       __amdgpu_buffer_rsrc_t rg, unsigned& soA, unsigned& soG, const WgradArgs& t, WTapLane& tl) {
     i32x2 al[KP][4], ah[KP][4], bl[KP][2], bh[KP][2];
+    int tnext = 0;
     read_slab<PS * KP>(c, al[0], ah[0], bl[0], bh[0]);
     if constexpr (KP == 2) read_slab<PS * KP + 1>(c, al[KP - 1], ah[KP - 1], bl[KP - 1], bh[KP - 1]);
 #pragma unroll
@@ -152,8 +170,9 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Wgra
         if constexpr (IMPL < 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, wtap_voffset<IMPL>(t, tl), 0, 0, 0);
-            wtap_advance<IMPL>(t, tl);
+            static_assert(IMPL < 0 || KP == 1, "implicit A: one slab per phase");
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + ds * kSlabBytes + c.dmaoff), 16, tl.vo, 0, 0, 0);
+            tnext = lds_read_b32(tl.taddr);                // the entry of the row after (consumed in this phase's MFMA shadow)
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + ds * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
         soA += (unsigned)c.stepA;
@@ -166,9 +185,10 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Wgra
     // MFMA's register tuples) is ordered behind it
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(al[0][0]), "+v"(ah[0][0]), "+v"(al[0][1]), "+v"(ah[0][1]), "+v"(al[0][2]), "+v"(ah[0][2]), "+v"(al[0][3]),
-                   "+v"(ah[0][3]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[0][1]), "+v"(bh[0][1])
+                   "+v"(ah[0][3]), "+v"(bl[0][0]), "+v"(bh[0][0]), "+v"(bl[0][1]), "+v"(bh[0][1]), "+v"(tnext)
                  :
                  : "memory");
+
     if constexpr (KP == 2)
         asm volatile(""
                      : "+v"(al[KP - 1][0]), "+v"(ah[KP - 1][0]), "+v"(al[KP - 1][1]), "+v"(ah[KP - 1][1]), "+v"(al[KP - 1][2]),
@@ -195,6 +215,10 @@ __device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const Wgra
                 acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u][it], b[u][jt], acc[it][jt], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (IMPL >= 0) {
+        wtap_step(t, tl, tnext);                            // (a dozen VALU instructions under the MFMAs just issued)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_barrier();
 }
 
@@ -250,20 +274,36 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p) {
     WTapLane tl = {};
     bool a_cst = false;
     if constexpr (IMPL >= 0) {
-        const int col0 = mt * kTile + 64 * (wave & 3);
-        int seg = -1;
-        for (int i = 0; i < p.nseg; ++i)
-            if (col0 >= p.seg_start[i] && col0 < p.seg_start[i + 1]) seg = i;
-        tl.is_cst = seg < 0 ? -1 : (int)p.kind[seg];            // (columns past Ka: nothing to read)
-        if (seg >= 0) {
-            tl.dz = p.dz[seg], tl.dy = p.dy[seg], tl.dx = p.dx[seg];
-            tl.choff = (col0 - p.seg_start[seg]) * 2 + pch * 16;
+        // the four offset tables of the tile's 64-column blocks, behind the ring (4 x P ints; the launcher has the LDS for them)
+        int* tables = reinterpret_cast<int*>(lds + kLdsBytes);
+        auto seg_of = [&](int col0) {
+            int seg = -1;
+            for (int i = 0; i < p.nseg; ++i)
+                if (col0 >= p.seg_start[i] && col0 < p.seg_start[i + 1]) seg = i;
+            return seg;
+        };
+        for (int q = 0; q < 4; ++q) {
+            const int seg = seg_of(mt * kTile + 64 * q);
+            for (int i = tid; i < p.P; i += 512) tables[q * p.P + i] = wtap_table_entry<IMPL>(p, seg, i);
         }
-        a_cst = tl.is_cst > 0;
+        __syncthreads();
+        const int col0 = mt * kTile + 64 * (wave & 3);
+        const int seg = seg_of(col0);
+        a_cst = seg >= 0 && p.kind[seg];
         const long r = row0 + 8 * (wave >> 2) + prow;
-        tl.b = (int)(r / p.P);
-        tl.pos = (int)(r - (long)tl.b * p.P);
-        tl.rows_left = min(p.M, row0 + p.Mc) - r;               // (a chunk ends where the next one starts)
+        const int b0 = (int)(r / p.P), pos0 = (int)(r - (long)b0 * p.P);
+        // bytes per viewpoint of the source (pattern table: none): layouts 0 / 2 hold a viewpoint's 4 H W cells together,
+        // the planar one H W cells per plane
+        tl.bstep = a_cst ? 0 : (IMPL == 3 ? p.H * p.W : 4 * p.H * p.W) * p.C * 2;
+        tl.boff = b0 * tl.bstep + (seg < 0 ? 0 : (col0 - p.seg_start[seg]) * 2) + pch * 16;
+        const int lbase = (int)(uintptr_t)(__attribute__((address_space(3))) char*)(lds + kLdsBytes) + (wave & 3) * p.P * 4;
+        tl.tend = lbase + 4 * p.P;
+        tl.taddr = lbase + 4 * pos0;
+        tl.pend = 0;
+        tl.rows_left = (int)min(min(p.M, row0 + p.Mc) - r, 0x7FFFFFF0L) + kSlabRows;   // (a chunk ends where the next one starts)
+        int t0 = lds_read_b32(tl.taddr);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0)::"memory");
+        wtap_step(p, tl, t0);                                   // -> tl.vo of the lane's first row, taddr at its second
     }
     const __amdgpu_buffer_rsrc_t ra =
         IMPL < 0 ? __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000)
@@ -303,8 +343,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p) {
         if constexpr (IMPL < 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, c.voA, (int)soA, 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, wtap_voffset<IMPL>(p, tl), 0, 0, 0);
-            wtap_advance<IMPL>(p, tl);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)(lds + s * kSlabBytes + c.dmaoff), 16, tl.vo, 0, 0, 0);
+            int tn = lds_read_b32(tl.taddr);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tn)::"memory");
+            wtap_step(p, tl, tn);
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void*)(lds + s * kSlabBytes + kSlabBytes / 2 + c.dmaoff), 16, c.voG, (int)soG, 0, 0);
         soA += (unsigned)c.stepA;
@@ -363,9 +405,9 @@ __global__ __launch_bounds__(512) void k_wgrad_tn(WgradArgs p) {
 }
 
 // the same kernel with the implicit tap matrix of a lattice in layout L as A (ver_wgrad_tn_segments)
-template <int L>
+template <int L, int PF>
 __global__ __launch_bounds__(512) void k_wgrad_tn_seg(WgradArgs p) {
-    wgrad_body<1, 3, L>(p);
+    wgrad_body<1, PF, L>(p);
 }
 
 // out[i][j] (bf16 or fp32, row pitch ldo) = sum over the S partial products, fp32; 4 elements per thread
@@ -446,10 +488,23 @@ void launch_tn(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
     e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
 }
+template <int L, int PF>
+void launch_tn_segments_pf(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
+    const int ldsb = kLdsBytes + 4 * p.P * 4;            // the ring + four offset tables of P ints
+    e = hipFuncSetAttribute((const void*)k_wgrad_tn_seg<L, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    if (e == hipSuccess) hipLaunchKernelGGL((k_wgrad_tn_seg<L, PF>), dim3((unsigned)blocks), dim3(512), ldsb, st, p);
+}
+
 template <int L>
 void launch_tn_segments(const WgradArgs& p, int blocks, hipStream_t st, hipError_t& e) {
-    e = hipFuncSetAttribute((const void*)k_wgrad_tn_seg<L>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e == hipSuccess) hipLaunchKernelGGL(k_wgrad_tn_seg<L>, dim3((unsigned)blocks), dim3(512), kLdsBytes, st, p);
+    static const int pf = [] {                             // (prefetch distance in slabs; VER_WGRAD_SEG_PF: experiments)
+        const char* v = getenv("VER_WGRAD_SEG_PF");
+        return v ? atoi(v) : 3;
+    }();
+    if (pf == 4) launch_tn_segments_pf<L, 4>(p, blocks, st, e);
+    else if (pf == 5) launch_tn_segments_pf<L, 5>(p, blocks, st, e);
+    else if (pf == 6) launch_tn_segments_pf<L, 6>(p, blocks, st, e);
+    else launch_tn_segments_pf<L, 3>(p, blocks, st, e);
 }
 }  // namespace
 
@@ -544,8 +599,9 @@ extern "C" int ver_wgrad_tn_segments(const void* lattice, int layout, int B, int
                 VER_EUNSUPPORTED, "ver_wgrad_tn_segments: segment widths (C = %d, pattern blocks of %d) must be multiples of 64", C, cw);
     const long M = (long)B * 2 * H * W, lbytes = (long)B * 4 * H * W * C * 2;
     const int P = 2 * H * W;
-    VER_REQUIRE(P >= kSlabRows && P < 65536 && lbytes < 0x7FFFFFFFL, VER_EUNSUPPORTED,
-                "ver_wgrad_tn_segments: %d rows per viewpoint / a source lattice of %ld bytes (16 <= rows < 65536, below 2 GiB)", P, lbytes);
+    VER_REQUIRE(P >= kSlabRows && P <= 2048 && lbytes < 0x7FFFFFFFL, VER_EUNSUPPORTED,
+                "ver_wgrad_tn_segments: %d rows per viewpoint / a source lattice of %ld bytes (16 <= rows <= 2048: four offset tables "
+                "next to the 128-KB ring in LDS; below 2 GiB)", P, lbytes);
     VER_REQUIRE(ldg >= N && ldo >= N && ldg % 8 == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)lattice & 15) == 0, VER_EUNSUPPORTED,
                 "ver_wgrad_tn_segments: g must be 16-byte aligned with a row pitch that is a multiple of 8 elements");
     VER_REQUIRE(N % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)out & 15) == 0, VER_EUNSUPPORTED,
@@ -596,8 +652,6 @@ extern "C" int ver_wgrad_tn_segments(const void* lattice, int layout, int B, int
     p.cst = (const __bf16*)cst;
     p.cst_bytes = cst ? (long)P * ncst * cw * 2 : 0;
     p.B = B, p.H = H, p.W = W, p.C = C, p.P = P, p.CW = cw, p.ncst = ncst, p.nseg = nseg;
-    p.mhw = (unsigned)((0x100000000UL + (unsigned long)(H * W) - 1) / (unsigned long)(H * W));
-    p.mw = (unsigned)((0x100000000UL + (unsigned long)W - 1) / (unsigned long)W);
     hipError_t e = hipSuccess;
     if (M > 0) {
         if (layout == 0) launch_tn_segments<0>(p, p.T * S, st, e);

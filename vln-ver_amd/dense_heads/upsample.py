@@ -502,6 +502,26 @@ def _block_offsets(kind, ci, co, device):
     return _BLOCK_OFFSETS[key]
 
 
+# Implicit tap matrix (round 6): from this many rows on, the forward and weight-gradient GEMMs of a bf16 lattice layer read
+# their A operand straight from the lattice (ver_gemm_nn_segments / ver_wgrad_tn_segments: a tap block of a row is the
+# contiguous channel vector of a neighbouring cell, fetched by the kernels' LDS-DMA) -- the tap matrix (10 GB for layer 3 at 192
+# viewpoints) is neither written nor kept for the backward pass; only d(input) still goes through an explicit matrix.  Below,
+# the skinny / library paths on the explicit matrix are faster.  VER_IMPLICIT_TAPS=0: explicit everywhere.
+_IMPLICIT_TAPS = os.environ.get('VER_IMPLICIT_TAPS', '1') in ('1', '2')
+# VER_IMPLICIT_TAPS=2 (A/B runs): implicit forward, but the backward pass writes the tap matrix after all and takes the explicit
+# weight-gradient kernel (ver_wgrad_tn)
+_IMPLICIT_WGRAD = os.environ.get('VER_IMPLICIT_TAPS', '1') != '2'
+
+
+def _implicit_taps(e, layout, rows, hw, ci, raw):
+    """True when a layer with source lattice ``e`` (layout 0 / 2 / 3), ``rows`` = B * 2 * H * W and H * W = ``hw`` takes the
+    implicit-operand kernels."""
+    if not (_IMPLICIT_TAPS and _OWN_GEMM and raw is not None and _on_hip(e) and e.dtype == torch.bfloat16 and rows >= _OWN_GEMM_MIN_ROWS):
+        return False
+    return (e.is_contiguous() and e.numel() * 2 < 2 ** 31 - 1 and ci % 64 == 0 and ci >= 64 and 16 <= 2 * hw < 65536
+            and _PW2 % 64 == 0)
+
+
 class _Layer0Z4(torch.autograd.Function):
     """First layer for Z = 4: every tap hits data.  x plain [B,4,H,W,Ci] -> z-split [B,2,H,W,2,Co]."""
 
@@ -513,6 +533,15 @@ class _Layer0Z4(torch.autograd.Function):
         ctx.raw = raw is not None
         co = raw.shape[1] if raw is not None else k.shape[-1]
         taps, offs, lo, hi = _layer0_z4_plan(ci, x.device)
+        ctx.implicit = _implicit_taps(x, ZS_PLAIN, b * 2 * h * w, h * w, ci, raw)
+        if ctx.implicit:
+            from ..hipops import convt_weight_forward_blocks, gemm_nn_taps
+            x = x.contiguous()
+            wmat = convt_weight_forward_blocks(raw, _block_offsets('l0', ci, co, x.device), x.new_empty(50 * ci, 2 * co), ci, co)
+            out = gemm_nn_taps(x, ZS_PLAIN, (h, w), taps, wmat, bias=torch.cat([bias, bias]).to(x.dtype).float())
+            ctx.save_for_backward(x, wmat)
+            ctx.geom = (tuple(x.shape), ci, co, h, w)
+            return out.view(b, 2, h, w, 2, co)
         a_mat = x.new_empty(b * 2 * h * w, 50 * ci)
         _gather_z4(x, ZS_PLAIN, a_mat, taps, offs, ci, h, w)
         if raw is not None:
@@ -536,7 +565,16 @@ class _Layer0Z4(torch.autograd.Function):
         with gemm_timed('head_gemm_dgrad', g.shape[0], g.shape[1], wmat.shape[0]):
             d_a = torch.mm(g, wmat.t())
         d_x = _scatter_z4(d_a, ZS_PLAIN, shape, taps, offs, ci, h, w)
-        d_w = rows_tn(a_mat, g)                                                            # [50 ci, 2 co]
+        if ctx.implicit and _IMPLICIT_WGRAD:                                               # (a_mat is the input lattice x here)
+            from ..hipops import wgrad_tn_segments
+            d_w = wgrad_tn_segments(a_mat, ZS_PLAIN, (h, w), taps, g)
+        elif ctx.implicit:
+            full = a_mat.new_empty(g.shape[0], 50 * ci)
+            _gather_z4(a_mat, ZS_PLAIN, full, taps, offs, ci, h, w)
+            d_w = rows_tn(full, g)
+            del full
+        else:
+            d_w = rows_tn(a_mat, g)                                                        # [50 ci, 2 co]
         acc = torch.float64 if g.dtype == torch.float64 else torch.float32
         d_b = g.sum(0, dtype=acc)
         if ctx.raw:
@@ -736,8 +774,9 @@ class _LatticeLayerZ4(torch.autograd.Function):
         dt = e.dtype
         plan, kt, total_rows, taps, offs = _layer_plan_z4(ci, e.device)
         m = b * 2 * hc * wc
-        a_mat = e.new_empty(m, kt)
-        if not _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=True):
+        ctx.implicit = _implicit_taps(e, layout, m, hc * wc, ci, raw)
+        a_mat = None if ctx.implicit else e.new_empty(m, kt)
+        if not ctx.implicit and not _gather_z4(e, layout, a_mat, taps, offs, ci, hc, wc, with_const=True):
             pats = _class_patterns(4, hc, wc, e.device, dt)
             a3 = a_mat.view(b, 2 * hc * wc, kt)
             for (pm, pn), pat in zip(_CLASSES, pats):
@@ -760,11 +799,18 @@ class _LatticeLayerZ4(torch.autograd.Function):
             v = blocks_vec_forward(stack, block_rows, ci, prev_bias).view(-1, co).index_select(0, tap_slot)     # [75, Co] fp32
             vaug = torch.cat([v.to(dt), bias.to(dt)[None], v.new_zeros(_PW - 75, co, dtype=dt)])                # + one zero row
             stack.view(-1, co).index_copy_(0, const_rows, vaug.index_select(0, const_src))
+            if ctx.implicit:
+                from ..hipops import gemm_nn_taps
+                e = e.contiguous()
+                table, _ = _const_rows_z4(ci, hc, wc, e.device, dt)
             for p, cls in enumerate(_CLASSES):
                 c0, c1 = plan[cls][:2]
                 r0 = class_rows[cls][0]
-                mm_fwd(a_mat[:, c0:c1], stack[r0:r0 + c1 - c0], out=out[p])
-            ctx.save_for_backward(a_mat, stack, prev_bias)
+                if ctx.implicit:
+                    gemm_nn_taps(e, layout, (hc, wc), _class_segments_z4(cls, ci), stack[r0:r0 + c1 - c0], const_rows=table, out=out[p])
+                else:
+                    mm_fwd(a_mat[:, c0:c1], stack[r0:r0 + c1 - c0], out=out[p])
+            ctx.save_for_backward(e if ctx.implicit else a_mat, stack, prev_bias)
             ctx.geom = (layout, tuple(e.shape), b, hc, wc, ci, co, total_rows)
             return out.view(4, b, 2, hc, wc, 2, co)
         v = _bias_through_taps(prev_bias.to(dt), k)                               # [75, Co]
@@ -792,8 +838,12 @@ class _LatticeLayerZ4(torch.autograd.Function):
         else:
             ws = ctx.saved_tensors[3:]
         dt = a_mat.dtype
-        m = a_mat.shape[0]
+        implicit = getattr(ctx, 'implicit', False)              # (a_mat is then the source lattice e, not its tap matrix)
+        m = b * 2 * hc * wc
         g = grad_out.contiguous().view(4, m, 2 * co)
+        if implicit and not _IMPLICIT_WGRAD:                    # (A/B mode: the tap matrix after all, for the explicit kernel)
+            lattice, a_mat, implicit = a_mat, a_mat.new_empty(m, kt), False
+            _gather_z4(lattice, layout, a_mat, taps, offs, ci, hc, wc, with_const=True)
         d_a = a_mat.new_empty(m, kt)
         d_a[:, kt - _PW2:] = 0                                  # P01 is outside class (0,0)'s range
         fused = ctx.raw
@@ -815,7 +865,12 @@ class _LatticeLayerZ4(torch.autograd.Function):
                     torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
             if fused:
                 r0 = class_rows[cls][0]
-                rows_tn(a_mat[:, c0:c1], g[p], out=stacked[r0:r0 + c1 - c0])
+                if implicit:
+                    from ..hipops import wgrad_tn_segments
+                    wgrad_tn_segments(a_mat, layout, (hc, wc), _class_segments_z4(cls, ci), g[p], out=stacked[r0:r0 + c1 - c0],
+                                      const_rows=_const_rows_z4(ci, hc, wc, a_mat.device, dt)[0])
+                else:
+                    rows_tn(a_mat[:, c0:c1], g[p], out=stacked[r0:r0 + c1 - c0])
                 continue
             d_w = rows_tn(a_mat[:, c0:c1], g[p])
             d_lo.index_copy_(0, lo, d_w[:, :co])

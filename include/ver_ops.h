@@ -536,6 +536,13 @@ int  ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int 
 int  ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
                           const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos, const float* bias,
                           void* c, long ldc, int N, void* stream);
+/*   ... reading its tap blocks from SEVERAL source lattices of one shape, plane_elems elements apart (tap t from plane
+ *   tap_plane[t], host int [ntaps]; each plane below 2 GiB): d(input) of a lattice layer as ONE gather-form product over the four
+ *   class planes of the output gradient, d_e[cell] = sum over (class, tap, half) of g_class[cell - tap] W^T -- no explicit
+ *   d(tap matrix), no ver_lattice_scatter (the reference's ConvTranspose3d backward-data, head:251-258 through autograd). */
+int  ver_gemm_nn_planes(const void* lattice, int layout, int B, int H, int W, int C, long plane_elems, int nplanes,
+                        const int* tap_plane, const int* taps, int ntaps, const void* cst, int ncst, int cw, const void* w,
+                        long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N, void* stream);
 int  ver_gemm_nn_splits(long M, int K, int N);
 int  ver_gemm_nn_splitk(const void* a, long lda, const void* w, long ldw, const float* bias, void* c, long ldc, long M, int K,
                         int N, int splits, void* workspace, long workspace_bytes, void* stream);

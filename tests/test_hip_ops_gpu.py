@@ -1778,3 +1778,75 @@ def test_wgrad_tn_segments_equals_gather_then_wgrad(planar, B, hc, C, splits):
         want = hip.wgrad_tn(a0, g, out_dtype=torch.float32, splits=2)
         got = hip.wgrad_tn_segments(x, 0, (hc, hc), taps0, g, out_dtype=torch.float32, splits=2)
         assert torch.equal(got, want)
+
+
+def test_lattice_stack_with_implicit_operands_equals_the_explicit_tap_matrices(monkeypatch):
+    """The three lattice layers (head:251-258 on the even lattice) at 110 viewpoints in bf16, where every product takes the
+    implicit-operand kernels (ver_gemm_nn_segments, ver_wgrad_tn_segments, ver_gemm_nn_planes for d(input)), against the same
+    layers on explicit tap matrices (VER_IMPLICIT_TAPS=0: gather, ver_gemm_nn / library, scatter): the lattice out of the
+    forward and every weight / bias gradient bit for bit (same operands, same order), d(input) within bf16 rounding (one
+    fp32 sum over all classes and taps instead of bf16 partial sums per class)."""
+    ups, hip = pkg('dense_heads.upsample'), pkg('hipops')
+    gen = torch.Generator(device='cpu').manual_seed(131)
+    B, C = 110, 768
+    x0 = (torch.randn(B, C, 4, 15, 15, generator=gen) * 0.5).to(DEV)
+    ws = [(torch.randn(C, C, 3, 5, 5, generator=gen) * 0.02).to(DEV) for _ in range(3)]
+    bs = [(torch.randn(C, generator=gen) * 0.1).to(DEV) for _ in range(3)]
+    res = {}
+    calls = []
+    real = hip.gemm_nn_taps
+    monkeypatch.setattr(hip, 'gemm_nn_taps', lambda *a, **k: (calls.append(k.get('timer_class', 'fwd')), real(*a, **k))[1])
+    for mode in ('implicit', 'explicit'):
+        monkeypatch.setattr(ups, '_IMPLICIT_TAPS', mode == 'implicit')
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            e, _ = ups.upsample_lattice(x, w, b)
+        gg = torch.randn(e.shape, generator=torch.Generator(device='cpu').manual_seed(5)).bfloat16().to(DEV)
+        e.backward(gg)
+        res[mode] = (e.detach(), x.grad, [t.grad for t in w], [t.grad for t in b])
+    assert calls.count('fwd') == 9 and calls.count('head_gemm_dgrad') == 6                  # (all in the implicit pass)
+    (e_i, dx_i, dw_i, db_i), (e_e, dx_e, dw_e, db_e) = res['implicit'], res['explicit']
+    assert torch.equal(e_i, e_e)
+    from util import rel_l2
+    assert torch.equal(dw_i[2], dw_e[2]) and torch.equal(db_i[2], db_e[2])      # the last layer: same gradient in, bit for bit
+    for a, c in zip(dw_i[:2] + db_i[:2] + [dx_i], dw_e[:2] + db_e[:2] + [dx_e]):
+        # layers 1-2 see the d(input) of the layer above: ONE fp32 sum over all classes and taps (implicit) against bf16
+        # partial sums per class (explicit) -- two bf16 evaluations apart (measured 5e-3 on the first layer's weight)
+        assert rel_l2(a, c) < 1e-2, rel_l2(a, c)
+
+
+@pytest.mark.parametrize('planar,B,hc', [(False, 3, 6), (True, 2, 8)])
+def test_implicit_input_gradient_of_a_lattice_layer_against_fp32(planar, B, hc):
+    """d(input) of a class-stacked lattice layer as gather-form products over the four class planes of the output gradient
+    (dense_heads/upsample.py::_dgrad_implicit on ver_gemm_nn_planes) against the definition in fp32 -- d(tap matrix) =
+    sum over classes of g_class W_class^T, scattered back by the adjoint of the gather: one bf16 rounding of the same sums,
+    and no further from them than the explicit bf16 path (which rounds d(tap matrix) after every class)."""
+    ups = pkg('dense_heads.upsample')
+    ci = co = 64
+    gen = torch.Generator(device='cpu').manual_seed(137 + hc)
+    layout = ups.ZS_PLANAR_SPLIT if planar else ups.ZS_SPLIT
+    plan, kt, _, taps, offs = ups._layer_plan_z4(ci, torch.device(DEV))
+    m = B * 2 * hc * hc
+    rows = sum(plan[cls][1] - plan[cls][0] for cls in ups._CLASSES)
+    stack = (torch.randn(rows, 2 * co, generator=gen) * 0.1).bfloat16().to(DEV)
+    g = torch.randn(4, m, 2 * co, generator=gen).bfloat16().to(DEV)
+    cr = ups._class_rows_z4(ci)
+    e_shape = (4, B, 2, hc // 2, hc // 2, 2, ci) if planar else (B, 2, hc, hc, 2, ci)
+    d_a32 = torch.zeros(m, kt, device=DEV)
+    d_a16 = torch.zeros(m, kt, device=DEV, dtype=torch.bfloat16)
+    for p, cls in enumerate(ups._CLASSES):
+        c0, c1 = plan[cls][:2]
+        w = stack[cr[cls][0]:cr[cls][0] + c1 - c0]
+        d_a32[:, c0:c1] += g[p].float() @ w.float().t()
+        d_a16[:, c0:c1] = (d_a16[:, c0:c1].float() + g[p].float() @ w.float().t()).bfloat16()
+    want = ups._scatter_z4(d_a32, layout, e_shape, taps, offs, ci, hc, hc)
+    explicit = ups._scatter_z4(d_a16, layout, e_shape, taps, offs, ci, hc, hc)
+    got = ups._dgrad_implicit('lat', g, stack, B, hc, hc, ci, co)
+    if planar:
+        got = got.view(B, 2, hc // 2, 2, hc // 2, 2, 2, ci).permute(3, 5, 0, 1, 2, 4, 6, 7).reshape(e_shape)
+    from util import rel_l2
+    assert got.dtype == torch.bfloat16 and rel_l2(got.float(), want) < 3e-3, rel_l2(got.float(), want)
+    assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    assert rel_l2(got.float(), want) <= rel_l2(explicit.float(), want) * 1.05

@@ -66,6 +66,10 @@ struct TapArgs {
     long cst_bytes;
     int CW, ncst;
     signed char kind[64], dz[64], dy[64], dx[64];
+    // several source lattices of one shape `plane_elems` elements apart (the four class planes of a layer's output gradient,
+    // ver_gemm_nn_segments' d(input) form): tap t reads plane pl[t]; lattice_bytes is the size of ONE plane
+    signed char pl[64];
+    long plane_elems;
 };
 
 struct GemmArgs {
@@ -117,7 +121,10 @@ struct TapLane {                // implicit operand: this lane's two rows and th
 };
 
 template <int L>
-__device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl) {
+__device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl, __amdgpu_buffer_rsrc_t& ra) {
+    if (t.plane_elems && tl.tap < t.ntaps && !t.kind[tl.tap])
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)(t.lattice + (long)t.pl[tl.tap] * t.plane_elems), 0,
+                                               (int)max(0L, min(t.lattice_bytes, 0x7FFFFFFFL)), 0x00020000);
     tl.is_cst = 0;
     tl.seglen = 2 * t.C;
     if (tl.tap < t.ntaps) {
@@ -140,7 +147,7 @@ __device__ __forceinline__ void tap_offsets(const TapArgs& t, TapLane& tl) {
 
 // this wave's two A pieces of one phase: explicit operand (IMPL < 0) or straight from the lattice
 template <int IMPL>
-__device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rcst,
+__device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu_buffer_rsrc_t& ra, __amdgpu_buffer_rsrc_t rcst,
                                           int& soA, const TapArgs& t, TapLane& tl) {
     if constexpr (IMPL < 0) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void*)dst, 16, c.voA, soA, 0, 0);
@@ -159,14 +166,14 @@ __device__ __forceinline__ void request_a(char* dst, const GemmLane& c, __amdgpu
         if (tl.ch == __builtin_amdgcn_readfirstlane(tl.seglen)) {    // next segment: the lane's two source vectors move
             tl.ch = 0;
             tl.tap = __builtin_amdgcn_readfirstlane(tl.tap) + 1;
-            tap_offsets<IMPL>(t, tl);
+            tap_offsets<IMPL>(t, tl, ra);
         }
     }
 }
 
 
 template <int ST, int IMPL>
-__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const GemmLane& c, __amdgpu_buffer_rsrc_t ra,
+__device__ __forceinline__ void phase(char* lds, f32x16 (&acc)[4][2], const GemmLane& c, __amdgpu_buffer_rsrc_t& ra,
                                       __amdgpu_buffer_rsrc_t rw, int& soA, int& soW, const TapArgs& t, TapLane& tl,
                                       __amdgpu_buffer_rsrc_t rcst) {
     // (the offset field of a DS instruction has 16 bits: stages 2-3 go through base registers 64 KiB up)
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
     // source lattice (implicit operand: the per-lane offsets address the tap vectors)
     const __bf16* ab = IMPL < 0 ? p.A + row0 * p.lda + k0 : p.t.lattice;
     const long abytes = IMPL < 0 ? ((p.M - row0 - 1) * p.lda + klen) * 2 : p.t.lattice_bytes;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, (int)max(0L, min(abytes, 0xFFFFFFFFL)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rcst = __builtin_amdgcn_make_buffer_rsrc((void*)(IMPL < 0 ? ab : p.t.cst), 0,
                                                                           (int)(IMPL < 0 ? 0L : max(0L, min(p.t.cst_bytes, 0x7FFFFFFFL))), 0x00020000);
     // W: columns nt * 256 .., the slice's rows (behind the last element: zeros)
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(512) void k_gemm_nn(GemmArgs p) {
         tl.pos2 = (tl.zl2 * p.t.H + tl.y2) * p.t.W + tl.x2;
         tl.chunk = ((lane & 3) ^ ((prow >> 2) & 3)) * 16;
         tl.tap = 0, tl.ch = 0;
-        tap_offsets<IMPL>(p.t, tl);
+        tap_offsets<IMPL>(p.t, tl, ra);
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -494,6 +501,10 @@ extern "C" int ver_gemm_nn_splitk(const void* a, long lda, const void* w, long l
 extern "C" int ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
                                     const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos,
                                     const float* bias, void* c, long ldc, int N, void* stream);
+extern "C" int ver_gemm_nn_planes(const void* lattice, int layout, int B, int H, int W, int C, long plane_elems, int nplanes,
+                                  const int* tap_plane, const int* taps, int ntaps, const void* cst, int ncst, int cw,
+                                  const void* w, long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N,
+                                  void* stream);
 
 extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
                                 const void* w, long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N,
@@ -504,6 +515,13 @@ extern "C" int ver_gemm_nn_taps(const void* lattice, int layout, int B, int H, i
 extern "C" int ver_gemm_nn_segments(const void* lattice, int layout, int B, int H, int W, int C, const int* taps, int ntaps,
                                     const void* cst, int ncst, int cw, const void* w, long ldw, const float* rowpos,
                                     const float* bias, void* c, long ldc, int N, void* stream) {
+    return ver_gemm_nn_planes(lattice, layout, B, H, W, C, 0, 0, nullptr, taps, ntaps, cst, ncst, cw, w, ldw, rowpos, bias, c, ldc, N, stream);
+}
+
+extern "C" int ver_gemm_nn_planes(const void* lattice, int layout, int B, int H, int W, int C, long plane_elems, int nplanes,
+                                  const int* tap_plane, const int* taps, int ntaps, const void* cst, int ncst, int cw,
+                                  const void* w, long ldw, const float* rowpos, const float* bias, void* c, long ldc, int N,
+                                  void* stream) {
     hipStream_t st = (hipStream_t)stream;
     VER_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0 && ntaps > 0, VER_EINVAL, "ver_gemm_nn_taps: bad sizes");
     VER_REQUIRE(layout == 0 || layout == 2 || layout == 3, VER_EINVAL, "ver_gemm_nn_taps: layout %d (0 plain, 2 z-split, 3 planar z-split)", layout);
@@ -549,6 +567,14 @@ extern "C" int ver_gemm_nn_segments(const void* lattice, int layout, int B, int 
     p.t.lattice_bytes = lbytes;
     p.t.B = B, p.t.H = H, p.t.W = W, p.t.C = C, p.t.ntaps = ntaps, p.t.P = 2 * H * W;
     p.t.rowpos = rowpos;
+    VER_REQUIRE((plane_elems == 0) == (tap_plane == nullptr) && plane_elems >= 0 && (plane_elems == 0 || (nplanes > 0 && nplanes <= 64 &&
+                plane_elems % 8 == 0)), VER_EINVAL, "ver_gemm_nn_planes: plane_elems, nplanes and tap_plane come together");
+    p.t.plane_elems = plane_elems;
+    for (int i = 0; i < ntaps; ++i) {
+        VER_REQUIRE(!tap_plane || (tap_plane[i] >= 0 && tap_plane[i] < nplanes), VER_EINVAL, "ver_gemm_nn_planes: tap %d reads plane %d of %d", i,
+                    tap_plane ? tap_plane[i] : 0, nplanes);
+        p.t.pl[i] = (signed char)(tap_plane ? tap_plane[i] : 0);
+    }
     p.t.cst = (const __bf16*)cst;
     p.t.cst_bytes = cst ? (long)2 * H * W * ncst * cw * 2 : 0;
     p.t.CW = cw, p.t.ncst = ncst;

@@ -507,7 +507,12 @@ def _block_offsets(kind, ci, co, device):
 # contiguous channel vector of a neighbouring cell, fetched by the kernels' LDS-DMA) -- the tap matrix (10 GB for layer 3 at 192
 # viewpoints) is neither written nor kept for the backward pass; only d(input) still goes through an explicit matrix.  Below,
 # the skinny / library paths on the explicit matrix are faster.  VER_IMPLICIT_TAPS=0: explicit everywhere.
-_IMPLICIT_TAPS = os.environ.get('VER_IMPLICIT_TAPS', '1') in ('1', '2')
+_IMPLICIT_TAPS = os.environ.get('VER_IMPLICIT_TAPS', '1') in ('1', '2', '3')
+# ... and d(input) as ONE gather-form product per input half over the four class planes of the output gradient
+# (ver_gemm_nn_planes: d_e[cell] = sum over (class, tap, output half) of g_class[cell - tap] W^T): no explicit d(tap matrix)
+# (10 GB transient at layer 3), no ver_lattice_scatter, fp32 sums over all classes and taps rounded once.
+# VER_IMPLICIT_TAPS=3 (A/B runs): d(input) through the library and the explicit matrix.
+_IMPLICIT_DGRAD = os.environ.get('VER_IMPLICIT_TAPS', '1') == '1'
 # VER_IMPLICIT_TAPS=2 (A/B runs): implicit forward, but the backward pass writes the tap matrix after all and takes the explicit
 # weight-gradient kernel (ver_wgrad_tn)
 _IMPLICIT_WGRAD = os.environ.get('VER_IMPLICIT_TAPS', '1') != '2'
@@ -520,6 +525,57 @@ def _implicit_taps(e, layout, rows, hw, ci, raw):
         return False
     return (e.is_contiguous() and e.numel() * 2 < 2 ** 31 - 1 and ci % 64 == 0 and ci >= 64 and 16 <= 2 * hw < 65536
             and _PW2 % 64 == 0)
+
+
+_DGRAD_PLAN = {}
+
+
+def _dgrad_plan(kind, ci, device):
+    """d(input) of a Z = 4 layer as gather-form products: per input half j the blocks that read it -- (first row of the
+    block in the layer's stacked weight matrix) as an index tensor, and the (dz, dy, dx) taps / source planes of
+    ``hipops.gemm_nn_taps`` on the output gradient: block (class p, dy, dx, j) of the forward contributes
+    g_p[cell - (dy, dx)][half h] W_block[:, h]^T for both output halves h (K order: block, h, co).
+    kind 'l0': layer 1 (one plane, 25 (bb, cc) blocks per j); 'lat': the class-stacked layers (4 planes)."""
+    key = (kind, ci, str(device))
+    if key not in _DGRAD_PLAN:
+        per_j = ([], [])
+        if kind == 'l0':
+            i = 0
+            for bb in range(5):
+                for cc in range(5):
+                    for j in range(2):
+                        per_j[j].append((0, i * ci, bb - 2, cc - 2))
+                        i += 1
+        else:
+            for p, cls in enumerate(_CLASSES):
+                roff, segs = _class_rows_z4(ci)[cls]
+                for kind_, val, r0 in segs:
+                    if kind_ == 'b':
+                        dxi, dyi, j = _ORDER4[val]
+                        per_j[j].append((p, roff + r0, dyi - 1, dxi - 1))
+        plan = []
+        for j in range(2):
+            rows = torch.from_numpy(np.concatenate([np.arange(r0, r0 + ci) for _, r0, _, _ in per_j[j]]).astype(np.int64)).to(device)
+            taps = [(2 * h, -dy, -dx) for _, _, dy, dx in per_j[j] for h in range(2)]
+            planes = [p for p, _, _, _ in per_j[j] for _ in range(2)]
+            plan.append((rows, taps, planes, len(per_j[j])))
+        _DGRAD_PLAN[key] = plan
+    return _DGRAD_PLAN[key]
+
+
+def _dgrad_implicit(kind, g_planes, weights, b, hc, wc, ci, co):
+    """d(input) lattice, z-split [B,2,hc,wc,2,Ci], from the output gradient ``g_planes`` bf16 [planes, B*2*hc*wc, 2 Co] and the
+    layer's stacked weight matrix ``weights`` [rows, 2 Co] (``_dgrad_plan``)."""
+    from ..hipops import gemm_nn_taps
+    m = b * 2 * hc * wc
+    lat = g_planes.view(g_planes.shape[0], b, 2, hc, wc, 2, co)
+    d_e = g_planes.new_empty(m, 2 * ci)
+    for j, (rows, taps, planes, nb) in enumerate(_dgrad_plan(kind, ci, g_planes.device)):
+        # W_j [blocks * 2 Co, Ci]: every block of the stacked matrix transposed (rows (h, co) of a block = its columns)
+        wj = weights.index_select(0, rows).view(nb, ci, 2 * co).transpose(1, 2).reshape(nb * 2 * co, ci)
+        gemm_nn_taps(lat if kind != 'l0' else lat[0], ZS_SPLIT, (hc, wc), taps, wj, out=d_e[:, j * ci:(j + 1) * ci],
+                     planes=planes if kind != 'l0' else None, timer_class='head_gemm_dgrad')
+    return d_e.view(b, 2, hc, wc, 2, ci)
 
 
 class _Layer0Z4(torch.autograd.Function):
@@ -562,9 +618,13 @@ class _Layer0Z4(torch.autograd.Function):
         shape, ci, co, h, w = ctx.geom
         taps, offs, lo, hi = _layer0_z4_plan(ci, a_mat.device)
         g = grad_out.contiguous().view(-1, 2 * co)
-        with gemm_timed('head_gemm_dgrad', g.shape[0], g.shape[1], wmat.shape[0]):
-            d_a = torch.mm(g, wmat.t())
-        d_x = _scatter_z4(d_a, ZS_PLAIN, shape, taps, offs, ci, h, w)
+        if ctx.implicit and _IMPLICIT_DGRAD:
+            d_x = zs_to_plain(_dgrad_implicit('l0', g[None], wmat, shape[0], h, w, ci, co))
+        else:
+            with gemm_timed('head_gemm_dgrad', g.shape[0], g.shape[1], wmat.shape[0]):
+                d_a = torch.mm(g, wmat.t())
+            d_x = _scatter_z4(d_a, ZS_PLAIN, shape, taps, offs, ci, h, w)
+            del d_a
         if ctx.implicit and _IMPLICIT_WGRAD:                                               # (a_mat is the input lattice x here)
             from ..hipops import wgrad_tn_segments
             d_w = wgrad_tn_segments(a_mat, ZS_PLAIN, (h, w), taps, g)
@@ -844,8 +904,10 @@ class _LatticeLayerZ4(torch.autograd.Function):
         if implicit and not _IMPLICIT_WGRAD:                    # (A/B mode: the tap matrix after all, for the explicit kernel)
             lattice, a_mat, implicit = a_mat, a_mat.new_empty(m, kt), False
             _gather_z4(lattice, layout, a_mat, taps, offs, ci, hc, wc, with_const=True)
-        d_a = a_mat.new_empty(m, kt)
-        d_a[:, kt - _PW2:] = 0                                  # P01 is outside class (0,0)'s range
+        dgrad_implicit = implicit and _IMPLICIT_DGRAD
+        if not dgrad_implicit:
+            d_a = a_mat.new_empty(m, kt)
+            d_a[:, kt - _PW2:] = 0                              # P01 is outside class (0,0)'s range
         fused = ctx.raw
         if fused:
             class_rows = _class_rows_z4(ci)
@@ -858,11 +920,12 @@ class _LatticeLayerZ4(torch.autograd.Function):
             w = ws[p]
             # (library GEMMs: a one-pass kernel of our own over all four classes was built and measured 7 % slower,
             #  scratch/experiments/k_dgrad_nt.hip.inc)
-            with gemm_timed('head_gemm_dgrad', m, 2 * co, c1 - c0):
-                if p == 0:                                      # class (0,0): initialises every tap block
-                    torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
-                else:
-                    torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
+            if not dgrad_implicit:
+                with gemm_timed('head_gemm_dgrad', m, 2 * co, c1 - c0):
+                    if p == 0:                                  # class (0,0): initialises every tap block
+                        torch.mm(g[p], w.t(), out=d_a[:, c0:c1])
+                    else:
+                        torch.addmm(d_a[:, c0:c1], g[p], w.t(), out=d_a[:, c0:c1])
             if fused:
                 r0 = class_rows[cls][0]
                 if implicit:
@@ -875,7 +938,13 @@ class _LatticeLayerZ4(torch.autograd.Function):
             d_w = rows_tn(a_mat[:, c0:c1], g[p])
             d_lo.index_copy_(0, lo, d_w[:, :co])
             d_hi.index_copy_(0, hi, d_w[:, co:])
-        d_e = _scatter_z4(d_a, layout, e_shape, taps, offs, ci, hc, wc)
+        if dgrad_implicit:
+            d_e = _dgrad_implicit('lat', g, k, b, hc, wc, ci, co)                  # z-split [B,2,hc,wc,2,Ci] (k: stacked weights)
+            if layout == ZS_PLANAR_SPLIT:                                           # -> the planar form of the source lattice
+                d_e = d_e.view(b, 2, hc // 2, 2, wc // 2, 2, 2, ci).permute(3, 5, 0, 1, 2, 4, 6, 7).reshape(e_shape)
+        else:
+            d_e = _scatter_z4(d_a, layout, e_shape, taps, offs, ci, hc, wc)
+            del d_a
         acc = torch.float64 if dt == torch.float64 else torch.float32
         if fused:
             from ..hipops import convt_weight_backward_blocks

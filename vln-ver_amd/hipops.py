@@ -26,7 +26,7 @@ SYMBOLS = ('ver_abi_version', 'ver_last_error', 'ver_sca_backward_grad_dtype', '
            'ver_run_scatter', 'ver_add_ln_forward', 'ver_add_ln_backward',
            'ver_relu_dropout_forward', 'ver_relu_dropout_backward', 'ver_occ_predict_blocks', 'ver_occ_predict',
            'ver_wgrad_tn_splits', 'ver_wgrad_tn_splits_ld', 'ver_wgrad_tn_segments', 'ver_wgrad_tn_segments_splits', 'ver_wgrad_tn_workspace', 'ver_wgrad_tn', 'ver_occ_mlp_forward_stats',
-           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_gemm_nn_taps', 'ver_gemm_nn_segments', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
+           'ver_occ_mlp_backward_fused_stats', 'ver_gemm_nn', 'ver_gemm_nn_splits', 'ver_gemm_nn_splitk', 'ver_gemm_nn_taps', 'ver_gemm_nn_segments', 'ver_gemm_nn_planes', 'ver_clip_adamw_step', 'ver_clip_adamw_step_tensors')
 
 _lib = None
 
@@ -1290,16 +1290,28 @@ def gemm_nn_taps_supported(lattice, layout, w, c):
             and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0)
 
 
-def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, out=None, const_rows=None):
+def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, out=None, const_rows=None, planes=None,
+                 timer_class='ver_gemm_nn'):
     """ver_gemm_nn_segments: ``tap_matrix(lattice) @ w (+ rowpos by row position) (+ bias)`` without the tap matrix: lattice
     bf16 in layout 0 / 2 / 3 (see ``lattice_gather``), rows = the cells (b, zl, y, x) of the combined (H, W) lattice.  ``taps``:
     the segments of the K axis in order -- (dz in {0, 2}, dy, dx) = the C channels of that neighbouring cell, or ('c', block) =
     the columns of constant-pattern block ``block`` of ``const_rows`` bf16 [2 H W, blocks, width] (what ``lattice_gather``
-    copies into every viewpoint's rows).  w bf16 [sum of the segment widths, N] -> bf16 [B * 2 * H * W, N]."""
+    copies into every viewpoint's rows).  w bf16 [sum of the segment widths, N] -> bf16 [B * 2 * H * W, N].
+    ``planes`` = list with the source plane of every tap: ``lattice`` is then [planes, ...] -- several lattices of one shape
+    (the four class planes of a layer's output gradient), tap t reads ``lattice[planes[t]]``."""
     lat, w = _gpu(lattice, 'lattice'), _gpu(w, 'w')
     H, W = combined_hw
-    B, _, C = _lattice_dims(lat, int(layout))
-    if not gemm_nn_taps_supported(lat, int(layout), w, C):
+    plane_elems = nplanes = 0
+    if planes is not None:
+        nplanes, plane_elems = int(lat.shape[0]), int(lat[0].numel())
+        if len(planes) != len(taps) or not lat.is_contiguous():
+            raise ValueError('gemm_nn_taps: one source plane per tap, contiguous planes')
+        B, _, C = _lattice_dims(lat[0], int(layout))
+        lat_one = lat[0]
+    else:
+        B, _, C = _lattice_dims(lat, int(layout))
+        lat_one = lat
+    if not gemm_nn_taps_supported(lat_one, int(layout), w, C):
         raise RuntimeError('gemm_nn_taps: unsupported operands %s layout %d / %s %s' % (tuple(lat.shape), layout, tuple(w.shape), w.stride()))
     m, n = B * 2 * H * W, w.shape[1]
     ncst = cw = 0
@@ -1324,8 +1336,10 @@ def gemm_nn_taps(lattice, layout, combined_hw, taps, w, rowpos=None, bias=None, 
         bias = _gpu(bias, 'bias').float().contiguous()
     flat = [int(v) for t in taps for v in t]
     arr = (ctypes.c_int * len(flat))(*flat)
-    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_segments(
-        _p(lat), int(layout), int(B), int(H), int(W), int(C), arr, len(taps), _p(const_rows) if const_rows is not None else None,
+    parr = (ctypes.c_int * len(taps))(*[int(v) for v in planes]) if planes is not None else None
+    _launch(timer_class, lambda: lib().ver_gemm_nn_planes(
+        _p(lat), int(layout), int(B), int(H), int(W), int(C), ctypes.c_long(plane_elems), nplanes, parr, arr, len(taps),
+        _p(const_rows) if const_rows is not None else None,
         ncst, cw, _p(w), ctypes.c_long(w.stride(0)), _p(rowpos) if rowpos is not None else None, _p(bias) if bias is not None else None, _p(out), ctypes.c_long(out.stride(0)),
         int(n), _stream()), meta=dict(flops=2.0 * m * w.shape[0] * n))
     return out

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 R=gpurun_out/r06; mkdir -p $R
-for mode in 1 0 2 1 0; do
+for mode in 1 0 3 1 0; do
 VER_IMPLICIT_TAPS=$mode python bench.py --steps 5 --warmup 1 --sub-records "" --host-fed-steps 0 --no-cpu-baseline --latency-batches "" > $R/bench_ab_$mode.json 2> $R/bench_ab_$mode.err
 python - <<PY
 import json

@@ -553,28 +553,27 @@ def _dgrad_plan(kind, ci, device):
                     if kind_ == 'b':
                         dxi, dyi, j = _ORDER4[val]
                         per_j[j].append((p, roff + r0, dyi - 1, dxi - 1))
-        plan = []
-        for j in range(2):
-            rows = torch.from_numpy(np.concatenate([np.arange(r0, r0 + ci) for _, r0, _, _ in per_j[j]]).astype(np.int64)).to(device)
-            taps = [(2 * h, -dy, -dx) for _, _, dy, dx in per_j[j] for h in range(2)]
-            planes = [p for p, _, _, _ in per_j[j] for _ in range(2)]
-            plan.append((rows, taps, planes, len(per_j[j])))
-        _DGRAD_PLAN[key] = plan
+        # both input halves read the SAME (class, dy, dx, h) sequence of the output gradient: one operand, weights side by side
+        assert [q[2:] for q in per_j[0]] == [q[2:] for q in per_j[1]] and [q[0] for q in per_j[0]] == [q[0] for q in per_j[1]]
+        rows = torch.from_numpy(np.stack([np.stack([np.arange(r0, r0 + ci) for _, r0, _, _ in per_j[j]]) for j in range(2)], 1)
+                                .reshape(-1).astype(np.int64)).to(device)                  # (block, j, ci)
+        taps = [(2 * h, -dy, -dx) for _, _, dy, dx in per_j[0] for h in range(2)]
+        planes = [p for p, _, _, _ in per_j[0] for _ in range(2)]
+        _DGRAD_PLAN[key] = (rows, taps, planes, len(per_j[0]))
     return _DGRAD_PLAN[key]
 
 
 def _dgrad_implicit(kind, g_planes, weights, b, hc, wc, ci, co):
     """d(input) lattice, z-split [B,2,hc,wc,2,Ci], from the output gradient ``g_planes`` bf16 [planes, B*2*hc*wc, 2 Co] and the
-    layer's stacked weight matrix ``weights`` [rows, 2 Co] (``_dgrad_plan``)."""
+    layer's stacked weight matrix ``weights`` [rows, 2 Co] (``_dgrad_plan``): ONE product [M, blocks * 2 Co] x [., 2 Ci]."""
     from ..hipops import gemm_nn_taps
     m = b * 2 * hc * wc
     lat = g_planes.view(g_planes.shape[0], b, 2, hc, wc, 2, co)
-    d_e = g_planes.new_empty(m, 2 * ci)
-    for j, (rows, taps, planes, nb) in enumerate(_dgrad_plan(kind, ci, g_planes.device)):
-        # W_j [blocks * 2 Co, Ci]: every block of the stacked matrix transposed (rows (h, co) of a block = its columns)
-        wj = weights.index_select(0, rows).view(nb, ci, 2 * co).transpose(1, 2).reshape(nb * 2 * co, ci)
-        gemm_nn_taps(lat if kind != 'l0' else lat[0], ZS_SPLIT, (hc, wc), taps, wj, out=d_e[:, j * ci:(j + 1) * ci],
-                     planes=planes if kind != 'l0' else None, timer_class='head_gemm_dgrad')
+    rows, taps, planes, nb = _dgrad_plan(kind, ci, g_planes.device)
+    # W [(block, h, co), (j, ci)] = S[row of block (.., j) + ci, h Co + co]: the two input halves' blocks transposed, side by side
+    wcat = weights.index_select(0, rows).view(nb, 2 * ci, 2 * co).transpose(1, 2).reshape(nb * 2 * co, 2 * ci)
+    d_e = gemm_nn_taps(lat if kind != 'l0' else lat[0], ZS_SPLIT, (hc, wc), taps, wcat, planes=planes if kind != 'l0' else None,
+                       timer_class='head_gemm_dgrad')
     return d_e.view(b, 2, hc, wc, 2, ci)
 
 

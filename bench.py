@@ -428,6 +428,9 @@ def main():
     # tensor sharing fails in hipIpcGetMemHandle).  Set before the first GPU call on EVERY path -- self-spawned ranks
     # inherit it, ranks started by an external launcher (the driver's torch.distributed.run) get it here.
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # hipGraph replay (config.latency): the runtime's AQL packet capture loses the order between memset nodes and the kernels
+    # behind them on this ROCm (vln-ver_amd/__init__.py); read when the HIP runtime starts, so set before any GPU call
+    os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))             # (nothing above this line touches the GPU)
     under_launcher = 'WORLD_SIZE' in os.environ
@@ -595,6 +598,12 @@ def main():
         if distributed:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         ms = float(dt) / args.latency_steps * 1e3
+        if graphed and not full:
+            # the replayed steps must have TRAINED: finite loss and parameters (a graph that silently produced garbage --
+            # vln-ver_amd/__init__.py -- would otherwise only show in the parity probe at the end)
+            assert torch.isfinite(small()).all() and all(torch.isfinite(p).all() for p in params), \
+                'non-finite loss / parameters after the replayed %d-viewpoint steps' % nb
+            opt.zero_grad(set_to_none=True)          # (the gradients live in the graph's pool: the next eager step makes its own)
         latency.append(dict(viewpoints_per_gpu_per_step=nb, steps=args.latency_steps, warmup=3,
                             graphed=graphed,
                             ms_per_step=round(ms, 3), viewpoints_per_s=round(nb * world / ms * 1e3, 2)))
@@ -650,10 +659,29 @@ def main():
                 traffic, src = measured_traffic(kernels, B)
                 obj = dict(kernel=name, bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                            frac=round(ach / HBM_PEAK_GBS, 4), traffic=int(traffic) if traffic else None,
-                           traffic_source=src, avg_launch_us=round(avg_ms * 1e3, 2),
+                           traffic_source=(None if src is None else '%s (committed PMC pass of this command on another box, '
+                                           'keyed to the sha256 of csrc/ver_sca.hip; not a measurement of this run)' % src),
+                           avg_launch_us=round(avg_ms * 1e3, 2),
                            launches=kt[name]['count'], algorithmic_bytes_per_launch=int(byts),
                            value_bytes_per_element=vbytes, viewpoints_per_launch=B, sigma_n=sigma_n)
                 if name == 'ver_sca_forward':
+                    # the zero fill of the rows the gather accumulates into (the reference's zeros_like inside the op,
+                    # spatial_cross_attention.py:139) runs on a side stream under the projection GEMMs: its duration there,
+                    # and what of it the launch stream still had to wait for in front of the gather (events on that stream
+                    # around the join) -- `frac_with_zero_fill` prices the unhidden part with the kernel
+                    zr, zw = kt.get('ver_sca_zero_rows'), kt.get('ver_sca_zero_wait')
+                    if zr and zw and zr['count'] and zw['count']:
+                        fl = kt.get('ver_event_floor')
+                        floor_ms = fl['ms'] / fl['count'] if fl and fl['count'] else 0.0
+                        join_ms = zw['ms'] / zw['count']
+                        unhidden_ms = max(0.0, join_ms - floor_ms)
+                        obj['zero_fill'] = dict(side_stream_us=round(zr['ms'] / zr['count'] * 1e3, 2), join_us=round(join_ms * 1e3, 2),
+                                                empty_bracket_us=round(floor_ms * 1e3, 2), unhidden_us=round(unhidden_ms * 1e3, 2),
+                                                launches=zr['count'], bytes=int(hit.zero_cnt.sum()) * 768 * 4,
+                                                note='zero fill of the rows the gather accumulates into, on a side stream under the '
+                                                     'projection GEMMs; join = events on the launch stream around the wait for it, '
+                                                     'unhidden = join - an empty event bracket')
+                        obj['frac_with_zero_fill'] = round(byts / ((avg_ms + unhidden_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     roof = obj
                 else:
                     others.append(obj)

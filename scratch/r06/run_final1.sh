@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+R=gpurun_out/r06; mkdir -p $R
+python -m pytest tests/ -x -q -m gpu --timeout 2400 > $R/gpu_suite2.log 2>&1; tail -3 $R/gpu_suite2.log
+python bench.py > $R/bench_default_a.json 2> $R/bench_default_a.err; echo "bench rc=$?"; tail -2 $R/bench_default_a.err

@@ -43,3 +43,9 @@ for _ in range(steps):
     step()
 torch.cuda.synchronize()
 print('B=%d graph=%d: %.3f ms per step' % (B, graph, (time.perf_counter() - t0) / steps * 1e3), flush=True)
+bad = [k for k, p in model.named_parameters() if not torch.isfinite(p).all()]
+print('non-finite parameters after the run:', len(bad), bad[:5], flush=True)
+if graph:
+    for i in range(3):
+        l = step(); torch.cuda.synchronize()
+        print('  replay loss %.6f grad norm %s' % (float(l), float(lift.grad_norm)), flush=True)

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# (before the first torch.cuda call of the session: see vln-ver_amd/__init__.py -- hipGraph replay and memset nodes on ROCm 7.2)
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tests', 'golden')):
     if p not in sys.path:

@@ -701,3 +701,36 @@ def test_graphed_lift_step_replays_the_eager_training_steps(autocast):
     models[1](*ins[1]).backward()
     opts[1].step()
     assert all(opts[1].state[p]['step'] == 6 for p in heads[1].parameters() if p.requires_grad)
+
+
+def test_graphed_lift_step_trains_for_many_replays():
+    """Regression (round 6): on ROCm 7.2 a replayed hipGraph does not keep memset nodes in front of the kernels behind them
+    unless the runtime's AQL packet capture is off (vln-ver_amd/__init__.py sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; our
+    launchers zero with kernels) -- from the SECOND replay on, d(offsets) of voxels seen by two cameras and the Linears' bias
+    gradients (PyTorch's multi-block reductions) came out as garbage and one non-finite element poisoned every parameter
+    through the clip norm.  Train mode (dropout on), bench.py's init and optimizer, twelve replays: every gradient norm
+    finite, the loss goes down, every parameter finite."""
+    import os
+    assert os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
+    syn, graphs, opt_mod = pkg('synthetic'), pkg('graphs'), pkg('optim')
+    torch.manual_seed(2)
+    head = pkg('registry').build_head(cases.vocc_head_cfg())
+    head.init_weights()
+    head = head.to(DEV).train()
+    lift = ('transformer.encoder.', 'transformer.level_embeds', 'transformer.cams_embeds', 'voxel_embedding.', 'up_sample.',
+            'occ_proj.', 'occ_branches.')
+    for k, p in head.named_parameters():
+        p.requires_grad_(k.startswith(lift))
+    model = _LiftModel(head, True)
+    params = [p for p in head.parameters() if p.requires_grad]
+    opt = opt_mod.ClipAdamW(params, lr=1e-4, weight_decay=0.01, max_norm=300.0)
+    w2p, org = syn.camera_batch(1, seed=1)
+    feats = T(syn.vit_features(1, seed=100)).to(DEV).permute(1, 0, 2, 3).contiguous()
+    gt = T(np.random.default_rng(7).integers(0, 17, size=(1, 504000))).to(DEV)
+    step = graphs.GraphedLiftStep(model, opt, feats, T(w2p).to(DEV), T(org).to(DEV), gt, warmup=1)
+    losses = []
+    for _ in range(12):
+        losses.append(float(step(*step.inputs)))
+        assert bool(torch.isfinite(step.grad_norm)), losses
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert all(bool(torch.isfinite(p).all()) for p in params)

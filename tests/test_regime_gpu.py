@@ -125,9 +125,9 @@ def test_training_step_at_192_viewpoints_equals_the_two_viewpoint_step(monkeypat
     monkeypatch.setattr(hip, 'gemm_nn_taps', lambda *a, **k: (calls.append(('fwd', a[0].shape)), real(*a, **k))[1])
     monkeypatch.setattr(hip, 'wgrad_tn_segments', lambda *a, **k: (calls.append(('wgrad', a[0].shape)), real_w(*a, **k))[1])
     loss, gb = _train_step(head, f, w, o, gt)
-    # the implicit-operand kernels did run: 1 + 4 + 4 forward products and as many weight gradients, layer 3's on the
-    # [4, 192, 2, 15, 15, 2, 768] lattice (345 600 rows)
-    assert sum(c[0] == 'fwd' for c in calls) == 9 and sum(c[0] == 'wgrad' for c in calls) == 9, calls
+    # the implicit-operand kernels did run: 1 + 4 + 4 forward products, one d(input) product per layer and 1 + 4 + 4 weight
+    # gradients, layer 3's on the [4, 192, 2, 15, 15, 2, 768] lattice (345 600 rows)
+    assert sum(c[0] == 'fwd' for c in calls) == 9 + 3 and sum(c[0] == 'wgrad' for c in calls) == 9, calls
     assert (4, B_BENCH, 2, 15, 15, 2, 768) in [tuple(c[1]) for c in calls]
     monkeypatch.setattr(ups, '_OWN_GEMM', False)
     n_before = len(calls)

@@ -258,8 +258,10 @@ extern "C" int ver_add_ln_backward(const float* grad_y, const void* grad_y_bf16,
     if (rc) return rc;
     VER_REQUIRE(grad_gamma && grad_beta, VER_EINVAL, "ver_add_ln_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_gamma, 0, C * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, C * sizeof(float), st);
+    int zrc = ver_zero_async(grad_gamma, C * sizeof(float), st);           // (kernel zero fills: ver_zero_async)
+    if (!zrc) zrc = ver_zero_async(grad_beta, C * sizeof(float), st);
+    if (zrc) return zrc;
+    hipError_t e = hipSuccess;
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_add_ln_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(grad_y && mean && rstd && grad_a && grad_residual, VER_EINVAL, "ver_add_ln_backward: null pointer argument");

@@ -8,6 +8,12 @@
 
 int ver_fail(int code, const char* fmt, ...);           // ver_abi.hip
 int ver_check_launch(const char* what);                 // ver_abi.hip
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) at `ptr` with a KERNEL on `stream` (ver_abi.hip).  Used instead of
+// hipMemsetAsync wherever a launcher may run under stream capture: in a replayed hipGraph (ROCm 7.2) the memset NODE of
+// ver_sca_backward did not reliably precede the kernel that accumulates into the buffer with atomics -- from the second
+// replay on the atomics met the previous replay's bytes (scratch/r06/graph_nan.py: non-finite d(offsets) of voxels seen by
+// two cameras).  A kernel node keeps the stream order.
+int ver_zero_async(void* ptr, size_t bytes, void* stream);
 
 #define VER_REQUIRE(cond, code, ...)                     \
     do {                                                 \

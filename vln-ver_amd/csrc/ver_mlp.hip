@@ -179,8 +179,10 @@ extern "C" int ver_ln_relu_backward(const void* x, const void* grad_y, const flo
     if (rc) return rc;
     VER_REQUIRE(grad_gamma && grad_beta, VER_EINVAL, "ver_ln_relu_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_gamma, 0, kW * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, kW * sizeof(float), st);
+    int zrc = ver_zero_async(grad_gamma, kW * sizeof(float), st);          // (kernel zero fills: ver_zero_async)
+    if (!zrc) zrc = ver_zero_async(grad_beta, kW * sizeof(float), st);
+    if (zrc) return zrc;
+    hipError_t e = hipSuccess;
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_ln_relu_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(grad_y && mean && rstd, VER_EINVAL, "ver_ln_relu_backward: null pointer argument");

@@ -723,7 +723,8 @@ extern "C" int ver_occ_mlp_backward(const void* x, const void* grad_logits, cons
     if (rc) return rc;
     VER_REQUIRE(param_grads, VER_EINVAL, "ver_occ_mlp_backward: null parameter-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW + kC) * sizeof(float), st);
+    if (int zrc = ver_zero_async(param_grads, (6 * kW + kC * kW + kC) * sizeof(float), st)) return zrc;   // (kernel: ver_zero_async)
+    hipError_t e = hipSuccess;
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(grad_logits && grad_x && (grad_a1 || !first_linear) && grad_a2 && h1, VER_EINVAL,
@@ -1632,7 +1633,8 @@ extern "C" int ver_occ_mlp_backward_fused_stats(const void* x, const void* grad_
                 "ver_occ_mlp_backward_fused: built for width %d / %d classes (got %d / %d)", kW, kC, width, classes);
     VER_REQUIRE(W2 && W3 && vectors && param_grads, VER_EINVAL, "ver_occ_mlp_backward_fused: null pointer argument");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(param_grads, 0, (6 * kW + kC * kW + kC + kW * kW) * sizeof(float), st);
+    if (int zrc = ver_zero_async(param_grads, (6 * kW + kC * kW + kC + kW * kW) * sizeof(float), st)) return zrc;   // (kernel: ver_zero_async)
+    hipError_t e = hipSuccess;
     if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_occ_mlp_backward_fused: memset: %s", hipGetErrorString(e));
     if (N == 0) return VER_OK;
     VER_REQUIRE(x && grad_logits && grad_x, VER_EINVAL, "ver_occ_mlp_backward_fused: null pointer argument");

@@ -2354,12 +2354,13 @@ extern "C" int ver_sca_backward(const void* value, int value_dtype, const float*
     const int nchunks = (Nq + kBwdChunk - 1) / kBwdChunk;
     hipStream_t st = (hipStream_t)stream;
     const size_t nsmall = (size_t)B * Nq * heads * points;
-    hipError_t e = hipMemsetAsync(grad_offsets, 0, nsmall * 2 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(grad_logits, 0, nsmall * sizeof(float), st);
-    if (e == hipSuccess && nchunks > 1 && grad_value_dtype == VER_F32)      // (the chunked two-kernel path flushes with atomics)
-        e = hipMemsetAsync(grad_value, 0, (size_t)B * Ncam * map_h * map_w * heads * head_dim * sizeof(float), st);
+    // (zero fills by kernel, not hipMemsetAsync: see ver_zero_async -- this launcher runs inside replayed hipGraphs)
+    rc = ver_zero_async(grad_offsets, nsmall * 2 * sizeof(float), st);
+    if (!rc) rc = ver_zero_async(grad_logits, nsmall * sizeof(float), st);
+    if (!rc && nchunks > 1 && grad_value_dtype == VER_F32)                  // (the chunked two-kernel path flushes with atomics)
+        rc = ver_zero_async(grad_value, (size_t)B * Ncam * map_h * map_w * heads * head_dim * sizeof(float), st);
     float* grad_value_f32 = reinterpret_cast<float*>(grad_value);          // (the two-kernel paths write fp32 only)
-    if (e != hipSuccess) return ver_fail(VER_ELAUNCH, "ver_sca_backward: memset: %s", hipGetErrorString(e));
+    if (rc) return rc;
     return dispatch_shape(head_dim, points, [&](auto hd, auto g, auto pp) {
         constexpr int HD = decltype(hd)::value, G = decltype(g)::value, P = decltype(pp)::value;
         if constexpr (P == 8 && HD % 32 == 0) {

@@ -128,11 +128,14 @@ class GraphedLiftStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            norm = None
             for _ in range(max(1, warmup)):                 # (at least one: the optimizer state must exist before the capture)
                 optimizer.zero_grad(set_to_none=True)
                 loss = model(*self.inputs)
                 loss.backward()
-                optimizer.step()
+                norm = optimizer.step()
+            self._clean_warmup = norm is not None and bool(torch.isfinite(norm))
+            self._unchecked = 3
             loss = None
             optimizer.zero_grad(set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
@@ -163,4 +166,14 @@ class GraphedLiftStep:
         self.optimizer.refresh()
         self.graph.replay()
         self.optimizer.replayed()
+        if self._unchecked:
+            # the first replays are checked (one synchronisation each): a replay that leaves a non-finite gradient norm behind
+            # after a clean capture step is the runtime's memset-node problem (vln-ver_amd/__init__.py), not the model's
+            self._unchecked -= 1
+            if not bool(torch.isfinite(self.grad_norm)) and self._clean_warmup:
+                raise RuntimeError(
+                    'GraphedLiftStep: the gradient norm of a replayed step is not finite although the eager warm-up steps were '
+                    'clean.  On ROCm 7.2 hipGraph replay needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment BEFORE the '
+                    'first GPU call of the process (memset nodes are not ordered against the kernels behind them otherwise); '
+                    'importing vln-ver_amd sets it, but only takes effect if HIP was not initialised earlier.')
         return self.loss

@@ -308,7 +308,12 @@ class SCAGatherFunction(Function):
         if prepared is not None:
             slots = prepared.slots
             assert slots.shape == (B, nq, heads * hd) and slots.dtype == torch.float32 and slots.is_contiguous()
-            torch.cuda.current_stream(slots.device).wait_event(prepared.done)      # (long done: it ran under the GEMMs)
+            # (long done: it ran under the GEMMs.  With a KernelTimer the join is bracketed by events on the launch stream:
+            #  what bench.py reports as the part of the zero fill that was NOT hidden)
+            with timed('ver_sca_zero_wait'):
+                torch.cuda.current_stream(slots.device).wait_event(prepared.done)
+            with timed('ver_event_floor'):          # (an empty bracket: what two event records cost by themselves)
+                pass
             flags |= 1                                                               # VER_SCA_ROWS_PREZEROED
         else:
             slots = torch.empty(B, nq, heads * hd, dtype=torch.float32, device=value.device)

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
+export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
 cd $GRAFT_REPO_ROOT
 R=gpurun_out/r06; mkdir -p $R
 for B in ${BATCHES:-1 8}; do

@@ -1,5 +1,5 @@
 """The regime the headline is measured in (bench.py: 192 viewpoints per step, bf16): everything else under ``-m gpu`` runs
-the head on <= 3 viewpoints, where ``ver_gemm_nn`` is not even selected (dense_heads/upsample.py: from 49 152 rows on) and
+the head on <= 3 viewpoints, where the own GEMM kernels are not even selected (dense_heads/upsample.py: from 14 000 rows on) and
 no operand reaches 2^31 elements.  Here
 
 * the head at B = 192 (96 x the two golden viewpoints) against the reference's own vectors (``head_vocc.npz``, reference

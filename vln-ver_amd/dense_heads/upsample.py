@@ -502,7 +502,7 @@ def _block_offsets(kind, ci, co, device):
     return _BLOCK_OFFSETS[key]
 
 
-# Implicit tap matrix (round 6): from this many rows on, the forward and weight-gradient GEMMs of a bf16 lattice layer read
+# Implicit tap matrix (round 6): from `_OWN_GEMM_MIN_ROWS` rows on, the forward and weight-gradient GEMMs of a bf16 lattice layer read
 # their A operand straight from the lattice (ver_gemm_nn_segments / ver_wgrad_tn_segments: a tap block of a row is the
 # contiguous channel vector of a neighbouring cell, fetched by the kernels' LDS-DMA) -- the tap matrix (10 GB for layer 3 at 192
 # viewpoints) is neither written nor kept for the backward pass; only d(input) still goes through an explicit matrix.  Below,
@@ -983,7 +983,9 @@ def gemm_timed(name, m, k, n):
 # 1 266-1 292 -> 1 312-1 338 TFLOP/s, layers 1 / 2 1 121-1 210 -> 1 310; occ_proj (K = 832) and the 8-viewpoint shapes are
 # faster in the library and stay there.  VER_OWN_GEMM=0: library everywhere.
 _OWN_GEMM = os.environ.get('VER_OWN_GEMM', '1') == '1'
-_OWN_GEMM_MIN_ROWS = 49152
+# (round 6: 14 000 instead of 49 152 -- with the implicit operands layer 3 of an eight-viewpoint step (14 400 rows) and layers 1-2 of a
+#  64-viewpoint one gain 0.5-1.6 %; 3 000 loses 9 % at eight viewpoints: too few tiles)
+_OWN_GEMM_MIN_ROWS = int(os.environ.get('VER_OWN_GEMM_MIN_ROWS', '14000'))
 # ... and the skinny products of the small-batch steps (config.latency: 450 / 1 800 rows at one viewpoint per step) cut into K
 # slices: the library's best recorded solution runs (450 x 38 400) x (38 400 x 1 536) in 144 us on 12 workgroups, the weight
 # matrix alone streams in 15

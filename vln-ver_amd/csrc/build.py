@@ -8,6 +8,7 @@ travels with the tree; it is never installed into site-packages.
 import os
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
@@ -17,6 +18,14 @@ HEADERS = ['ver_common.h', os.path.join('..', '..', 'include', 'ver_ops.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-munsafe-fp-atomics',
          '-Wall', '-Wno-unused-function']
 
+
+# Per-source device target features.  ver_occ_mlp.hip: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) -- hipcc
+# forms them from every float4 expression, and beside a matrix-core wave on the same SIMD one of them costs more issue time
+# than the two scalar instructions it replaces (k_occ_mlp_bwd_ws 30.2 -> 28.2 ms over 96.8 M rows, k_occ_mlp_fwd 7.2 -> 6.75;
+# scratch/r06/ubench/valu_cost.hip).  A function attribute would do it too, but then nothing un-attributed inlines into the
+# kernel.  The host pass does not know the feature and says so on stderr: that one line is filtered below.
+TARGET_FEATURES = {'ver_occ_mlp.hip': ['-packed-fp32-ops']}
+_HOST_PASS_NOISE = 'is not a recognized feature for this target'
 
 OBJ_DIR = os.path.join(HERE, 'build')
 CFLAGS = [f for f in FLAGS if f != '-shared']
@@ -72,13 +81,20 @@ def build_hip(force=False, verbose=True, defines=(), lib=None, asan=False):
         objs.append(obj)
         if force or _newer(obj, [path] + hdrs):
             cflags = [f for f in CFLAGS if f != '-O3'] + ASAN_FLAGS if asan else CFLAGS
-            cmd = [hipcc] + cflags + (['-D' + d for d in defines] if mytag.replace('_asan', '') else []) + ['-c', path, '-o', obj]
+            feats = [a for f in TARGET_FEATURES.get(src, ()) for a in ('-Xclang', '-target-feature', '-Xclang', f)]
+            cmd = [hipcc] + cflags + feats + (['-D' + d for d in defines] if mytag.replace('_asan', '') else []) + ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
+            err = tempfile.TemporaryFile(mode='w+') if feats else None
+            procs.append((cmd, subprocess.Popen(cmd, stderr=err), err))
+    for cmd, pr, err in procs:
+        rc = pr.wait()
+        if err is not None:
+            err.seek(0)
+            sys.stderr.write(''.join(ln for ln in err if _HOST_PASS_NOISE not in ln))
+            err.close()
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd)
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + (['-fsanitize=address', '-shared-libsan'] if asan else []) + objs + ['-o', lib]
     if verbose:
         print(' '.join(cmd), flush=True)

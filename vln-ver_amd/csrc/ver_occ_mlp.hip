@@ -1098,10 +1098,43 @@ constexpr int kWsVec0 = kW;                                      // b1 is not st
 constexpr size_t kWsLds = (size_t)9 * kWsTile * 2 + (size_t)2 * kWsRows * kNsDlLd * 2 + (kVecFloats - kWsVec0) * sizeof(float);
 }  // namespace
 
+#ifdef VER_WS_TIMELINE
+// Slot timeline of k_occ_mlp_bwd_ws (scratch/r06/ws_timeline.py; build with -DVER_WS_TIMELINE): s_memtime of every wave of
+// kWsTlProbes workgroups at the end of each slot's work (before the barrier) and behind the barrier, for kWsTlRounds rounds
+// from round kWsTlFirst on.  g_ws_tl[probe][wave][round][slot][2]; [probe][wave] start / end stamps in g_ws_tl_span.
+constexpr int kWsTlProbes = 8, kWsTlRounds = 16, kWsTlFirst = 200;
+__device__ long long g_ws_tl[kWsTlProbes * 8 * kWsTlRounds * 8 * 2];
+__device__ long long g_ws_tl_span[kWsTlProbes * 8 * 2];
+__device__ __forceinline__ int ws_tl_probe() { return (blockIdx.x % 29 == 3 && blockIdx.x / 29 < kWsTlProbes) ? (int)(blockIdx.x / 29) : -1; }
+#define WS_TL(k, slot, which)                                                                                       \
+    do {                                                                                                            \
+        const int pr_ = ws_tl_probe();                                                                              \
+        const long kk_ = (k) - kWsTlFirst;                                                                          \
+        if (pr_ >= 0 && kk_ >= 0 && kk_ < kWsTlRounds && (threadIdx.x & 63) == 0)                                   \
+            g_ws_tl[(((pr_ * 8 + (threadIdx.x >> 6)) * kWsTlRounds + kk_) * 8 + (slot)) * 2 + (which)] =            \
+                (long long)__builtin_amdgcn_s_memtime();                                                            \
+    } while (0)
+#define WS_SPAN(which)                                                                                              \
+    do {                                                                                                            \
+        const int pr_ = ws_tl_probe();                                                                              \
+        if (pr_ >= 0 && (threadIdx.x & 63) == 0)                                                                    \
+            g_ws_tl_span[(pr_ * 8 + (threadIdx.x >> 6)) * 2 + (which)] = (long long)__builtin_amdgcn_s_memtime();   \
+    } while (0)
+extern "C" int ver_ws_timeline_read(long long* slots, long long* span) {
+    hipError_t e = hipMemcpyFromSymbol(slots, HIP_SYMBOL(g_ws_tl), sizeof(long long) * kWsTlProbes * 8 * kWsTlRounds * 8 * 2);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_ws_tl_span), sizeof(long long) * kWsTlProbes * 8 * 2);
+}
+#else
+#define WS_TL(k, slot, which) do { } while (0)
+#define WS_SPAN(which) do { } while (0)
+#endif
+
 namespace {
 // Workgroup barrier that orders LDS traffic only: this wave's LDS operations are complete, global loads may stay in flight
 // across it (__syncthreads() also waits for vmcnt(0), which would serialise the row team's prefetch of the next block's x).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define WS_SLOT_END(k, n) do { WS_TL(k, n, 0); lds_barrier(); WS_TL(k, n, 1); } while (0)
 }  // namespace
 
 // CENTERED: the forward ran with VER_OCC_MLP_CENTERED (zero-mean LayerNorm inputs by construction): the two recomputed
@@ -1140,6 +1173,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
     const long nmine = blockIdx.x < nblk ? (nblk - 1 - blockIdx.x) / gridDim.x + 1 : 0;
     const long rounds = nmine / 2 + 1;
     __syncthreads();
+    WS_SPAN(0);
     if constexpr (ROWS4) {
         static_assert(!ROWS4 || (RSTD && CENTERED), "the 4-row mapping is built for the saved-statistics form");
         if (team == 0) {
@@ -1289,23 +1323,28 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (long k = 0; k < rounds; ++k) {
                 const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
                 const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
+#ifdef VER_WS_ABL_NOROW
+                for (int sl = 0; sl < 8; ++sl) lds_barrier();
+                continue;
+#endif
                 if (va) r0(sa, TA, DLs, blk_a);
-                lds_barrier();
+                WS_SLOT_END(k, 0);
                 if (vp) r6(sb, TB, blk_b);
-                lds_barrier();
+                WS_SLOT_END(k, 1);
                 if (va) r2(sa, TA);
-                lds_barrier();
+                WS_SLOT_END(k, 2);
                 if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
-                lds_barrier();
+                WS_SLOT_END(k, 3);
                 if (va) r4(sa, TA);
-                lds_barrier();
+                WS_SLOT_END(k, 4);
                 if (vb) r2(sb, TB);
-                lds_barrier();
+                WS_SLOT_END(k, 5);
                 if (va) r6(sa, TA, blk_a + 2 * (long)gridDim.x);
-                lds_barrier();
+                WS_SLOT_END(k, 6);
                 if (vb) r4(sb, TB);
-                lds_barrier();
+                WS_SLOT_END(k, 7);
             }
+            WS_SPAN(1);
             return;
         }
     }
@@ -1572,24 +1611,25 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int sl = 0; sl < 8; ++sl) lds_barrier();
 #else
             if (vp) f5(TB);
-            lds_barrier();
+            WS_SLOT_END(k, 0);
             if (va) f1(TA);
-            lds_barrier();
+            WS_SLOT_END(k, 1);
             if (vp) f7(TB);
-            lds_barrier();
+            WS_SLOT_END(k, 2);
             if (va) f3(TA, DLA);
-            lds_barrier();
+            WS_SLOT_END(k, 3);
             if (vb) f1(TB);
-            lds_barrier();
+            WS_SLOT_END(k, 4);
             if (va) f5(TA);
-            lds_barrier();
+            WS_SLOT_END(k, 5);
             if (vb) f3(TB, DLB);
-            lds_barrier();
+            WS_SLOT_END(k, 6);
             if (va) f7(TA);
-            lds_barrier();
+            WS_SLOT_END(k, 7);
 #endif
         }
     }
+    WS_SPAN(1);
     // ---- parameter gradients: one atomic per element and workgroup
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {

@@ -72,3 +72,16 @@ for s in range(NS):
 print('round| row work %6.0f / %6.0f | feature work %6.0f / %6.0f | slots %6.0f ticks = %.2f us' % (tot[0], tot[1], tot[2], tot[3], tot[4], tot[4] * us))
 print('share of a round: row team working %.2f, feature team working %.2f; slot = max(slowest row wave, slowest feature wave) would be %.0f ticks'
       % (tot[0] / tot[4], tot[2] / tot[4], sum(max(work[:, :4, :, s].max(axis=1).mean(), work[:, 4:, :, s].max(axis=1).mean()) for s in range(NS))))
+
+if hasattr(L, 'ver_ws_timeline_fine_read'):
+    fine = (ctypes.c_longlong * (NP * NW * NR * 8))()
+    assert L.ver_ws_timeline_fine_read(fine) == 0
+    f = np.array(list(fine), dtype=np.int64).reshape(NP, NW, NR, 8)[:, :4, 1:]          # row team, rounds 1..
+    rel = flat.reshape(NP, NW, NR, NS, 2)[:, :4, 1:]
+    for name, base, slot in (('r4(A) LN2 bwd', 0, 4), ('r6(B) LN1 bwd', 4, 1)):
+        t = f[..., base:base + 4].astype(np.float64)
+        start = rel[..., slot - 1, 1].astype(np.float64)            # release of the previous slot
+        end = rel[..., slot, 0].astype(np.float64)
+        print('%s: entry %+5.0f | reads + masks + sums %5.0f | DPP reductions %5.0f | output %5.0f | to the end of the step %5.0f'
+              % (name, (t[..., 0] - start).mean(), (t[..., 1] - t[..., 0]).mean(), (t[..., 2] - t[..., 1]).mean(),
+                 (t[..., 3] - t[..., 2]).mean(), (end - t[..., 3]).mean()))

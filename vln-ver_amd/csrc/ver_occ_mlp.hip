@@ -1088,11 +1088,23 @@ __global__ __launch_bounds__(NW * 64) void k_occ_mlp_bwd_ns(const __bf16* __rest
 //     slot     0      1      2      3      4      5      6      7          (one workgroup barrier after each)
 //     rows     A.0    B.6    A.2    B.0    A.4    B.2    A.6    B.4
 //     features B.5    A.1    B.7    A.3    B.1    A.5    B.3    A.7
-// Steps of a block: 0 LN1 fwd | 1 a2 = W2 h1 | 2 LN2 fwd | 3 d(h2), d(W3) | 4 LN2 bwd | 5 sums, d(W2), d(h1) | 6 LN1 bwd | 7 LN1 sums.
-// LDS: per block set T0 h1, T1 a2 -> d(h2) -> d(z2)n2, T2 h2 -> d(z2) -> d(z1), T3 d(a2) -> d(z1)n1, DL; ONE shared tile for
-// d(h1) (A writes it in slot 5 and reads it in slot 6, B in slots 0 and 1): 9 x 17 KB + 4 KB + vectors = 159.6 KB.
+// Steps of a block: 0 LN1 fwd | 1 a2 = W2 h1 | 2 LN2 fwd | 3 d(h2), d(W3) | 4 LN2 bwd | 5 LN2 sums, d(h1) | 6 LN1 bwd |
+// 7 LN1 sums, d(W2), store d(x)  (d(W2) in step 5 with -DVER_WS_DW2_STEP7=0: the same time on the box that measured both).
+// LDS: per block set T0 h1, T1 a2 -> d(h2) -> n2 -> n1, T2 h2 -> d(z2) -> d(z1), T3 d(a2), DL; ONE shared tile T4 for d(h1),
+// which step 6 turns into d(x) in place (A writes it in slot 5, rewrites it in slot 6, the feature team stores it in slot 7;
+// B in slots 0, 1 and 3): 9 x 17 KB + 4 KB + vectors = 159.6 KB.
+// Round 6 (profiles/r06_occ_mlp_bwd_timeline.txt has the slot timeline before and after): the kernel is the VALU work of the
+// ROW team -- one wave per SIMD issues an instruction every 6-8 cycles whatever it is -- so that team lost instructions and
+// everything that is not arithmetic: the ReLU mask is a 16-bit integer product with the ReLU's own output, the LayerNorm
+// backward two fused multiply-adds per value, global operands go through per-block buffer resources (no selects, no 64-bit
+// lane arithmetic), no packed fp32 (build.py), d(x) leaves through the shared tile and the feature team, and the two
+// s_waitcnt vmcnt(0) of a round are written where they cost nothing.  29.3 -> 24.8-25.7 ms over 96.8 M rows.
 namespace {
 constexpr int kWsRows = 64;
+#ifndef VER_WS_DW2_STEP7
+#define VER_WS_DW2_STEP7 1
+#endif
+constexpr bool kWsDw2InStep7 = VER_WS_DW2_STEP7;       // d(W2) in step 7 (beside the row team's heavy LN2 backward) or in step 5
 constexpr int kWsTile = kWsRows * kNsLd;
 constexpr int kWsVec0 = kW;                                      // b1 is not staged (folded mode)
 constexpr size_t kWsLds = (size_t)9 * kWsTile * 2 + (size_t)2 * kWsRows * kNsDlLd * 2 + (kVecFloats - kWsVec0) * sizeof(float);
@@ -1120,12 +1132,25 @@ __device__ __forceinline__ int ws_tl_probe() { return (blockIdx.x % 29 == 3 && b
         if (pr_ >= 0 && (threadIdx.x & 63) == 0)                                                                    \
             g_ws_tl_span[(pr_ * 8 + (threadIdx.x >> 6)) * 2 + (which)] = (long long)__builtin_amdgcn_s_memtime();   \
     } while (0)
+__device__ long long g_ws_tl_fine[kWsTlProbes * 8 * kWsTlRounds * 8];
+#define WS_TLF(k, idx)                                                                                              \
+    do {                                                                                                            \
+        const int pr_ = ws_tl_probe();                                                                              \
+        const long kk_ = (k) - kWsTlFirst;                                                                          \
+        if (pr_ >= 0 && kk_ >= 0 && kk_ < kWsTlRounds && (threadIdx.x & 63) == 0 && (idx) < 8)                      \
+            g_ws_tl_fine[((pr_ * 8 + (threadIdx.x >> 6)) * kWsTlRounds + kk_) * 8 + (idx)] =                        \
+                (long long)__builtin_amdgcn_s_memtime();                                                            \
+    } while (0)
+extern "C" int ver_ws_timeline_fine_read(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_tl_fine), sizeof(long long) * kWsTlProbes * 8 * kWsTlRounds * 8);
+}
 extern "C" int ver_ws_timeline_read(long long* slots, long long* span) {
     hipError_t e = hipMemcpyFromSymbol(slots, HIP_SYMBOL(g_ws_tl), sizeof(long long) * kWsTlProbes * 8 * kWsTlRounds * 8 * 2);
     if (e != hipSuccess) return (int)e;
     return (int)hipMemcpyFromSymbol(span, HIP_SYMBOL(g_ws_tl_span), sizeof(long long) * kWsTlProbes * 8 * 2);
 }
 #else
+#define WS_TLF(k, idx) do { } while (0)
 #define WS_TL(k, slot, which) do { } while (0)
 #define WS_SPAN(which) do { } while (0)
 #endif
@@ -1192,36 +1217,48 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             }
             struct Row4 {
                 bf16x8 xh1[4], xh2[4];
-                float rs1[4], rs2[4];
-                long r0;
+                f32x4 rsv[2];                   // saved 1/std of the block in flight: {LN1, LN2} of rows 2j, 2j + 1
             };
-            Row4 sa, sb;
-            // ONE operand buffer for both blocks: A's step 0 (slot 0) consumes it and requests B's rows, B's step 0 (slot 3)
-            // consumes those and requests the next round's A rows -- three and five slots of flight
+            // ONE operand buffer for both blocks (the register file has no room for two): A's step 0 (slot 0) consumes it and
+            // requests B's rows, B's step 0 (slot 3) consumes those and requests the next round's A rows -- three and five
+            // slots of flight
             bf16x8 xn[4], dln;
-            bool okx[4], okd;               // rows past N (or of a block this workgroup does not have) read as zeros: no gradient
+            Row4 sa, sb;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const int dlrow = lane >> 1, dlh = lane & 1;            // d(logits) staging: lanes 0-31 of a wave, 16 rows x 2 halves
-            // (unconditional loads from clamped rows: loads under a branch make the compiler wait for vmcnt(0) everywhere)
-            auto prefetch = [&](long blk, bool valid) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long rn = blk * kWsRows + rbase + i;
-                    okx[i] = valid && rn < N;
-                    xn[i] = *reinterpret_cast<const bf16x8*>(x + (okx[i] ? rn : N - 1) * kW + 8 * fc);
-                }
-                const long rd = blk * kWsRows + 16 * q + dlrow;
-                okd = valid && rd < N;
-                dln = *reinterpret_cast<const bf16x8*>(dlog + (okd ? rd : N - 1) * kC + 8 * dlh);
+            // Global operands go through ONE BUFFER RESOURCE PER BLOCK (base = the block's first row, size = its rows below N,
+            // both wave-uniform): a lane's byte offsets into a block never change, rows past N -- or a whole block this
+            // workgroup does not have -- read as zeros and are not written, with no select, no branch and no 64-bit address
+            // arithmetic per lane (they were a quarter of the instructions of step 0 and a tenth of step 6).
+            const unsigned ones16 = 0x00010001u;
+            const int xoff = (rbase * kW + 8 * fc) * 2, dloff = ((16 * q + dlrow) * kC + 8 * dlh) * 2, rsoff = rbase * 8;
+            const int nfull = (int)(N / kWsRows), ntail = (int)(N % kWsRows);      // (block ids fit an int: N < 2^37)
+            auto block_rsrc = [&](const void* base, long blk, int row_bytes) {
+                const int b = blk < nblk ? (int)blk : nfull + 1;                // past the end: no rows
+                const int rows = b < nfull ? kWsRows : (b == nfull ? ntail : 0);
+                return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)base + (long)b * (kWsRows * row_bytes)), 0, rows * row_bytes,
+                                                         0x00020000);
             };
+            // (the loads' results are bit_cast as a WHOLE: this hipcc compiles __builtin_bit_cast(float, v.y) of a vector element
+            //  as a read of element 0, and an implicit conversion of the builtin's result to an ext_vector_type as a splat)
+            auto prefetch = [&](long blk) {
+                const __amdgpu_buffer_rsrc_t rx = block_rsrc(x, blk, kW * 2), rd = block_rsrc(dlog, blk, kC * 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xn[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + i * kW * 2, 0, 0));
+                dln = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, dloff, 0, 0));
+            };
+            // The saved 1/std of a state's NEXT block are requested at the end of its step 6, straight into the registers that
+            // step has just used for the last time (requested earlier they need a second set, and the register file is full;
+            // 1/std of rows past N: 0 -- the row contributes nothing).  First use: the state's step 0, one or two slots later.
             auto prefetch_rs = [&](Row4& st, long blk) {
+                const __amdgpu_buffer_rsrc_t rr = block_rsrc(rstd, blk, 8);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const long rn = blk * kWsRows + rbase + i;
-                    const float2 v = *reinterpret_cast<const float2*>(rstd + 2 * (rn < N ? rn : N - 1));
-                    st.rs1[i] = v.x;
-                    st.rs2[i] = v.y;
-                }
+                for (int j = 0; j < 2; ++j)
+                    st.rsv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rsoff + 16 * j, 0, 0));
             };
+#define WS_RS1(st) {st.rsv[0].x, st.rsv[0].z, st.rsv[1].x, st.rsv[1].z}
+#define WS_RS2(st) {st.rsv[0].y, st.rsv[0].w, st.rsv[1].y, st.rsv[1].w}
             // LayerNorm forward of the lane's 4 x 8 values with the saved 1/std: n = v rs (kept as bf16), y = n gamma + beta
             // from the ROUNDED n, h = relu(y) -> tile
             auto ln_fwd4 = [&](const bf16x8 (&xin)[4], const float (&rs)[4], const f32x4 (&gm)[2], const f32x4 (&bt)[2],
@@ -1229,7 +1266,6 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     xh[i] = pack8(unpack_half(xin[i], 0) * rs[i], unpack_half(xin[i], 1) * rs[i]);
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     u32x4 raw = __builtin_bit_cast(u32x4, xh[i]);
                     asm("" : "+v"(raw));                      // (see ln_relu_nat: keeps the pack + unpack from being seen through)
                     xh[i] = __builtin_bit_cast(bf16x8, raw);
@@ -1237,53 +1273,79 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                     *reinterpret_cast<bf16x8*>(dst + (rbase + i) * kNsLd + 8 * fc) = relu_packed(pack8(y0, y1));
                 }
             };
-            // LayerNorm + ReLU backward: d = gradient w.r.t. the post-ReLU values (4 rows x 8), xh = kept normalised values.
-            // dz -> pz tile, n -> pn tile (the feature team forms their row sums), d(pre-LayerNorm) -> out (row pitch ldo)
-            auto ln_bwd4 = [&](const bf16x8 (&din)[4], const bf16x8 (&xh)[4], const float (&rs)[4], const f32x4 (&gm)[2],
-                               const f32x4 (&bt)[2], __bf16* pz, __bf16* pn, __bf16* out, long ldo, const bool (&ok)[4]) {
-                f32x4 dg[4][2];
+            // LayerNorm + ReLU backward: din = gradient w.r.t. the post-ReLU values (4 rows x 8), hin = those post-ReLU values
+            // themselves (still in their tile), xh = kept normalised values.  d(z) -> pz tile, n -> pn tile (the feature team
+            // forms their row sums), d(pre-LayerNorm) -> put(i, 8 values of row i).
+            //   * the ReLU mask comes from the ReLU's OUTPUT, as packed 16-bit integers: h is a bf16 in [+0, inf), so min(h, 1)
+            //     as u16 is 0 / 1 and d(z) = d * min(h, 1) as a 16-bit INTEGER product is d or 0 -- already the packed bf16 the
+            //     tile wants: one instruction per value where recomputing y = n gamma + beta, comparing, selecting and
+            //     re-packing took 3.5;
+            //   * a = (dg - m1 - n m2) rs is evaluated as dg rs + (n k2 + k1) with k1 = -m1 rs, k2 = -m2 rs per row: two fused
+            //     multiply-adds per value instead of four operations.
+            long tl_k = 0;
+            int tl_base = 0;
+            (void)tl_k; (void)tl_base;
+            auto ln_bwd4 = [&](const bf16x8 (&din)[4], const bf16x8 (&hin)[4], const bf16x8 (&xh)[4], const float (&rs)[4],
+                               const f32x4 (&gm)[2], __bf16* pz, __bf16* pn, auto&& put) {
+                WS_TLF(tl_k, tl_base + 0);
+                f32x4 dg[4][2], nn[4][2];
                 float s1[4], s2[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f32x4 dz[2];
-                    s1[i] = s2[i] = 0.0f;
+                    const u32x4 hw = __builtin_bit_cast(u32x4, hin[i]), dw = __builtin_bit_cast(u32x4, din[i]);
+                    u32x4 zw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // (as instructions: written as vector code the compiler turns min(h, 1) into two 16-bit compares,
+                        //  two selects and a byte permute per pair)
+                        unsigned t;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(hw[j]), "v"(ones16));
+                        asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(t) : "v"(dw[j]), "v"(t));
+                        zw[j] = t;
+                    }
+                    const bf16x8 dz = __builtin_bit_cast(bf16x8, zw);
+                    *reinterpret_cast<bf16x8*>(pz + (rbase + i) * kNsLd + 8 * fc) = dz;
+                    *reinterpret_cast<bf16x8*>(pn + (rbase + i) * kNsLd + 8 * fc) = xh[i];
+                    float sa1 = 0.0f, sb1 = 0.0f, sa2 = 0.0f, sb2 = 0.0f;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const f32x4 n = unpack_half(xh[i], h), d = unpack_half(din[i], h);
-                        const f32x4 y = n * gm[h] + bt[h];
-                        dz[h].x = y.x > 0.0f ? d.x : 0.0f;
-                        dz[h].y = y.y > 0.0f ? d.y : 0.0f;
-                        dz[h].z = y.z > 0.0f ? d.z : 0.0f;
-                        dz[h].w = y.w > 0.0f ? d.w : 0.0f;
-                        dg[i][h] = dz[h] * gm[h];
-                        s1[i] += (dg[i][h].x + dg[i][h].y) + (dg[i][h].z + dg[i][h].w);
-                        const f32x4 dn = dg[i][h] * n;
-                        s2[i] += (dn.x + dn.y) + (dn.z + dn.w);
+                        nn[i][h] = unpack_half(xh[i], h);
+                        dg[i][h] = unpack_half(dz, h) * gm[h];
+                        sa1 += dg[i][h].x + dg[i][h].y;
+                        sb1 += dg[i][h].z + dg[i][h].w;
+                        sa2 = __builtin_fmaf(dg[i][h].x, nn[i][h].x, sa2);
+                        sb2 = __builtin_fmaf(dg[i][h].y, nn[i][h].y, sb2);
+                        sa2 = __builtin_fmaf(dg[i][h].z, nn[i][h].z, sa2);
+                        sb2 = __builtin_fmaf(dg[i][h].w, nn[i][h].w, sb2);
                     }
-                    *reinterpret_cast<bf16x8*>(pz + (rbase + i) * kNsLd + 8 * fc) = pack8(dz[0], dz[1]);
-                    *reinterpret_cast<bf16x8*>(pn + (rbase + i) * kNsLd + 8 * fc) = xh[i];
+                    s1[i] = sa1 + sb1;
+                    s2[i] = sa2 + sb2;
                 }
+                WS_TLF(tl_k, tl_base + 1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     s1[i] = group_sum<16>(s1[i]);
                     s2[i] = group_sum<16>(s2[i]);
                 }
+                WS_TLF(tl_k, tl_base + 2);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float m1 = s1[i] * (1.0f / kW), m2 = s2[i] * (1.0f / kW);
-                    const f32x4 a = (dg[i][0] - m1 - unpack_half(xh[i], 0) * m2) * rs[i];
-                    const f32x4 b = (dg[i][1] - m1 - unpack_half(xh[i], 1) * m2) * rs[i];
-                    if (ok[i]) *reinterpret_cast<bf16x8*>(out + (long)i * ldo) = pack8(a, b);
-                }
-            };
-            const bool all4[4] = {true, true, true, true};
-            auto r0 = [&](Row4& st, __bf16* T, __bf16* DL, long blk) {
-                st.r0 = blk * kWsRows + rbase;
-                bf16x8 xr[4];
+                    const float k1 = -(s1[i] * (1.0f / kW)) * rs[i], k2 = -(s2[i] * (1.0f / kW)) * rs[i];
+                    f32x4 a[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xr[i] = okx[i] ? xn[i] : z8;
+                    for (int h = 0; h < 2; ++h) {
+                        a[h].x = __builtin_fmaf(dg[i][h].x, rs[i], __builtin_fmaf(nn[i][h].x, k2, k1));
+                        a[h].y = __builtin_fmaf(dg[i][h].y, rs[i], __builtin_fmaf(nn[i][h].y, k2, k1));
+                        a[h].z = __builtin_fmaf(dg[i][h].z, rs[i], __builtin_fmaf(nn[i][h].z, k2, k1));
+                        a[h].w = __builtin_fmaf(dg[i][h].w, rs[i], __builtin_fmaf(nn[i][h].w, k2, k1));
+                    }
+                    put(i, pack8(a[0], a[1]));
+                }
+                WS_TLF(tl_k, tl_base + 3);
+            };
+            auto r0 = [&](Row4& st, __bf16* T, __bf16* DL, long blk) {
                 if (lane < 32) {
-                    bf16x8 dl = okd ? dln : z8;
+                    bf16x8 dl = dln;
                     if (gscale != 1.0f) {        // (wave-uniform) d(logits) arrives unscaled: ver_focal_loss_forward_grad
                         const f32x4 lo = __builtin_convertvector(__builtin_shufflevector(dl, dl, 0, 1, 2, 3), f32x4) * gscale;
                         const f32x4 hi = __builtin_convertvector(__builtin_shufflevector(dl, dl, 4, 5, 6, 7), f32x4) * gscale;
@@ -1291,35 +1353,53 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                     }
                     *reinterpret_cast<bf16x8*>(DL + (16 * q + dlrow) * kNsDlLd + 8 * dlh) = dl;
                 }
-                const long nxt = blk + (long)gridDim.x;             // the block whose step 0 comes next (the other set)
-                prefetch(nxt, nxt < nblk);
-                ln_fwd4(xr, st.rs1, g1v, b1v, st.xh1, T);
+                const float rs[4] = WS_RS1(st);
+                ln_fwd4(xn, rs, g1v, b1v, st.xh1, T);
+                // (requested AFTER the last use of the buffer: issued first, the loads went to fresh registers and the step ended
+                //  with s_waitcnt vmcnt(0) + 14 moves into the buffer's own -- a full HBM round trip in every step 0)
+                prefetch(blk + (long)gridDim.x);                    // the block whose step 0 comes next (the other set)
             };
             auto r2 = [&](Row4& st, __bf16* T) {                                      // a2 (T1) -> LN2 + ReLU -> h2 (T2)
                 bf16x8 xr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const bf16x8*>(T + kWsTile + (rbase + i) * kNsLd + 8 * fc);
-                ln_fwd4(xr, st.rs2, g2v, b2v, st.xh2, T + 2 * kWsTile);
+                const float rs[4] = WS_RS2(st);
+                ln_fwd4(xr, rs, g2v, b2v, st.xh2, T + 2 * kWsTile);
             };
-            auto r4 = [&](Row4& st, __bf16* T) {                                      // d(h2) (T1) -> LN2 bwd -> d(a2) T3, d(z2) T2, n2 T1
-                bf16x8 d[4];
+            auto r4 = [&](Row4& st, __bf16* T) {                 // d(h2) (T1), h2 (T2) -> LN2 bwd -> d(a2) T3, d(z2) T2, n2 T1
+                bf16x8 d[4], h[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const bf16x8*>(T + kWsTile + (rbase + i) * kNsLd + 8 * fc);
-                ln_bwd4(d, st.xh2, st.rs2, g2v, b2v, T + 2 * kWsTile, T + kWsTile, T + 3 * kWsTile + rbase * kNsLd + 8 * fc, kNsLd, all4);
+                for (int i = 0; i < 4; ++i) {
+                    d[i] = *reinterpret_cast<const bf16x8*>(T + kWsTile + (rbase + i) * kNsLd + 8 * fc);
+                    h[i] = *reinterpret_cast<const bf16x8*>(T + 2 * kWsTile + (rbase + i) * kNsLd + 8 * fc);
+                }
+                __bf16* const out = T + 3 * kWsTile + rbase * kNsLd + 8 * fc;
+                const float rs[4] = WS_RS2(st);
+                ln_bwd4(d, h, st.xh2, rs, g2v, T + 2 * kWsTile, T + kWsTile,
+                        [&](int i, bf16x8 v) { *reinterpret_cast<bf16x8*>(out + i * kNsLd) = v; });
             };
-            auto r6 = [&](Row4& st, __bf16* T, long blk_next) {                       // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, n1 T3
-                bf16x8 d[4];
+            auto r6 = [&](Row4& st, __bf16* T, long blk_next) {  // d(h1) (T4), h1 (T0) -> LN1 bwd -> d(x) T4 (in place); d(z1) T2, n1 T1
+                bf16x8 d[4], h[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const bf16x8*>(T4 + (rbase + i) * kNsLd + 8 * fc);
-                const bool ok[4] = {st.r0 < N, st.r0 + 1 < N, st.r0 + 2 < N, st.r0 + 3 < N};
-                ln_bwd4(d, st.xh1, st.rs1, g1v, b1v, T + 2 * kWsTile, T + 3 * kWsTile, dx + st.r0 * kW + 8 * fc, kW, ok);
-                prefetch_rs(st, blk_next < nblk ? blk_next : nblk - 1);
+                for (int i = 0; i < 4; ++i) {
+                    d[i] = *reinterpret_cast<const bf16x8*>(T4 + (rbase + i) * kNsLd + 8 * fc);
+                    h[i] = *reinterpret_cast<const bf16x8*>(T + (rbase + i) * kNsLd + 8 * fc);
+                }
+                // d(x) replaces d(h1) in the shared tile, lane for lane; the FEATURE team stores it in its next light slot
+                // (four 1-KB stores cost this wave ~500 cycles of a slot it is the critical path of)
+                __bf16* const out = T4 + rbase * kNsLd + 8 * fc;
+                const float rs[4] = WS_RS1(st);
+                ln_bwd4(d, h, st.xh1, rs, g1v, T + 2 * kWsTile, T + kWsTile,
+                        [&](int i, bf16x8 v) { *reinterpret_cast<bf16x8*>(out + i * kNsLd) = v; });
+#ifndef VER_WS_ABL_NORS
+                prefetch_rs(st, blk_next);
+#endif
             };
             __bf16* const TA = tiles;
             __bf16* const TB = tiles + 4 * kWsTile;
-            prefetch(blockIdx.x, blockIdx.x < nblk);
-            prefetch_rs(sa, blockIdx.x < nblk ? (long)blockIdx.x : nblk - 1);
-            prefetch_rs(sb, blockIdx.x + (long)gridDim.x < nblk ? blockIdx.x + (long)gridDim.x : nblk - 1);
+            prefetch(blockIdx.x);
+            prefetch_rs(sa, blockIdx.x);
+            prefetch_rs(sb, blockIdx.x + (long)gridDim.x);
             for (long k = 0; k < rounds; ++k) {
                 const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
                 const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
@@ -1327,15 +1407,24 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 for (int sl = 0; sl < 8; ++sl) lds_barrier();
                 continue;
 #endif
+                // Everything in flight here is what step 0 of A is about to use (its rows since slot 3, its 1/std since slot
+                // 6).  Said ONCE and unconditionally: the compiler cannot count loads across the conditional steps of a round,
+                // and without this it waits for vmcnt(0) at the first use of B's 1/std in slot 1 -- behind the rows requested
+                // in slot 0, a full HBM round trip in the longest step of the round.
+                __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
                 if (va) r0(sa, TA, DLs, blk_a);
                 WS_SLOT_END(k, 0);
+                tl_k = k; tl_base = 4;
                 if (vp) r6(sb, TB, blk_b);
                 WS_SLOT_END(k, 1);
                 if (va) r2(sa, TA);
                 WS_SLOT_END(k, 2);
+                __builtin_amdgcn_s_waitcnt(0x0F70);                 // (the same for B: its rows since slot 0, its 1/std since slot 1)
                 if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
                 WS_SLOT_END(k, 3);
+                tl_base = 0;
                 if (va) r4(sa, TA);
+                tl_base = 8;
                 WS_SLOT_END(k, 4);
                 if (vb) r2(sb, TB);
                 WS_SLOT_END(k, 5);
@@ -1421,7 +1510,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             ns_ln_relu_bwd<true, true>(d, st.xh2, st.rs2, sv_n + 4 * kW, sv_n + 5 * kW, T + 3 * kWsTile + myrow * kNsLd + 8 * g,
                            T + 2 * kWsTile + myrow * kNsLd + 8 * g, T + kWsTile + myrow * kNsLd + 8 * g, true);
         };
-        auto r6 = [&](RowState& st, __bf16* T, long blk_next) {                   // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, d(z1)n1 T3
+        auto r6 = [&](RowState& st, __bf16* T, long blk_next) {                   // d(h1) (T4) -> LN1 bwd -> d(x); d(z1) T2, n1 T1
             f32x4 d[8];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1430,7 +1519,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 d[2 * t + 1] = unpack_half(v, 1);
             }
             ns_ln_relu_bwd<true, true>(d, st.xh1, st.rs1, sv_n + kW, sv_n + 2 * kW, dx + st.r * kW + 8 * g, T + 2 * kWsTile + myrow * kNsLd + 8 * g,
-                           T + 3 * kWsTile + myrow * kNsLd + 8 * g, st.ok);
+                           T + kWsTile + myrow * kNsLd + 8 * g, st.ok);
             prefetch_rs(st, blk_next < nblk ? blk_next : nblk - 1);
         };
         __bf16* const TA = tiles;
@@ -1545,7 +1634,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             for (int ft = 0; ft < OT; ++ft) dw3[ft] = mfma(a, ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ft, c, g), dw3[ft]);
         }
     };
-    auto f5 = [&](__bf16* T) {                                            // LN2 row sums, d(W2), d(h1) = W2^T d(a2) -> T4
+    auto f5 = [&](__bf16* T) {                                            // LN2 row sums, d(h1) = W2^T d(a2) -> T4
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 ada[OT];
@@ -1560,12 +1649,14 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 sgam2[ot] = mfma(adz, ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam2[ot]);
 #endif
             }
+            if constexpr (!kWsDw2InStep7) {
 #pragma unroll
-            for (int kt = 0; kt < 8; ++kt) {
-                const bf16x8 b = ns_tr_frag(T, kNsLd, 32 * ks, 16 * kt, c, g);
+                for (int kt = 0; kt < 8; ++kt) {
+                    const bf16x8 b = ns_tr_frag(T, kNsLd, 32 * ks, 16 * kt, c, g);
 #pragma unroll
-                for (int ot = 0; ot < OT; ++ot) dw2[ot][kt] = mfma(ada[ot], b, dw2[ot][kt]);
-                if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int ot = 0; ot < OT; ++ot) dw2[ot][kt] = mfma(ada[ot], b, dw2[ot][kt]);
+                    if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
 #pragma unroll
@@ -1585,19 +1676,50 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto f7 = [&](__bf16* T) {                                            // LN1 row sums from T2, T3
-#ifdef VER_WS_ABL_NOSUMS
-        (void)T;
-        return;
-#endif
+    // d(W2) += d(a2)^T h1 runs HERE, not in step 5 beside the product that step 6 waits for: nothing downstream reads it, T3
+    // (d(a2)) and T0 (h1) stay untouched until the block's set starts over (step 6 puts n1 into T1), and step 7 was 0.5 k
+    // cycles of a slot the row team needs 2 k for, while step 5 (3.1 k) had the row team idle for 1.5 k.
+    auto f7 = [&](__bf16* T) {                                            // LN1 row sums from T2, T1; d(W2) from T3, T0
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 ada[OT];
 #pragma unroll
             for (int ot = 0; ot < OT; ++ot) {
+                if constexpr (kWsDw2InStep7) ada[ot] = ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
+#ifndef VER_WS_ABL_NOSUMS
                 const bf16x8 adz = ns_tr_frag(T + 2 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g);
                 sbet1[ot] = mfma(adz, ones, sbet1[ot]);
-                sgam1[ot] = mfma(adz, ns_tr_frag(T + 3 * kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam1[ot]);      // diagonal, as above
+                sgam1[ot] = mfma(adz, ns_tr_frag(T + kWsTile, kNsLd, 32 * ks, f0 + 16 * ot, c, g), sgam1[ot]);      // diagonal, as in step 5
+#endif
             }
+            if constexpr (kWsDw2InStep7) {
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) {
+                    const bf16x8 b = ns_tr_frag(T, kNsLd, 32 * ks, 16 * kt, c, g);
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) dw2[ot][kt] = mfma(ada[ot], b, dw2[ot][kt]);
+                    if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    // d(x) of a block, left in T4 by the row team's step 6 (4-row mapping): wave q stores rows 16 q .. + 15, four whole
+    // 256-byte rows per instruction, through a per-block buffer resource (rows past N are dropped by its size)
+    auto store_dx = [&](long blk) {
+        if constexpr (ROWS4) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const long left = N - blk * kWsRows;
+            const int rows = left < kWsRows ? (int)left : kWsRows;
+            const __amdgpu_buffer_rsrc_t ro =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(dx + blk * (long)(kWsRows * kW)), 0, rows * kW * 2, 0x00020000);
+            const int row = 16 * q + (lane >> 4), ch = lane & 15;
+            bf16x8 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const bf16x8*>(T4 + (row + 4 * i) * kNsLd + 8 * ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), ro, ((row + 4 * i) * kW + 8 * ch) * 2, 0, 0);
+        }
     };
     {
         __bf16* const TA = tiles;
@@ -1610,6 +1732,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             (void)va; (void)vb; (void)vp; (void)DLA; (void)DLB;
             for (int sl = 0; sl < 8; ++sl) lds_barrier();
 #else
+            const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x;
             if (vp) f5(TB);
             WS_SLOT_END(k, 0);
             if (va) f1(TA);
@@ -1617,6 +1740,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             if (vp) f7(TB);
             WS_SLOT_END(k, 2);
             if (va) f3(TA, DLA);
+            if (vp) store_dx(blk_a - (long)gridDim.x);        // B's d(x): in T4 since slot 1, T4 is rewritten in slot 5
             WS_SLOT_END(k, 3);
             if (vb) f1(TB);
             WS_SLOT_END(k, 4);
@@ -1625,6 +1749,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             if (vb) f3(TB, DLB);
             WS_SLOT_END(k, 6);
             if (va) f7(TA);
+            if (va) store_dx(blk_a);                          // A's d(x): in T4 since slot 6, T4 is rewritten in slot 0
             WS_SLOT_END(k, 7);
 #endif
         }

@@ -686,14 +686,15 @@ def main():
                 else:
                     others.append(obj)
         # the dense part ("MFMA utilisation for the dense part"): the head's GEMMs -- the three lattice layers
-        # and occ_proj, forward / d(input) through hipBLASLt, d(weight) through ver_wgrad_tn -- bracketed by HIP events on
+        # and occ_proj (which kernel runs which product: the `implementation` strings below) -- bracketed by HIP events on
         # the launch stream in the timed region; flops = 2 m k n of every GEMM AS EXECUTED (with the constant / pad columns
         # the operands carry, ~3 % over the useful count).  `whole_step` prices the USEFUL multiply-adds of one step
         # (473.9 GFLOP per viewpoint forward, x 3 with the two backward products) on the step time.
-        classes = (('ver_gemm_nn', 'forward of the lattice layers: ver_gemm_nn (csrc/ver_gemm.hip)'),
+        classes = (('ver_gemm_nn', 'forward of the lattice layers: ver_gemm_nn_segments, operands read from the lattice (csrc/ver_gemm.hip)'),
                    ('head_gemm_fwd', 'forward of occ_proj (and of small batches): hipBLASLt N x N'),
-                   ('head_gemm_dgrad', 'd(input): hipBLASLt N x T'),
-                   ('ver_wgrad_tn', 'd(weight): ver_wgrad_tn (csrc/ver_wgrad.hip)'))
+                   ('head_gemm_dgrad', 'd(input): lattice layers ver_gemm_nn_planes (one product per layer, operands read from the '
+                                       'gradient lattice), occ_proj ver_gemm_nn (832-column groups) / hipBLASLt (768-column groups)'),
+                   ('ver_wgrad_tn', 'd(weight): ver_wgrad_tn / ver_wgrad_tn_segments (csrc/ver_wgrad.hip)'))
         tot_f = tot_ms = 0.0
         for name, impl in classes:
             if name in kt and kt[name]['ms'] > 0:

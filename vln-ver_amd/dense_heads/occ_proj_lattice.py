@@ -33,6 +33,7 @@ import torch
 from .upsample import gemm_timed, rows_tn
 
 _PLAN_CACHE = {}
+_OWN_DGRAD = os.environ.get('VER_OCC_PROJ_OWN_DGRAD', '1') == '1'
 
 
 class _Plan:
@@ -321,8 +322,15 @@ class _OccProjLattice(torch.autograd.Function):
             # d(operand): data columns go back to their lattice positions (each written exactly once)
             if fused:
                 d_all = d_rows[spans[gi][0]:spans[gi][0] + spans[gi][1]].view(bs * g.n_rows, g.k_aug)
-                with gemm_timed('head_gemm_dgrad', go.shape[0], go.shape[1], wa.shape[1]):
-                    torch.mm(go, wa, out=d_all)
+                # operand widths that are not whole 256-column tiles (832 at the vocc.py sizes) go to ver_gemm_nn: the
+                # library's solution for [552 960, 4480] x [4480, 832] runs at 0.92 PFLOP/s, ours at 1.04 (4.49 -> 3.97 ms,
+                # three groups per step; scratch/r06/occproj_gemm_bench.py -- at 768 columns, and in the forward, they tie)
+                from .. import hipops
+                if _OWN_DGRAD and g.k_aug % 256 and go.shape[0] >= 14000 and hipops.gemm_nn_supported(go, wa):
+                    hipops.gemm_nn(go, wa, out=d_all, timer_class='head_gemm_dgrad')
+                else:
+                    with gemm_timed('head_gemm_dgrad', go.shape[0], go.shape[1], wa.shape[1]):
+                        torch.mm(go, wa, out=d_all)
                 d_const = d_all[:, g.n_cols:g.n_cols + Z]
             elif d_lat.is_cuda and g.run_len and dt in (torch.float32, torch.bfloat16):
                 # the Z constant columns sit right behind the data columns of W_aug: ONE GEMM returns both (their own

@@ -1261,10 +1261,11 @@ def gemm_nn_splits(m, k, n):
     return int(lib().ver_gemm_nn_splits(ctypes.c_long(m), int(k), int(n)))
 
 
-def gemm_nn(a, w, bias=None, out=None, splits=None):
+def gemm_nn(a, w, bias=None, out=None, splits=None, timer_class='ver_gemm_nn'):
     """``a @ w (+ bias)`` on ver_gemm_nn: a bf16 [M, K] (may be a column range of a wider row-major matrix), w bf16 [K, N]
     row-major, bias fp32 [N] or None -> bf16 [M, N] (``out``: a bf16 matrix with unit column stride to write into).
-    ``splits``: K slices (None: the library's choice -- 1 except for skinny operands; fp32 partial tiles, added up once)."""
+    ``splits``: K slices (None: the library's choice -- 1 except for skinny operands; fp32 partial tiles, added up once).
+    ``timer_class``: the name a KernelTimer files the launch under (bench.py's classes of the head's products)."""
     if not gemm_nn_supported(a, w):
         raise RuntimeError('gemm_nn: unsupported operands %s %s / %s %s' % (tuple(a.shape), a.stride(), tuple(w.shape), w.stride()))
     m, k = a.shape
@@ -1280,7 +1281,7 @@ def gemm_nn(a, w, bias=None, out=None, splits=None):
     if splits > 1 and (n % 4 or out.stride(0) % 4 or out.data_ptr() % 8):
         splits = 1
     ws = torch.empty(splits * m * n, dtype=torch.float32, device=a.device) if splits > 1 else None
-    _launch('ver_gemm_nn', lambda: lib().ver_gemm_nn_splitk(
+    _launch(timer_class, lambda: lib().ver_gemm_nn_splitk(
         _p(a), ctypes.c_long(a.stride(0)), _p(w), ctypes.c_long(w.stride(0)), _p(bias) if bias is not None else None,
         _p(out), ctypes.c_long(out.stride(0)), ctypes.c_long(m), k, n, int(splits), _p(ws) if ws is not None else None,
         ctypes.c_long(ws.numel() * 4 if ws is not None else 0), _stream()), meta=dict(flops=2.0 * m * k * n))

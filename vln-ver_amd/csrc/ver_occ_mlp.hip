@@ -1104,6 +1104,14 @@ constexpr int kWsRows = 64;
 #ifndef VER_WS_DW2_STEP7
 #define VER_WS_DW2_STEP7 1
 #endif
+#ifndef VER_WS_AHEAD
+#define VER_WS_AHEAD 2
+#endif
+#ifndef VER_WS_BIAS_LATE
+#define VER_WS_BIAS_LATE 0
+#endif
+constexpr bool kWsBiasLate = VER_WS_BIAS_LATE;         // step 1: b2 added to the finished tile (8 more registers) or the accumulators' start value
+constexpr int kWsAhead = VER_WS_AHEAD;                 // operand fragments requested ahead in the 64-row products of steps 1 and 5
 constexpr bool kWsDw2InStep7 = VER_WS_DW2_STEP7;       // d(W2) in step 7 (beside the row team's heavy LN2 backward) or in step 5
 constexpr int kWsTile = kWsRows * kNsLd;
 constexpr int kWsVec0 = kW;                                      // b1 is not staged (folded mode)
@@ -1132,6 +1140,8 @@ __device__ __forceinline__ int ws_tl_probe() { return (blockIdx.x % 29 == 3 && b
         if (pr_ >= 0 && (threadIdx.x & 63) == 0)                                                                    \
             g_ws_tl_span[(pr_ * 8 + (threadIdx.x >> 6)) * 2 + (which)] = (long long)__builtin_amdgcn_s_memtime();   \
     } while (0)
+// (-DVER_WS_TIMELINE_FINE: four more stamps inside the LayerNorm backward of slots 1 and 4; they cost those steps ~600 cycles)
+#ifdef VER_WS_TIMELINE_FINE
 __device__ long long g_ws_tl_fine[kWsTlProbes * 8 * kWsTlRounds * 8];
 #define WS_TLF(k, idx)                                                                                              \
     do {                                                                                                            \
@@ -1144,6 +1154,9 @@ __device__ long long g_ws_tl_fine[kWsTlProbes * 8 * kWsTlRounds * 8];
 extern "C" int ver_ws_timeline_fine_read(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_tl_fine), sizeof(long long) * kWsTlProbes * 8 * kWsTlRounds * 8);
 }
+#else
+#define WS_TLF(k, idx) do { } while (0)
+#endif
 extern "C" int ver_ws_timeline_read(long long* slots, long long* span) {
     hipError_t e = hipMemcpyFromSymbol(slots, HIP_SYMBOL(g_ws_tl), sizeof(long long) * kWsTlProbes * 8 * kWsTlRounds * 8 * 2);
     if (e != hipSuccess) return (int)e;
@@ -1223,6 +1236,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             // requests B's rows, B's step 0 (slot 3) consumes those and requests the next round's A rows -- three and five
             // slots of flight
             bf16x8 xn[4], dln;
+            f32x4 rsn[2];                       // ... and the block's saved 1/std, moved into its state in step 0
             Row4 sa, sb;
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const int dlrow = lane >> 1, dlh = lane & 1;            // d(logits) staging: lanes 0-31 of a wave, 16 rows x 2 halves
@@ -1241,21 +1255,22 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
             };
             // (the loads' results are bit_cast as a WHOLE: this hipcc compiles __builtin_bit_cast(float, v.y) of a vector element
             //  as a read of element 0, and an implicit conversion of the builtin's result to an ext_vector_type as a splat)
+            // EVERY global load of the row team is issued here, once per block, UNCONDITIONALLY (a block this workgroup does not
+            // have reads as zeros) and behind the step that consumed the buffer: the compiler then counts the loads in flight
+            // exactly (s_waitcnt vmcnt(n) at the first use, three slots later) and lands them in the buffer's own registers.
+            // Requested inside the conditional steps -- or the 1/std at the end of step 6, as round 5 had it -- every first use
+            // became vmcnt(0) behind whatever was requested last (~600 cycles in the longest step of the round).
+            // (1/std of rows past N: 0 -- the row contributes nothing)
             auto prefetch = [&](long blk) {
                 const __amdgpu_buffer_rsrc_t rx = block_rsrc(x, blk, kW * 2), rd = block_rsrc(dlog, blk, kC * 2);
+                const __amdgpu_buffer_rsrc_t rr = block_rsrc(rstd, blk, 8);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     xn[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + i * kW * 2, 0, 0));
                 dln = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rd, dloff, 0, 0));
-            };
-            // The saved 1/std of a state's NEXT block are requested at the end of its step 6, straight into the registers that
-            // step has just used for the last time (requested earlier they need a second set, and the register file is full;
-            // 1/std of rows past N: 0 -- the row contributes nothing).  First use: the state's step 0, one or two slots later.
-            auto prefetch_rs = [&](Row4& st, long blk) {
-                const __amdgpu_buffer_rsrc_t rr = block_rsrc(rstd, blk, 8);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    st.rsv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rsoff + 16 * j, 0, 0));
+                    rsn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, rsoff + 16 * j, 0, 0));
             };
 #define WS_RS1(st) {st.rsv[0].x, st.rsv[0].z, st.rsv[1].x, st.rsv[1].z}
 #define WS_RS2(st) {st.rsv[0].y, st.rsv[0].w, st.rsv[1].y, st.rsv[1].w}
@@ -1343,7 +1358,9 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 }
                 WS_TLF(tl_k, tl_base + 3);
             };
-            auto r0 = [&](Row4& st, __bf16* T, __bf16* DL, long blk) {
+            auto r0 = [&](Row4& st, __bf16* T, __bf16* DL) {
+                st.rsv[0] = rsn[0];
+                st.rsv[1] = rsn[1];
                 if (lane < 32) {
                     bf16x8 dl = dln;
                     if (gscale != 1.0f) {        // (wave-uniform) d(logits) arrives unscaled: ver_focal_loss_forward_grad
@@ -1355,9 +1372,6 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 }
                 const float rs[4] = WS_RS1(st);
                 ln_fwd4(xn, rs, g1v, b1v, st.xh1, T);
-                // (requested AFTER the last use of the buffer: issued first, the loads went to fresh registers and the step ended
-                //  with s_waitcnt vmcnt(0) + 14 moves into the buffer's own -- a full HBM round trip in every step 0)
-                prefetch(blk + (long)gridDim.x);                    // the block whose step 0 comes next (the other set)
             };
             auto r2 = [&](Row4& st, __bf16* T) {                                      // a2 (T1) -> LN2 + ReLU -> h2 (T2)
                 bf16x8 xr[4];
@@ -1378,7 +1392,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 ln_bwd4(d, h, st.xh2, rs, g2v, T + 2 * kWsTile, T + kWsTile,
                         [&](int i, bf16x8 v) { *reinterpret_cast<bf16x8*>(out + i * kNsLd) = v; });
             };
-            auto r6 = [&](Row4& st, __bf16* T, long blk_next) {  // d(h1) (T4), h1 (T0) -> LN1 bwd -> d(x) T4 (in place); d(z1) T2, n1 T1
+            auto r6 = [&](Row4& st, __bf16* T) {                 // d(h1) (T4), h1 (T0) -> LN1 bwd -> d(x) T4 (in place); d(z1) T2, n1 T1
                 bf16x8 d[4], h[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1391,15 +1405,10 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 const float rs[4] = WS_RS1(st);
                 ln_bwd4(d, h, st.xh1, rs, g1v, T + 2 * kWsTile, T + kWsTile,
                         [&](int i, bf16x8 v) { *reinterpret_cast<bf16x8*>(out + i * kNsLd) = v; });
-#ifndef VER_WS_ABL_NORS
-                prefetch_rs(st, blk_next);
-#endif
             };
             __bf16* const TA = tiles;
             __bf16* const TB = tiles + 4 * kWsTile;
             prefetch(blockIdx.x);
-            prefetch_rs(sa, blockIdx.x);
-            prefetch_rs(sb, blockIdx.x + (long)gridDim.x);
             for (long k = 0; k < rounds; ++k) {
                 const bool va = 2 * k < nmine, vb = 2 * k + 1 < nmine, vp = k > 0 && 2 * k - 1 < nmine;
                 const long blk_a = blockIdx.x + (2 * k) * (long)gridDim.x, blk_b = blk_a + gridDim.x;
@@ -1407,20 +1416,16 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 for (int sl = 0; sl < 8; ++sl) lds_barrier();
                 continue;
 #endif
-                // Everything in flight here is what step 0 of A is about to use (its rows since slot 3, its 1/std since slot
-                // 6).  Said ONCE and unconditionally: the compiler cannot count loads across the conditional steps of a round,
-                // and without this it waits for vmcnt(0) at the first use of B's 1/std in slot 1 -- behind the rows requested
-                // in slot 0, a full HBM round trip in the longest step of the round.
-                __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
-                if (va) r0(sa, TA, DLs, blk_a);
+                if (va) r0(sa, TA, DLs);
+                prefetch(blk_b);                                    // B's block of this round: step 0 in slot 3
                 WS_SLOT_END(k, 0);
                 tl_k = k; tl_base = 4;
-                if (vp) r6(sb, TB, blk_b);
+                if (vp) r6(sb, TB);
                 WS_SLOT_END(k, 1);
                 if (va) r2(sa, TA);
                 WS_SLOT_END(k, 2);
-                __builtin_amdgcn_s_waitcnt(0x0F70);                 // (the same for B: its rows since slot 0, its 1/std since slot 1)
-                if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd, blk_b);
+                if (vb) r0(sb, TB, DLs + kWsRows * kNsDlLd);
+                prefetch(blk_a + 2 * (long)gridDim.x);              // A's block of the next round: step 0 in slot 0
                 WS_SLOT_END(k, 3);
                 tl_base = 0;
                 if (va) r4(sa, TA);
@@ -1428,7 +1433,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 WS_SLOT_END(k, 4);
                 if (vb) r2(sb, TB);
                 WS_SLOT_END(k, 5);
-                if (va) r6(sa, TA, blk_a + 2 * (long)gridDim.x);
+                if (va) r6(sa, TA);
                 WS_SLOT_END(k, 6);
                 if (vb) r4(sb, TB);
                 WS_SLOT_END(k, 7);
@@ -1592,29 +1597,47 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) dw2[ot][kt] = zero4;
     }
-    // The four product steps are SOFTWARE PIPELINED by hand (round 5): a lone wave per SIMD has nothing to switch to while an
-    // LDS read is in flight, and written as "read a fragment, use it" every group of 2-4 MFMAs waited for a full LDS round
-    // trip -- ~60 exposed round trips per block: the feature team ALONE took as long as the whole kernel (29.8 ms per 96.8 M
-    // rows with -DVER_WS_ABL_NOROW; the row team alone 24).  Every step now requests all the operands of a group of 6-16 MFMAs
-    // up front (and the next row tile's while the current one is multiplied); the scheduling barriers pin that order and keep
-    // the compiler from hoisting every read of a step to its top (128+ VGPRs).
-    auto f1 = [&](__bf16* T) {                                            // a2 = W2 h1 + b2: T0 -> T1
+    // The product steps of the feature team are LATENCY bound, and the register file is why: 188 of a wave's 256 registers hold
+    // weights and accumulators for the whole kernel, and with what was left hipcc kept ONE operand fragment in flight in steps 1
+    // and 5 ("ds_read_b128, s_waitcnt lgkmcnt(0), two MFMAs" sixteen times: 2.6 k cycles for 0.5 k cycles of matrix work).
+    // Round 6: (a) the fully pipelined form (all four k-step fragments of a 16-row tile requested together, the next tile's before
+    // the current one is multiplied; b2 added to the finished tile) compiles as written, runs step 1 in 2.15 k -- LDS contention
+    // with the row team's step keeps it there -- and its 40 extra registers spill accumulators to scratch INSIDE the round:
+    // 24.1 -> 31.4 ms; (b) a ring of THREE fragments (two requested ahead) fits: steps 1 / 5 2.6 / 2.5 -> 2.2 / 2.05 k,
+    // 24.1 -> 23.1 ms; (c) the same ring for the transposed fragments of d(W2) in step 7 spills again and is not used.
+    // (what fits: a ring of kWsAhead + 1 fragments -- the fragment of k-step i + kWsAhead is requested before k-step i is multiplied)
+    auto rows_product = [&](const __bf16* src, __bf16* dst, const bf16x8 (&w)[OT][4], const float* init) {
+        constexpr int NF = 4 * RT, RING = kWsAhead + 1;
+        bf16x8 b[RING];
+        auto frag = [&](int i) { return *reinterpret_cast<const bf16x8*>(src + (16 * (i >> 2) + c) * kNsLd + 32 * (i & 3) + 8 * g); };
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            f32x4 acc[OT];
+        for (int i = 0; i < kWsAhead; ++i) b[i] = frag(i);
+        f32x4 acc[OT], bias[OT];
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) acc[ot] = *reinterpret_cast<const f32x4*>(sv + 3 * kW + f0 + 16 * ot + 4 * g);
+        for (int i = 0; i < NF; ++i) {
+            const int rt = i >> 2, ks = i & 3;
+            if (i + kWsAhead < NF) b[(i + kWsAhead) % RING] = frag(i + kWsAhead);
+            // (the bias is ADDED to the finished tile, not the accumulators' start value: requested here it has four k-steps to
+            //  arrive; as the start value every tile began with an exposed LDS round trip)
+            if (ks == 0 && init) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
-#pragma unroll
-                for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma(wa2[ot][ks], b, acc[ot]);
+                for (int ot = 0; ot < OT; ++ot) bias[ot] = *reinterpret_cast<const f32x4*>(init + 16 * ot);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool late = kWsBiasLate || !init;
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
-                *reinterpret_cast<bf16x4*>(T + kWsTile + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) = pack4(acc[ot]);
+            for (int ot = 0; ot < OT; ++ot) acc[ot] = mfma(w[ot][ks], b[i % RING], ks == 0 ? (late ? zero4 : bias[ot]) : acc[ot]);
+            if (ks == 3) {
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+                    *reinterpret_cast<bf16x4*>(dst + (16 * rt + c) * kNsLd + f0 + 16 * ot + 4 * g) =
+                        pack4(init && kWsBiasLate ? acc[ot] + bias[ot] : acc[ot]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto f1 = [&](__bf16* T) {                                            // a2 = W2 h1 + b2: T0 -> T1
+        rows_product(T, T + kWsTile, wa2, sv + 3 * kW + f0 + 4 * g);
     };
     auto f3 = [&](__bf16* T, __bf16* DL) {                                 // d(h2) = W3^T d(logits) -> T1; d(W3), d(b3) from DL, T2
 #pragma unroll
@@ -1659,22 +1682,7 @@ __global__ __launch_bounds__(512) void k_occ_mlp_bwd_ws(const __bf16* __restrict
                 }
             }
         }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            f32x4 acc[OT];
-#pragma unroll
-            for (int kt = 0; kt < OT; ++kt) acc[kt] = zero4;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(T + 3 * kWsTile + (16 * rt + c) * kNsLd + 32 * ks + 8 * g);
-#pragma unroll
-                for (int kt = 0; kt < OT; ++kt) acc[kt] = mfma(wb2[kt][ks], b, acc[kt]);
-            }
-#pragma unroll
-            for (int kt = 0; kt < OT; ++kt)
-                *reinterpret_cast<bf16x4*>(T4 + (16 * rt + c) * kNsLd + f0 + 16 * kt + 4 * g) = pack4(acc[kt]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        rows_product(T + 3 * kWsTile, T4, wb2, nullptr);
     };
     // d(W2) += d(a2)^T h1 runs HERE, not in step 5 beside the product that step 6 waits for: nothing downstream reads it, T3
     // (d(a2)) and T0 (h1) stay untouched until the block's set starts over (step 6 puts n1 into T1), and step 7 was 0.5 k

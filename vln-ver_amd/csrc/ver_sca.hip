@@ -360,6 +360,14 @@ __device__ __forceinline__ int tl_probe() {
         if ((int)blockIdx.x == (int)(((long)nb * (2 * i + 1)) / (2 * kTlProbes))) return i;
     return -1;
 }
+// (VER_TLQ: the probe index looked up ONCE per kernel -- `const int tlq_pr = tl_probe();` -- the 32-step search of VER_TL costs a
+//  stamp ~2 k cycles, more than the phases of k_sca_bwd_mm it is meant to time)
+#define VER_TLQ_INIT const int tlq_pr = tl_probe()
+#define VER_TLQ(ev)                                                                                       \
+    do {                                                                                                  \
+        if (tlq_pr >= 0 && (threadIdx.x & 63) == 0 && (ev) < 64)                                           \
+            g_tl[(tlq_pr * 16 + (threadIdx.x >> 6)) * 64 + (ev)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 #define VER_TL(ev)                                                                                        \
     do {                                                                                                  \
         const int pr_ = tl_probe();                                                                       \
@@ -371,6 +379,8 @@ extern "C" int ver_timeline_read(long long* out, int n) {
 }
 #else
 #define VER_TL(ev) do { } while (0)
+#define VER_TLQ(ev) do { } while (0)
+#define VER_TLQ_INIT do { } while (0)
 #endif
 
 template <int N>
@@ -1759,6 +1769,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     bid /= heads;
     const int c = bid % Ncam, b = bid / Ncam;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (said out loud: without it every `wave + NW * i < tiles` below is a run-time branch, and a fragment read cannot be hoisted
+    //  over a branch -- the D^T phase compiled to "ds_read_b128, s_waitcnt lgkmcnt(0), one MFMA" 21 times per chunk)
+    __builtin_assume(wave >= 0 && wave < NW);
     const int cc = lane & 15, g = lane >> 4;
     const bool scalar = tid < 256;                    // this thread is a (voxel, point) of the scalar phases
     const int vloc = (tid & 255) >> 3, p = tid & 7;   // voxel of the chunk, sampling point
@@ -1788,11 +1801,14 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     // chunks: voxel ids two chunks ahead, everything that hangs off the id one chunk ahead (a chunk is ~2 us of work;
     // without this every chunk started with two dependent global-memory latencies)
     constexpr int SEG = HD / 8;                        // floats of the grad row this thread converts (12)
+    // (the grad-row segment stays as LOADED: unpacking bf16 -> float at load time made the compiler wait for the loads it had
+    //  just issued -- s_waitcnt vmcnt(3) / vmcnt(2) in every chunk, a global round trip in front of the first barrier)
+    typedef typename std::conditional<GBF, uint2, float4>::type GRaw;
     struct Ops {
         unsigned m;
         float lg;
         float2 of, u;
-        float gf[SEG];
+        GRaw graw[SEG / 4];
     };
     auto entry_of = [&](int e0, bool& live, bool& multi) -> int {     // voxel id (clamped to a live one), flags
         const int e = e0 + vloc;
@@ -1812,16 +1828,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
         o.u = *reinterpret_cast<const float2*>(uv + ((((size_t)b * Ncam + c) * Nq + n) * D + ad) * 2);
         const GST* grow = gslots + qh * HD + p * SEG;
 #pragma unroll
-        for (int i = 0; i < SEG / 4; ++i) {
-            if constexpr (GBF) {
-                const uint2 t2 = *reinterpret_cast<const uint2*>(grow + 4 * i);
-                o.gf[4 * i] = __uint_as_float(t2.x << 16); o.gf[4 * i + 1] = __uint_as_float(t2.x & 0xffff0000u);
-                o.gf[4 * i + 2] = __uint_as_float(t2.y << 16); o.gf[4 * i + 3] = __uint_as_float(t2.y & 0xffff0000u);
-            } else {
-                const float4 t4 = *reinterpret_cast<const float4*>(grow + 4 * i);
-                o.gf[4 * i] = t4.x; o.gf[4 * i + 1] = t4.y; o.gf[4 * i + 2] = t4.z; o.gf[4 * i + 3] = t4.w;
-            }
-        }
+        for (int i = 0; i < SEG / 4; ++i) o.graw[i] = *reinterpret_cast<const GRaw*>(grow + 4 * i);
         return o;
     };
     bool live_c = false, multi_c = false, live_n = false, multi_n = false;
@@ -1829,9 +1836,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
     int n_n = (scalar && total > 32) ? entry_of(32, live_n, multi_n) : 0;
     Ops ops = {};
     if (scalar && total > 0) ops = load_ops(n_c);
-    VER_TL(0);
+    VER_TLQ_INIT;
+    VER_TLQ(0);
     for (int e0 = 0; e0 < total; e0 += 32) {
-        if (e0 == 64) VER_TL(1);
+        if (e0 == 64) VER_TLQ(1);
         const bool live = live_c, multi = multi_c;     // multi is wave-uniform
         const int n = n_c;
         const unsigned m = live ? ops.m : 0u;
@@ -1845,9 +1853,18 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
 #pragma unroll
             for (int i = 0; i < SEG / 4; ++i) {
                 __bf16 hi[4], lo[4];
+                float gf[4];
+                if constexpr (GBF) {
+                    const uint2 t2 = ops.graw[i];
+                    gf[0] = __uint_as_float(t2.x << 16); gf[1] = __uint_as_float(t2.x & 0xffff0000u);
+                    gf[2] = __uint_as_float(t2.y << 16); gf[3] = __uint_as_float(t2.y & 0xffff0000u);
+                } else {
+                    const float4 t4 = ops.graw[i];
+                    gf[0] = t4.x; gf[1] = t4.y; gf[2] = t4.z; gf[3] = t4.w;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float gs = ops.gf[4 * i + j] * icnt;
+                    const float gs = gf[j] * icnt;
                     hi[j] = (__bf16)gs;
                     lo[j] = (__bf16)(gs - (float)hi[j]);
                 }
@@ -1861,10 +1878,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
         multi_c = multi_n;
         if (scalar && e0 + 32 < total) ops = load_ops(n_c);
         if (scalar && e0 + 64 < total) n_n = entry_of(e0 + 64, live_n, multi_n);
-        if (e0 == 64) VER_TL(2);
+        if (e0 == 64) VER_TLQ(2);
         if (e0 == 0) __builtin_amdgcn_s_waitcnt(0);   // the tile's LDS-DMA has landed
         __syncthreads();
-        if (e0 == 64) VER_TL(3);
+        if (e0 == 64) VER_TLQ(3);
         // ---------------- D^T[k][v] = sum_ch V[k][ch] G[v][ch]   (A = tile rows, B = grad rows, both row-major in LDS)
         // The 2 x KS grad-row fragments (hi, lo) are read once per chunk; the MT x 2 output tiles are dealt to the waves
         // one by one (26 tiles over 4 waves: 7, 7, 6, 6).
@@ -1888,6 +1905,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                 for (int ui = 0; ui < UMAX; ++ui) {
+                    // (with the range of `wave` known -- __builtin_assume above -- only a wave's LAST tile is conditional;
+                    //  computing it unconditionally on a clamped index measured the same: 425-430 against 429-431 us)
                     const int un = wave + NW * ui;
                     if (un < 2 * MT) {
                         const int mt = un >> 1, nt = un & 1;
@@ -1911,9 +1930,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
                 }
             }
         }
-        if (e0 == 64) VER_TL(4);
+        if (e0 == 64) VER_TLQ(4);
         __syncthreads();
-        if (e0 == 64) VER_TL(5);
+        if (e0 == 64) VER_TLQ(5);
         // ---------------- this thread's sample: pick its four dots, d(offset), d(logit), and its four events
         float coef[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         int key[4] = {0, 0, 0, 0};
@@ -1948,20 +1967,28 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
                 }
             }
         }
-        if (e0 == 64) VER_TL(6);
-        __syncthreads();
-        if (e0 == 64) VER_TL(7);
-        // ---------------- S^T[k][v]: zero, then add the chunk's events
-        for (int i = tid; i < Nk * kMmDss / 4; i += NW * 64) reinterpret_cast<float4*>(DS)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        __syncthreads();
-        if (e0 == 64) VER_TL(8);
+        if (e0 == 64) VER_TLQ(6);
+        // ---------------- S^T[k][v]: zero, then add the chunk's events.  COLUMN-LOCAL (round 6): a sample reads its dots from
+        // column vloc of DS and adds its events into column vloc, and the eight points of a voxel sit in one wave -- so the
+        // columns 8 w .. 8 w + 7 belong to scalar wave w from the sample phase to the scatter: it zeroes them itself (rows on the
+        // lanes, 32 bytes per row) and no workgroup barrier is needed in between (LDS operations of a wave complete in order).
+        // Two barriers and a workgroup-wide zero pass (0.9 k of a chunk's 8 k cycles) less.
+        if (scalar) {
+            float* col = DS + 8 * wave;
+            for (int r = lane; r < Nk; r += 64) {
+                *reinterpret_cast<float4*>(col + r * kMmDss) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                *reinterpret_cast<float4*>(col + r * kMmDss + 4) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if (e0 == 64) VER_TLQ(7);
+        if (e0 == 64) VER_TLQ(8);
 #pragma unroll
         for (int t = 0; t < 4; ++t)          // S <= 1: 2^-30 fixed point, integer LDS atomics (float ones retire ~0.5 lane/clk)
             if (coef[t] != 0.0f)
                 atomicAdd(reinterpret_cast<unsigned*>(DS) + key[t] * kMmDss + vloc, __float2uint_rn(coef[t] * 1073741824.0f));
-        if (e0 == 64) VER_TL(9);
+        if (e0 == 64) VER_TLQ(9);
         __syncthreads();
-        if (e0 == 64) VER_TL(10);
+        if (e0 == 64) VER_TLQ(10);
         // ---------------- d(value)[k][ch] += sum_v S^T[k][v] G[v][ch]   (B = grad rows read transposed: 8 voxels of one channel)
         mm_bf16x8 bh[NT], bl[NT];
         {
@@ -1999,11 +2026,11 @@ __global__ __launch_bounds__(NW * 64, 2) void k_sca_bwd_mm(
                 }
             }
         }
-        if (e0 == 64) VER_TL(11);
+        if (e0 == 64) VER_TLQ(11);
         __syncthreads();
-        if (e0 == 64) VER_TL(12);
+        if (e0 == 64) VER_TLQ(12);
     }
-    VER_TL(13);
+    VER_TLQ(13);
     // ---------------- d(value) tile of this (camera, head): written in full (zeros for a camera that sees nothing)
     GVT* gv = gvalue + ((size_t)b * Ncam + c) * Nk * rstride + (size_t)h * HD;
 #pragma unroll

@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
     for (int i = threadIdx.x; i < kFwdFrags * 64; i += 256) frag[i] = reinterpret_cast<const bf16x8*>(img)[i];
     for (int i = threadIdx.x; i < kVecFloats; i += 256) sv[i] = vec[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (wave index as a SCALAR: the per-block buffer resource below is built from it; as a vector value every load through the
+    //  resource becomes a readfirstlane loop)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
     const long nblk = (N + 16 * RT - 1) / (16 * RT);
     // (stores beyond row N - 1, and those of the lanes g != 0 -- sent there on purpose -- fall outside the range and are dropped)
@@ -277,14 +279,18 @@ __global__ __launch_bounds__(256, 2) void k_occ_mlp_fwd(const __bf16* __restrict
         const bf16x8* fr = frag + lane_off;
         const float* sv_g = sv + 4 * (lane_off >> 4);
         bf16x8 bf[RT][4];
+        {
+            // the block's rows through ONE buffer resource (base = its first row, size = its rows below N): sixteen
+            // unconditional loads issued back to back, rows past N read as zeros.  (As `r < N ? load : 0` every load sat in its
+            // own basic block behind a branch.)
+            const long left = N - r0;
+            const int rows = left < 16 * RT ? (int)left : 16 * RT;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + r0 * kW), 0, rows * kW * 2, 0x00020000);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const long r = r0 + rt * 16 + c;
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                bf[rt][kt] = r < N ? *reinterpret_cast<const bf16x8*>(x + r * kW + 32 * kt + 8 * g) : z;
-            }
+                for (int kt = 0; kt < 4; ++kt)
+                    bf[rt][kt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rx, ((rt * 16 + c) * kW + 32 * kt + 8 * g) * 2, 0, 0));
         }
         if constexpr (!L1) {
             const float* sv_n = sv + 8 * (lane_off >> 4);

@@ -756,6 +756,41 @@ def test_occ_proj_lattice_fused_rows_path_is_bit_identical(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_occ_proj_lattice_input_gradient_on_ver_gemm_nn_equals_the_library(monkeypatch):
+    """d(input) of ``occ_proj``'s 832-column groups runs on ``ver_gemm_nn`` from 14 000 rows per group on (round 6:
+    dense_heads/occ_proj_lattice.py, ``_OWN_DGRAD``); five viewpoints = 14 400 rows per group.  Same operands, fp32 accumulation
+    either way: the lattice gradient agrees with the library's product to bf16 rounding (rel. L2 < 2e-3, most elements identical),
+    everything that does not pass through that product is bit-identical, and the kernel did run for three of the five groups."""
+    opl, hip = pkg('dense_heads.occ_proj_lattice'), pkg('hipops')
+    from util import rel_l2
+    gen = torch.Generator(device='cpu').manual_seed(44)
+    C, Z, hh, wh, bs = 768, 4, 30, 30, 5
+    e0 = (torch.randn(4, bs, 2, hh, wh, 2, C, generator=gen) * 0.5).bfloat16().to(DEV)
+    up_bias = torch.randn(C, generator=gen).to(DEV)
+    weight = (torch.randn(4480, Z * C, generator=gen) * 0.02).to(DEV)
+    bias = torch.randn(4480, generator=gen).to(DEV)
+    calls = []
+    real = hip.gemm_nn
+    monkeypatch.setattr(hip, 'gemm_nn', lambda *a, **k: (calls.append((tuple(a[0].shape), tuple(a[1].shape), k.get('timer_class'))), real(*a, **k))[1])
+    res = {}
+    for own in (False, True):
+        monkeypatch.setattr(opl, '_OWN_DGRAD', own)
+        e, ub, w, b = (t.clone().requires_grad_(True) for t in (e0, up_bias, weight, bias))
+        rows, plan = opl.occ_proj_from_lattice(e, ub, w, b)
+        g = torch.randn(rows.shape, generator=torch.Generator(device='cpu').manual_seed(5)).bfloat16().to(DEV)
+        n_before = len(calls)
+        rows.backward(g)
+        res[own] = (rows.detach(), e.grad, ub.grad, w.grad, b.grad, len(calls) - n_before)
+    assert res[False][5] == 0 and res[True][5] == 3, (res[False][5], res[True][5])
+    assert all(c == ((bs * 2880, 4480), (4480, 832), 'head_gemm_dgrad') for c in calls), calls
+    assert torch.equal(res[False][0], res[True][0])                       # forward untouched
+    assert torch.equal(res[False][3], res[True][3]) and torch.equal(res[False][4], res[True][4])      # d(weight), d(bias)
+    r = rel_l2(res[True][1].float(), res[False][1].float())
+    same = float((res[True][1] == res[False][1]).float().mean())
+    assert r < 2e-3 and same > 0.9, (r, same)
+    assert rel_l2(res[True][2], res[False][2]) < 1e-3                      # d(up_bias): column sums of the same product
+
+
 def test_upsample_on_gpu_matches_conv_transpose():
     up = pkg('dense_heads.upsample')
     gen = torch.Generator(device='cpu').manual_seed(6)
